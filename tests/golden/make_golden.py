@@ -1,0 +1,374 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own code (imported from /root/reference/src).
+
+Run in the build container only (`python tests/golden/make_golden.py`); /root/reference does not exist on
+the GPU box and nothing under tests/ reads it at test time -- only the small .npz fixtures travel.
+
+The reference has no tests or golden vectors of its own and ships no weights, so
+the vectors are its outputs on the synthetic weights/inputs of avcer_amd/synth.py (bit-identical on every box).
+Harness-side shims (none of them touch arithmetic on the hot path):
+  * cv2 / torchvision / torchaudio are absent: stubbed in sys.modules. PILToTensor is restated as the u8
+    HWC->CHW view it is; cv2.imread serves in-memory frames; torch.load / os.listdir serve synthetic data.
+  * transformers 5.x (installed) vs 4.36.2 (pinned): `init_weights()` is made a no-op (all weights are
+    overwritten by load_state_dict) and attention is forced to the pinned eager matmul-softmax-matmul.
+"""
+from __future__ import annotations
+
+import ast
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/src"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from avcer_amd import synth  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def stats(t):
+    t = t.detach().float()
+    return np.array([t.mean().item(), t.abs().max().item(), t.std().item()], dtype=np.float64)
+
+
+def head16(t):
+    return t.detach().float().reshape(-1)[:16].numpy().copy()
+
+
+# ----------------------------------------------------------------------------- stubs
+FRAME_STORE: dict[str, np.ndarray] = {}
+
+
+def install_stubs():
+    cv2 = types.ModuleType("cv2")
+    cv2.COLOR_BGR2RGB = 4
+    cv2.imread = lambda p: FRAME_STORE[os.path.basename(p)][..., ::-1].copy()  # RGB store -> BGR like cv2
+    cv2.cvtColor = lambda img, code: img[..., ::-1].copy()
+    cv2.resize = None
+    cv2.imwrite = None
+    sys.modules["cv2"] = cv2
+
+    tv = types.ModuleType("torchvision")
+    tr = types.ModuleType("torchvision.transforms")
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class PILToTensor:
+        def __call__(self, img):
+            return torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).contiguous()
+
+    tr.Compose, tr.PILToTensor = Compose, PILToTensor
+    tv.transforms = tr
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.transforms"] = tr
+    sys.modules["torchaudio"] = types.ModuleType("torchaudio")
+    vis = types.ModuleType("visualization.visualize")
+    vis.show_cam_on_image = None
+    vis.plot_compound_expression_prediction = None
+    pkg = types.ModuleType("visualization")
+    pkg.visualize = vis
+    sys.modules["visualization"] = pkg
+    sys.modules["visualization.visualize"] = vis
+
+
+# ----------------------------------------------------------------------------- F1/F2/F3 visual
+def gen_visual():
+    from architectures.video import ResNet50, LSTMPyTorch
+    import data.utils as du
+
+    sd_s = synth.to_torch(synth.static_state_dict(42))
+    sd_d = synth.to_torch(synth.dynamic_state_dict(42))
+    net = ResNet50(7, channels=3)
+    net.load_state_dict(sd_s)
+    net.eval()
+    lstm = LSTMPyTorch()
+    lstm.load_state_dict(sd_d)
+    lstm.eval()
+
+    # F1: static CNN, B=8 (BASELINE config 1)
+    from PIL import Image
+
+    frames = synth.face_frames(1234, 8)
+    x = torch.cat([du.pth_processing(Image.fromarray(f)) for f in frames])
+    out = {"pre_head16": head16(x), "pre_stats": stats(x)}
+    taps = {}
+    hooks = [
+        net.max_pool.register_forward_hook(lambda m, i, o: taps.__setitem__("stem", o)),
+        net.avgpool.register_forward_hook(lambda m, i, o: taps.__setitem__("avgpool", o)),
+        net.fc1.register_forward_hook(lambda m, i, o: taps.__setitem__("features", o)),
+    ]
+    for li in range(1, 5):
+        hooks.append(getattr(net, f"layer{li}").register_forward_hook(
+            lambda m, i, o, li=li: taps.__setitem__(f"layer{li}", o)))
+    with torch.no_grad():
+        logits = net(x)
+        probs = torch.nn.functional.softmax(logits, dim=1)
+    for h in hooks:
+        h.remove()
+    for k, v in taps.items():
+        out[f"{k}_stats"] = stats(v)
+        out[f"{k}_head16"] = head16(v)
+    out.update(logits=logits.numpy(), probs=probs.numpy(), feats=taps["features"].numpy())
+    # non-224 crop through the reference's PIL NEAREST resize
+    odd = synth.u8(77, "odd", (150, 131, 3))
+    out["resize_in_shape"] = np.array(odd.shape)
+    out["resize_out"] = du.pth_processing(Image.fromarray(odd))[0, :, ::16, ::16].numpy()
+    np.savez_compressed(os.path.join(HERE, "static.npz"), **out)
+    print("static: logits spread", logits.std().item(), "probs max", probs.max(dim=1).values.numpy())
+    for k in ("stem", "layer1", "layer2", "layer3", "layer4", "avgpool", "features"):
+        print("  ", k, out[f"{k}_stats"])
+
+    # F2: LSTM, 4 windows incl. the first-frame-x10 case
+    w = np.maximum(synth.centered(5, "lstm_in", (4, 10, 512), 1.0), 0).astype(np.float32)
+    w[0] = w[0, 0]
+    with torch.no_grad():
+        lo = lstm(torch.from_numpy(w))
+    np.savez_compressed(os.path.join(HERE, "lstm.npz"), logits=lo.numpy())
+    print("lstm logits", lo.numpy()[0])
+
+    # F3: harness semantics of get_prob_video.preprocess_video_and_predict through stubs
+    real_load, real_listdir = torch.load, os.listdir
+    torch.load = lambda p, *a, **k: sd_s if "static" in p else sd_d
+    import get_prob_video as gpv
+
+    torch.load = real_load
+    out3 = {}
+    clip = synth.face_frames(4321, 16)
+    cases = {
+        "gap25": (25, [1] * 6 + [0] * 3 + [1] * 7),
+        "gap30": (30, [1] * 4 + [0] * 2 + [1] * 10),
+        "lead25": (25, [0, 1, 0, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1]),
+        "full25": (25, [1] * 16),
+    }
+    for name, (fps, present) in cases.items():
+        FRAME_STORE.clear()
+        names = []
+        for i, p in enumerate(present):
+            if p:
+                FRAME_STORE[f"{i:06d}.jpg"] = clip[i]
+                names.append(f"{i:06d}.jpg")
+        os.listdir = lambda p, names=names: list(names)
+        df_d, df_s = gpv.preprocess_video_and_predict(path_images="/nonexistent/clip", fps=fps, total_frames=16)
+        os.listdir = real_listdir
+        out3[f"{name}_static"] = df_s.values
+        out3[f"{name}_dynamic"] = df_d.values
+        out3[f"{name}_present"] = np.array(present, dtype=np.bool_)
+        out3[f"{name}_fps"] = np.array(fps)
+        assert list(df_s.columns) == ["Neutral", "Happiness", "Sadness", "Surprise", "Fear", "Disgust", "Anger"]
+    np.savez_compressed(os.path.join(HERE, "visual_harness.npz"), **out3)
+    print("harness dtypes", {k: v.dtype for k, v in out3.items() if k.endswith("static")})
+
+
+# ----------------------------------------------------------------------------- F4/F5/F6 audio
+def w2v_config():
+    from transformers import Wav2Vec2Config
+
+    return Wav2Vec2Config(
+        hidden_size=1024, num_hidden_layers=12, num_attention_heads=16, intermediate_size=4096,
+        conv_dim=[512] * 7, conv_kernel=[10, 3, 3, 3, 3, 2, 2], conv_stride=[5, 2, 2, 2, 2, 2, 2],
+        feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True,
+        num_conv_pos_embeddings=128, num_conv_pos_embedding_groups=16,
+        hidden_act="gelu", feat_extract_activation="gelu", layer_norm_eps=1e-5,
+        attn_implementation="eager")
+
+
+def gen_audio():
+    import data.utils as du
+    from transformers import Wav2Vec2FeatureExtractor
+    from transformers.models.wav2vec2.modeling_wav2vec2 import Wav2Vec2PreTrainedModel
+
+    Wav2Vec2PreTrainedModel.init_weights = lambda self: None
+    from architectures.audio_8_cl import ExprModelV3
+
+    proc = Wav2Vec2FeatureExtractor(feature_size=1, sampling_rate=16000, padding_value=0.0,
+                                    do_normalize=True, return_attention_mask=True)
+
+    # F4: padding + normaliser
+    out4 = {}
+    win = 4000
+    for n in (1, 999, 4000, 4001):
+        wav = torch.from_numpy(synth.waveforms(9, 1, n)[0])
+        for mode in ("mean", "constant"):
+            p = du.pad_wav_zeros(wav, win, mode=mode)
+            out4[f"pad_{mode}_{n}"] = p.numpy()
+            a = proc(torch.unsqueeze(p, 0), sampling_rate=16000)["input_values"][0]
+            out4[f"norm_{mode}_{n}"] = np.asarray(a)
+        out4[f"pad_repeat_{n}"] = du.pad_wav(wav, win).numpy()
+    empty = du.pad_wav_zeros(torch.zeros(0), 8, mode="mean")
+    out4["pad_mean_0"] = empty.numpy()
+    np.savez_compressed(os.path.join(HERE, "audio_pad.npz"), **out4)
+
+    # F5: ExprModelV3 with synthetic weights
+    sd = synth.to_torch(synth.audio_state_dict(42))
+    model = ExprModelV3(w2v_config())
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    model.eval()
+    n_w2v = sum(p.numel() for p in model.wav2vec2.parameters())
+    n_all = sum(p.numel() for p in model.parameters())
+    print("audio params", n_w2v, n_all)
+    out5 = {"n_params": np.array([n_w2v, n_all])}
+    taps = {}
+    w2 = model.wav2vec2
+    hooks = [
+        w2.feature_extractor.conv_layers[0].register_forward_hook(lambda m, i, o: taps.__setitem__("conv0", o)),
+        w2.feature_extractor.register_forward_hook(lambda m, i, o: taps.__setitem__("extract", o.transpose(1, 2))),
+        w2.feature_projection.register_forward_hook(lambda m, i, o: taps.__setitem__("proj", o[0])),
+        w2.encoder.register_forward_hook(lambda m, i, o: taps.__setitem__("w2v", o[0])),
+        model.tl1.register_forward_hook(lambda m, i, o: taps.__setitem__("tl1", o)),
+        model.tl2.register_forward_hook(lambda m, i, o: taps.__setitem__("tl2", o)),
+    ]
+    for li in (0, 5, 11):
+        hooks.append(w2.encoder.layers[li].register_forward_hook(
+            lambda m, i, o, li=li: taps.__setitem__(f"layer{li}", o[0] if isinstance(o, tuple) else o)))
+    wav2 = synth.waveforms(5678, 2, 32000)
+    wav4 = synth.waveforms(5679, 1, 64000)
+    for tag, wv in (("t32000", wav2), ("t64000", wav4)):
+        x = np.stack([np.asarray(proc(torch.from_numpy(r[None]), sampling_rate=16000)["input_values"][0])[0]
+                      for r in wv])
+        taps.clear()
+        with torch.no_grad():
+            lg = model(torch.from_numpy(x))
+        out5[f"{tag}_logits"] = lg.numpy()
+        out5[f"{tag}_input_head16"] = x.reshape(-1)[:16].copy()
+        for k, v in taps.items():
+            out5[f"{tag}_{k}_stats"] = stats(v)
+            out5[f"{tag}_{k}_head16"] = head16(v)
+            out5[f"{tag}_{k}_shape"] = np.array(v.shape)
+        print(tag, "logits", lg.numpy().reshape(-1, 8)[0], "shape", tuple(lg.shape))
+        for k in ("conv0", "extract", "proj", "layer0", "layer5", "layer11", "w2v", "tl1", "tl2"):
+            print("  ", k, out5[f"{tag}_{k}_shape"], out5[f"{tag}_{k}_stats"])
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(HERE, "audio_model.npz"), **out5)
+
+    # F6: chunker / frame mapping of EmotionRecognition.load_audio_features with a probe model
+    import get_prob_audio_8_cl as gpa
+
+    def probe(x):  # (1,T) -> (8,) deterministic summary of the (normalised, padded) chunk
+        x = x[0]
+        return torch.stack([x[0], x[-1], x[len(x) // 2], x[123], x.mean(), x.abs().max(), x[1], x[-2]])
+
+    out6 = {}
+    for fps in (24, 25, 29, 30, 60):
+        for n in (8000, 20000, 64000, 70001):
+            for window, step, padding in ((4, 0.5, "mean"), (4, 1, "repeat"), (2, 0.5, "constant")):
+                if padding == "repeat" and n % int(step * 16000) == 0:
+                    continue  # reference divides by zero on the empty tail chunk in 'repeat' mode
+                wav = torch.from_numpy(synth.waveforms(31, 1, n)[0])
+                er = object.__new__(gpa.EmotionRecognition)
+                er.window, er.step, er.sr, er.device, er.padding = window, step, 16000, "cpu", padding
+                er.flag_save_prob = False
+                er.processor = proc
+                er.audio_model = probe
+                gpa.convert_mp4_to_mp3 = lambda path, sr, wav=wav: wav
+                df = er.load_audio_features("x.mp4", fps)
+                key = f"fps{fps}_n{n}_w{window}_s{step}_{padding}"
+                out6[key + "_rows"] = df.iloc[:, :8].values.astype(np.float32)
+                out6[key + "_frames"] = np.array([int(f[:6]) for f in df["frames"]], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "chunker.npz"), **out6)
+    print("chunker cases", len(out6) // 2)
+
+
+# ----------------------------------------------------------------------------- F7/F8 fusion
+def gen_fusion():
+    import pandas as pd
+
+    for name in ("data.get_face_images", "get_prob_video", "get_prob_audio_8_cl"):
+        m = types.ModuleType(name)
+        m.VideoPredictor = None
+        m.preprocess_video_and_predict = None
+        m.preprocess_audio_and_predict = None
+        sys.modules[name] = m
+    argv = sys.argv
+    sys.argv = ["run.py"]
+    import run as ref_run
+
+    sys.argv = argv
+    rec = []
+    real_gce = ref_run.get_compound_expression
+    ref_run.get_compound_expression = lambda *a, **k: (rec.append(real_gce(*a, **k)), rec[-1])[1]
+
+    src = open(os.path.join(REF, "run.py")).read()
+    tree = ast.parse(src)
+    w_run = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") == "weights_av_1":
+            w_run = np.array(ast.literal_eval(node.value))
+    src2 = open(os.path.join(REF, "get_weights_matrices.py")).read()
+    w3 = None
+    for node in ast.walk(ast.parse(src2)):
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") == "weights_3":
+            w3 = np.array(ast.literal_eval(node.value.args[0]))
+    out = {"weights_av_1": w_run, "weights_3": w3}
+
+    vid_cols = ["Neutral", "Happiness", "Sadness", "Surprise", "Fear", "Disgust", "Anger"]
+    aud_cols = ["Neutral", "Anger", "Disgust", "Fear", "Happiness", "Sadness", "Surprise", "Other"]
+    from data.utils import softmax as ref_softmax
+
+    case = 0
+    for n, aud_cover in ((16, 16), (40, 33), (25, 30)):
+        stat = ref_softmax(synth.centered(100 + case, "stat", (n, 7), 1.5)).astype(np.float32)
+        dyn = synth.centered(200 + case, "dyn", (n, 7), 2.0).astype(np.float32)
+        # overlapping audio windows: frame f gets 1..4 logit rows
+        rows, frames = [], []
+        win = 0
+        for lo in range(0, aud_cover, 5):
+            lg = synth.centered(300 + case, f"aud{win}", (8,), 2.0).astype(np.float32)
+            for f in range(lo, min(lo + 12, aud_cover)):
+                rows.append(lg)
+                frames.append(f)
+            win += 1
+        rows = np.array(rows, dtype=np.float32)
+        frames = np.array(frames, dtype=np.int64)
+        for wname, w1 in (("w", [list(r) for r in w_run]), ("none", None)):
+            for cwt in (False, True):
+                for cm in (False, True):
+                    rec.clear()
+                    stat_df = pd.DataFrame(stat.copy(), columns=vid_cols)
+                    dyn_df = pd.DataFrame(dyn.copy(), columns=vid_cols)
+                    aud_df = pd.DataFrame(rows.copy(), columns=aud_cols)
+                    aud_df["frames"] = [f"{f:06d}.jpg" for f in frames]
+                    av, vs, vd, a, _ = ref_run.get_c_expr_db_pred(
+                        stat_df=stat_df, dyn_df=dyn_df, audio_df=aud_df, name_video="v",
+                        weights_1=w1, weights_2=[1, 1, 1], ce_weights_type=cwt, ce_mask=cm, flag_save_prob=False)
+                    key = f"c{case}_{wname}_{int(cwt)}{int(cm)}"
+                    out[key + "_argmax"] = np.stack([av, vs, vd, a])
+                    out[key + "_prob"] = np.stack(rec)
+        out[f"c{case}_stat"] = stat
+        out[f"c{case}_dyn"] = dyn
+        out[f"c{case}_aud_rows"] = rows
+        out[f"c{case}_aud_frames"] = frames
+        case += 1
+    out["n_cases"] = np.array(case)
+    np.savez_compressed(os.path.join(HERE, "fusion.npz"), **out)
+    print("fusion cases", case, "prob dtype", out["c0_w_01_prob"].dtype)
+
+
+if __name__ == "__main__":
+    import transformers  # noqa: F401  (must be imported before the torchvision stub exists)
+    from transformers import Wav2Vec2FeatureExtractor  # noqa: F401
+    from transformers.models.wav2vec2 import modeling_wav2vec2  # noqa: F401
+
+    install_stubs()
+    which = sys.argv[1:] or ["visual", "audio", "fusion"]
+    if "visual" in which:
+        gen_visual()
+    if "audio" in which:
+        gen_audio()
+    if "fusion" in which:
+        gen_fusion()
