@@ -1,0 +1,85 @@
+"""ctypes binding of libavcer_hip.so (include/avcer_hip.h).  There is no CPU fallback: if the library is
+missing or fails to load, importing a model class raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .build import LIB
+
+c_ctx = C.c_void_p
+c_stream = C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    """struct avcer_conv_desc"""
+    _fields_ = [
+        ("batch", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
+        ("out_h", C.c_int32), ("out_w", C.c_int32),
+        ("cin", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+        ("stride_h", C.c_int32), ("stride_w", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
+        ("dil_h", C.c_int32), ("dil_w", C.c_int32),
+        ("x_stride_b", C.c_int64), ("x_stride_h", C.c_int64), ("x_stride_w", C.c_int64),
+        ("x_coff", C.c_int32), ("n", C.c_int32),
+        ("y_ld", C.c_int64), ("y_coff", C.c_int32),
+        ("r_ld", C.c_int64), ("r_coff", C.c_int32),
+        ("act", C.c_int32), ("res_after_act", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); exactly the symbols include/avcer_hip.h declares
+SIGNATURES = {
+    "avcer_abi_version": (C.c_int, []),
+    "avcer_ctx_create": (C.c_int, [C.c_int, C.POINTER(c_ctx)]),
+    "avcer_ctx_destroy": (None, [c_ctx]),
+    "avcer_last_error": (C.c_char_p, [c_ctx]),
+    "avcer_load_static": (C.c_int, [c_ctx, C.c_void_p, C.c_size_t]),
+    "avcer_load_dynamic": (C.c_int, [c_ctx, C.c_void_p, C.c_size_t]),
+    "avcer_load_audio": (C.c_int, [c_ctx, C.c_void_p, C.c_size_t]),
+    "avcer_static_forward": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, c_stream]),
+    "avcer_static_forward_nchw": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            c_stream]),
+    "avcer_gather_windows": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, c_stream]),
+    "avcer_dynamic_forward": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, c_stream]),
+    "avcer_audio_forward": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, c_stream]),
+    "avcer_audio_num_classes": (C.c_int, [c_ctx]),
+    "avcer_audio_chunks": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     c_stream]),
+    "avcer_audio_frame_mean": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, c_stream]),
+    "avcer_fuse": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                             C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, c_stream]),
+    "avcer_conv_gemm": (C.c_int, [c_ctx, C.POINTER(ConvDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, c_stream]),
+    "avcer_gemm_stats": (C.c_int, [c_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
+    "avcer_debug_tap": (C.c_int, [c_ctx, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "avcer_debug_tap_copied": (C.c_int64, [c_ctx]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library (built by `python -m avcer_amd.build` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise RuntimeError(
+                f"{LIB} is missing: run `python -m avcer_amd.build` (hipcc, gfx950). "
+                "avcer_amd has no CPU or PyTorch fallback for the hot path.")
+        import torch  # noqa: F401  -- loads the process's one HIP runtime (libamdhip64.so.7) before the dlopen
+
+        lib = C.CDLL(LIB, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class AvcerError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libavcer_hip error {code}: {msg}")
+        self.code = code

@@ -1,0 +1,671 @@
+// C ABI of libavcer_hip.so: context, packed-weight loading, and the forward passes of the three AVCER models
+// expressed as sequences of the kernels in gemm.hip / kernels.hip.  See include/avcer_hip.h for the contract.
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <new>
+
+// ------------------------------------------------------------------------------------------------ plumbing
+int set_err(avcer_ctx* ctx, int code, const char* fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+int ws_reserve(avcer_ctx* ctx, int slot, size_t bytes, void** out) {
+    DevBuf& b = ctx->ws[slot];
+    if (b.cap < bytes) {
+        if (b.p) {
+            HIP_TRY(ctx, hipDeviceSynchronize());
+            HIP_TRY(ctx, hipFree(b.p));
+            b.p = nullptr;
+            b.cap = 0;
+        }
+        const size_t want = bytes + (bytes >> 3) + (1 << 20);
+        if (hipMalloc(&b.p, want) != hipSuccess) {
+            b.p = nullptr;
+            (void)hipGetLastError();
+            return set_err(ctx, AVCER_ENOMEM, "workspace slot %d: hipMalloc(%zu) failed", slot, want);
+        }
+        b.cap = want;
+    }
+    *out = b.p;
+    return AVCER_OK;
+}
+
+namespace {
+
+struct Arena {
+    char* base;
+    size_t off = 0, cap;
+    Arena(void* p, size_t c) : base((char*)p), cap(c) {}
+    void* get(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* r = base + off;
+        off += bytes;
+        return off <= cap ? r : nullptr;
+    }
+};
+
+#pragma pack(push, 1)
+struct BlobHeader {
+    char magic[8];
+    uint32_t count;
+    uint32_t reserved;
+};
+struct BlobEntry {
+    char name[96];
+    uint32_t ndim;
+    uint32_t pad;
+    int64_t dims[4];
+    uint64_t offset;
+    uint64_t nbytes;
+};
+#pragma pack(pop)
+
+void free_model(Model& m) {
+    for (void* p : m.allocs) (void)hipFree(p);
+    m.allocs.clear();
+    m.t.clear();
+    m.loaded = false;
+}
+
+int load_blob(avcer_ctx* ctx, Model& m, const void* blob, size_t nbytes) {
+    if (!blob || nbytes < sizeof(BlobHeader)) return set_err(ctx, AVCER_EFORMAT, "weight blob too small");
+    const BlobHeader* h = (const BlobHeader*)blob;
+    if (memcmp(h->magic, "AVCERW01", 8) != 0) return set_err(ctx, AVCER_EFORMAT, "bad blob magic");
+    const size_t table = sizeof(BlobHeader) + (size_t)h->count * sizeof(BlobEntry);
+    if (table > nbytes) return set_err(ctx, AVCER_EFORMAT, "blob table truncated");
+    const BlobEntry* e = (const BlobEntry*)((const char*)blob + sizeof(BlobHeader));
+    size_t lo = nbytes, hi = 0;
+    for (uint32_t i = 0; i < h->count; ++i) {
+        if (e[i].offset % 64 || e[i].offset + e[i].nbytes > nbytes || e[i].offset < table)
+            return set_err(ctx, AVCER_EFORMAT, "blob entry %u (%.95s) out of range", i, e[i].name);
+        size_t numel = 1;
+        for (uint32_t d = 0; d < e[i].ndim && d < 4; ++d) numel *= (size_t)e[i].dims[d];
+        if (e[i].ndim > 4 || numel * 4 != e[i].nbytes)
+            return set_err(ctx, AVCER_EFORMAT, "blob entry %u (%.95s) shape/size mismatch", i, e[i].name);
+        lo = std::min(lo, (size_t)e[i].offset);
+        hi = std::max(hi, (size_t)(e[i].offset + e[i].nbytes));
+    }
+    if (h->count == 0 || hi <= lo) return set_err(ctx, AVCER_EFORMAT, "empty blob");
+    free_model(m);
+    void* dev = nullptr;
+    if (hipMalloc(&dev, hi - lo) != hipSuccess) {
+        (void)hipGetLastError();
+        return set_err(ctx, AVCER_ENOMEM, "hipMalloc(%zu) for weights failed", hi - lo);
+    }
+    m.allocs.push_back(dev);
+    HIP_TRY(ctx, hipMemcpy(dev, (const char*)blob + lo, hi - lo, hipMemcpyHostToDevice));
+    for (uint32_t i = 0; i < h->count; ++i) {
+        Tensor t;
+        t.f32 = (float*)((char*)dev + (e[i].offset - lo));
+        t.ndim = (int)e[i].ndim;
+        t.numel = e[i].nbytes / 4;
+        for (int d = 0; d < 4; ++d) t.dims[d] = e[i].dims[d];
+        char nm[97];
+        memcpy(nm, e[i].name, 96);
+        nm[96] = 0;
+        m.t[nm] = t;
+    }
+    m.loaded = true;
+    return AVCER_OK;
+}
+
+// bf16 copies of every GEMM weight (names ending in ".w"), made once on the first bf16-mode call
+int ensure_all_bf16(avcer_ctx* ctx, Model& m, hipStream_t st) {
+    size_t total = 0;
+    for (auto& kv : m.t)
+        if (!kv.second.bf16 && kv.first.size() > 2 && kv.first.compare(kv.first.size() - 2, 2, ".w") == 0)
+            total += (kv.second.numel * 2 + 255) & ~(size_t)255;
+    if (!total) return AVCER_OK;
+    void* dev = nullptr;
+    if (hipMalloc(&dev, total) != hipSuccess) {
+        (void)hipGetLastError();
+        return set_err(ctx, AVCER_ENOMEM, "hipMalloc(%zu) for bf16 weights failed", total);
+    }
+    m.allocs.push_back(dev);
+    size_t off = 0;
+    for (auto& kv : m.t)
+        if (!kv.second.bf16 && kv.first.size() > 2 && kv.first.compare(kv.first.size() - 2, 2, ".w") == 0) {
+            kv.second.bf16 = (bf16_t*)((char*)dev + off);
+            TRY(k_f32_to_bf16(ctx, kv.second.f32, kv.second.bf16, kv.second.numel, st));
+            off += (kv.second.numel * 2 + 255) & ~(size_t)255;
+        }
+    return AVCER_OK;
+}
+
+struct Net {
+    avcer_ctx* ctx;
+    Model& m;
+    int bf16;  // activation / weight type of the MFMA contractions
+    hipStream_t st;
+    int err = AVCER_OK;
+
+    const Tensor* T(const std::string& name) {
+        auto it = m.t.find(name);
+        if (it == m.t.end()) {
+            if (err == AVCER_OK) err = set_err(ctx, AVCER_EFORMAT, "tensor '%s' missing from packed weights", name.c_str());
+            return nullptr;
+        }
+        return &it->second;
+    }
+    const float* F(const std::string& name) {
+        const Tensor* t = T(name);
+        return t ? t->f32 : nullptr;
+    }
+    // contraction with weights `wname`; in_bf16/out_bf16 choose the kernel instantiation
+    void gemm(avcer_conv_desc d, const std::string& wname, const float* scale, const float* bias, const void* x,
+              const void* res, void* y, bool in_bf16, bool out_bf16) {
+        if (err != AVCER_OK) return;
+        const Tensor* w = T(wname);
+        if (!w) return;
+        int dtype;
+        const void* wp;
+        if (!in_bf16) {
+            if (out_bf16) { err = set_err(ctx, AVCER_EINVAL, "gemm %s: f32 in / bf16 out unsupported", wname.c_str()); return; }
+            dtype = 0;
+            wp = w->f32;
+        } else {
+            dtype = out_bf16 ? 1 : 2;
+            wp = w->bf16;
+            if (!wp) { err = set_err(ctx, AVCER_ESTATE, "gemm %s: bf16 weights not prepared", wname.c_str()); return; }
+        }
+        const long K = (long)d.kh * d.kw * d.cin;
+        if ((long)w->numel != (long)d.n * K) {
+            err = set_err(ctx, AVCER_EFORMAT, "gemm %s: weight has %zu elements, expected %ld x %ld", wname.c_str(),
+                          w->numel, (long)d.n, K);
+            return;
+        }
+        err = launch_conv_gemm(ctx, d, dtype, x, wp, scale, bias, res, y, st);
+    }
+    void chk(int r) { if (err == AVCER_OK && r != AVCER_OK) err = r; }
+    // debug tap: raw copy of min(requested, available) bytes of an intermediate tensor
+    void tap(const char* name, const void* src, size_t bytes) {
+        if (err != AVCER_OK || !ctx->tap_dst || ctx->tap_name != name) return;
+        const size_t nb = std::min(bytes, ctx->tap_bytes);
+        if (hipMemcpyAsync(ctx->tap_dst, src, nb, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            err = set_err(ctx, AVCER_EHIP, "debug tap %s: copy failed", name);
+        ctx->tap_copied = (int64_t)nb;
+        ctx->tap_dst = nullptr;
+    }
+};
+
+avcer_conv_desc linear_desc(long m, int k, int n, int act) {
+    avcer_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.batch = (int32_t)m; d.in_h = 1; d.in_w = 1; d.out_h = 1; d.out_w = 1;
+    d.cin = k; d.kh = 1; d.kw = 1;
+    d.stride_h = d.stride_w = 1; d.dil_h = d.dil_w = 1;
+    d.x_stride_b = k; d.x_stride_h = k; d.x_stride_w = k;
+    d.n = n; d.y_ld = n; d.r_ld = n; d.act = act;
+    return d;
+}
+
+avcer_conv_desc conv2d_desc(int nb, int h, int w, int c, int kh, int kw, int stride, int pad, int n, int act) {
+    avcer_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.batch = nb; d.in_h = h; d.in_w = w;
+    d.out_h = (h + 2 * pad - kh) / stride + 1;
+    d.out_w = (w + 2 * pad - kw) / stride + 1;
+    d.cin = c; d.kh = kh; d.kw = kw;
+    d.stride_h = d.stride_w = stride; d.pad_h = d.pad_w = pad; d.dil_h = d.dil_w = 1;
+    d.x_stride_b = (int64_t)h * w * c; d.x_stride_h = (int64_t)w * c; d.x_stride_w = c;
+    d.n = n; d.y_ld = n; d.r_ld = n; d.act = act;
+    return d;
+}
+
+// Conv1d over a time-major [nb, len, c] tensor
+avcer_conv_desc conv1d_desc(int nb, int len, int c, int k, int stride, int pad, int dil, int out_len, int n, int act) {
+    avcer_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.batch = nb; d.in_h = len; d.in_w = 1; d.out_h = out_len; d.out_w = 1;
+    d.cin = c; d.kh = k; d.kw = 1;
+    d.stride_h = stride; d.stride_w = 1; d.pad_h = pad; d.pad_w = 0; d.dil_h = dil; d.dil_w = 1;
+    d.x_stride_b = (int64_t)len * c; d.x_stride_h = c; d.x_stride_w = c;
+    d.n = n; d.y_ld = n; d.r_ld = n; d.act = act;
+    return d;
+}
+
+constexpr int kStages[4][3] = {{64, 3, 1}, {128, 4, 2}, {256, 6, 2}, {512, 3, 2}};  // video.py:105-108,165
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI: context
+extern "C" int avcer_abi_version(void) { return 1; }
+
+extern "C" int avcer_ctx_create(int device, avcer_ctx** out) {
+    if (!out) return AVCER_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return AVCER_EHIP;
+    if (hipSetDevice(device) != hipSuccess) return AVCER_EHIP;
+    avcer_ctx* c = new (std::nothrow) avcer_ctx();
+    if (!c) return AVCER_ENOMEM;
+    c->device = device;
+    *out = c;
+    return AVCER_OK;
+}
+
+extern "C" void avcer_ctx_destroy(avcer_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    free_model(ctx->stat);
+    free_model(ctx->dyn);
+    free_model(ctx->aud);
+    for (auto& b : ctx->ws)
+        if (b.p) (void)hipFree(b.p);
+    delete ctx;
+}
+
+extern "C" const char* avcer_last_error(const avcer_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+extern "C" int avcer_load_static(avcer_ctx* ctx, const void* blob, size_t nbytes) {
+    if (!ctx) return AVCER_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return load_blob(ctx, ctx->stat, blob, nbytes);
+}
+extern "C" int avcer_load_dynamic(avcer_ctx* ctx, const void* blob, size_t nbytes) {
+    if (!ctx) return AVCER_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return load_blob(ctx, ctx->dyn, blob, nbytes);
+}
+extern "C" int avcer_load_audio(avcer_ctx* ctx, const void* blob, size_t nbytes) {
+    if (!ctx) return AVCER_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    TRY(load_blob(ctx, ctx->aud, blob, nbytes));
+    auto it = ctx->aud.t.find("fd.w");
+    if (it == ctx->aud.t.end()) return set_err(ctx, AVCER_EFORMAT, "audio blob lacks fd.w");
+    ctx->aud_classes = (int)it->second.dims[0];
+    return AVCER_OK;
+}
+extern "C" int avcer_audio_num_classes(const avcer_ctx* ctx) { return ctx ? ctx->aud_classes : 0; }
+
+// ------------------------------------------------------------------------------------------------ static CNN
+// ref: architectures/video.py:93-166 (ResNet-50, stride on the first 1x1 of a bottleneck, BN eps 1e-3 folded into
+// per-channel scale/bias by avcer_amd/packing.py), data/utils.py:19-39, get_prob_video.py:47-49,103-112.
+static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const float* nchw, int n, int in_h, int in_w, int mode,
+                               float* logits, float* probs, float* feats, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (!ctx->stat.loaded) return set_err(ctx, AVCER_ESTATE, "static weights not loaded");
+    if ((!frames && !nchw) || n <= 0 || in_h <= 0 || in_w <= 0) return set_err(ctx, AVCER_EINVAL, "static_forward: bad arguments");
+    if (mode != AVCER_MODE_FP32 && mode != AVCER_MODE_BF16) return set_err(ctx, AVCER_EINVAL, "static_forward: mode %d", mode);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int bf = mode == AVCER_MODE_BF16;
+    if (bf) TRY(ensure_all_bf16(ctx, ctx->stat, st));
+    const size_t es = bf ? 2 : 4;
+    const int NB = std::min(n, 256);
+    const size_t act_elems = (size_t)NB * 112 * 112 * 64;  // largest activation (stem output)
+    const size_t pre_elems = (size_t)NB * 230 * 230 * 4;
+    const size_t total = pre_elems * es + 5 * (act_elems * es + 256) + (size_t)NB * (2048 + 512) * 4 + 4096;
+    void* wsp = nullptr;
+    TRY(ws_reserve(ctx, 0, total, &wsp));
+    Arena ar(wsp, ctx->ws[0].cap);
+    void* P = ar.get(pre_elems * es);
+    void* buf[5];
+    for (auto& b : buf) b = ar.get(act_elems * es);
+    float* pooled = (float*)ar.get((size_t)NB * 2048 * 4);
+    float* feat_ws = (float*)ar.get((size_t)NB * 512 * 4);
+    if (!feat_ws) return set_err(ctx, AVCER_ENOMEM, "static workspace arithmetic");
+
+    Net net{ctx, ctx->stat, bf, st};
+    for (int s0 = 0; s0 < n; s0 += NB) {
+        const int nb = std::min(NB, n - s0);
+        if (frames) net.chk(k_preprocess(ctx, frames + (size_t)s0 * in_h * in_w * 3, nb, in_h, in_w, P, bf, st));
+        else net.chk(k_pack_nchw(ctx, nchw + (size_t)s0 * 3 * 224 * 224, nb, P, bf, st));
+        {  // stem: 8 tap rows x (8 pixels x 4 channels) over the zero-bordered 230x230x4 image, stride 2
+            avcer_conv_desc d;
+            memset(&d, 0, sizeof(d));
+            d.batch = nb; d.in_h = 230; d.in_w = 230; d.out_h = 112; d.out_w = 112;
+            d.cin = 32; d.kh = 8; d.kw = 1;
+            d.stride_h = 2; d.stride_w = 2; d.dil_h = d.dil_w = 1;
+            d.x_stride_b = 230L * 230 * 4; d.x_stride_h = 230 * 4; d.x_stride_w = 4;
+            d.n = 64; d.y_ld = 64; d.r_ld = 64; d.act = 1;
+            net.gemm(d, "stem.w", net.F("stem.s"), net.F("stem.b"), P, nullptr, buf[0], bf, bf);
+        }
+        net.tap("pre", P, (size_t)nb * 230 * 230 * 4 * es);
+        net.tap("stem_conv", buf[0], (size_t)nb * 112 * 112 * 64 * es);
+        net.chk(k_maxpool3s2(ctx, buf[0], buf[1], nb, 112, 112, 64, 55, 55, bf, st));
+        net.tap("stem", buf[1], (size_t)nb * 55 * 55 * 64 * es);
+        void* X = buf[1];
+        void* T1 = buf[2];
+        void* T2 = buf[3];
+        void* ID = buf[4];
+        void* OUT = buf[0];
+        int h = 55, cin = 64;
+        for (int li = 0; li < 4; ++li) {
+            const int planes = kStages[li][0], blocks = kStages[li][1];
+            for (int b = 0; b < blocks; ++b) {
+                const int stride = b == 0 ? kStages[li][2] : 1;
+                const std::string p = "l" + std::to_string(li + 1) + "." + std::to_string(b) + ".";
+                const int oh = (h - 1) / stride + 1;
+                net.gemm(conv2d_desc(nb, h, h, cin, 1, 1, stride, 0, planes, 1), p + "c1.w", net.F(p + "c1.s"),
+                         net.F(p + "c1.b"), X, nullptr, T1, bf, bf);
+                net.gemm(conv2d_desc(nb, oh, oh, planes, 3, 3, 1, 1, planes, 1), p + "c2.w", net.F(p + "c2.s"),
+                         net.F(p + "c2.b"), T1, nullptr, T2, bf, bf);
+                const void* identity = X;
+                if (b == 0) {
+                    net.gemm(conv2d_desc(nb, h, h, cin, 1, 1, stride, 0, planes * 4, 0), p + "ds.w", net.F(p + "ds.s"),
+                             net.F(p + "ds.b"), X, nullptr, ID, bf, bf);
+                    identity = ID;
+                }
+                net.gemm(conv2d_desc(nb, oh, oh, planes, 1, 1, 1, 0, planes * 4, 1), p + "c3.w", net.F(p + "c3.s"),
+                         net.F(p + "c3.b"), T2, identity, OUT, bf, bf);
+                std::swap(X, OUT);
+                h = oh;
+                cin = planes * 4;
+                if (li == 0 && b == 0) {
+                    net.tap("l1b0_c1", T1, (size_t)nb * h * h * planes * es);
+                    net.tap("l1b0_c2", T2, (size_t)nb * h * h * planes * es);
+                    net.tap("l1b0_ds", ID, (size_t)nb * h * h * cin * es);
+                    net.tap("l1b0", X, (size_t)nb * h * h * cin * es);
+                }
+            }
+            net.tap(("layer" + std::to_string(li + 1)).c_str(), X, (size_t)nb * h * h * cin * es);
+        }
+        net.chk(k_avgpool_hw(ctx, X, pooled, nb, h * h, 2048, bf, st));
+        net.tap("avgpool", pooled, (size_t)nb * 2048 * 4);
+        float* fo = feats ? feats + (size_t)s0 * 512 : feat_ws;
+        net.gemm(linear_desc(nb, 2048, 512, 0), "fc1.w", nullptr, net.F("fc1.b"), pooled, nullptr, fo, false, false);
+        if (logits || probs)
+            net.chk(k_small_linear(ctx, fo, net.F("fc2.w"), net.F("fc2.b"), logits ? logits + (size_t)s0 * 7 : nullptr,
+                                   probs ? probs + (size_t)s0 * 7 : nullptr, nb, 512, 7, 1, st));
+        if (net.err != AVCER_OK) return net.err;
+    }
+    return net.err;
+}
+
+extern "C" int avcer_static_forward(avcer_ctx* ctx, const uint8_t* frames, int n, int in_h, int in_w, int mode,
+                                    float* logits, float* probs, float* feats, avcer_stream_t stream) {
+    if (!frames) return ctx ? set_err(ctx, AVCER_EINVAL, "static_forward: null frames") : AVCER_EINVAL;
+    return static_forward_impl(ctx, frames, nullptr, n, in_h, in_w, mode, logits, probs, feats, stream);
+}
+
+extern "C" int avcer_static_forward_nchw(avcer_ctx* ctx, const float* x, int n, int mode, float* logits, float* probs,
+                                         float* feats, avcer_stream_t stream) {
+    if (!x) return ctx ? set_err(ctx, AVCER_EINVAL, "static_forward_nchw: null input") : AVCER_EINVAL;
+    return static_forward_impl(ctx, nullptr, x, n, 224, 224, mode, logits, probs, feats, stream);
+}
+
+extern "C" int avcer_gather_windows(avcer_ctx* ctx, const float* feats, const int32_t* idx, int nwin, float* out,
+                                    avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (!feats || !idx || !out || nwin <= 0) return set_err(ctx, AVCER_EINVAL, "gather_windows: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return k_gather_windows(ctx, feats, idx, nwin, out, (hipStream_t)stream);
+}
+
+extern "C" int avcer_audio_chunks(avcer_ctx* ctx, const float* wav, const int32_t* starts, const int32_t* ends, int n,
+                                  int window, int mode, float* out, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (!wav || !starts || !ends || !out || n <= 0 || window <= 0 || mode < 0 || mode > 2)
+        return set_err(ctx, AVCER_EINVAL, "audio_chunks: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return k_audio_chunks(ctx, wav, starts, ends, n, window, mode, out, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ dynamic LSTM
+// ref: architectures/video.py:169-185.  Input projections of all 10 steps are one GEMM per layer; the recurrent
+// part is one [n,H]x[H,4H] GEMM + one cell kernel per step (h_0 = c_0 = 0, so step 0 needs no GEMM).
+extern "C" int avcer_dynamic_forward(avcer_ctx* ctx, const float* windows, int n, float* logits, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (!ctx->dyn.loaded) return set_err(ctx, AVCER_ESTATE, "dynamic weights not loaded");
+    if (!windows || !logits || n <= 0) return set_err(ctx, AVCER_EINVAL, "dynamic_forward: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    constexpr int T = 10, I = 512, H1 = 512, H2 = 256;
+    const size_t total = ((size_t)n * T * 4 * H1 + (size_t)n * 4 * H1 + (size_t)n * T * H1 + (size_t)n * H1 +
+                          (size_t)n * T * 4 * H2 + (size_t)n * H2 * 2) * 4 + 8 * 256;
+    void* wsp = nullptr;
+    TRY(ws_reserve(ctx, 1, total, &wsp));
+    Arena ar(wsp, ctx->ws[1].cap);
+    float* xp1 = (float*)ar.get((size_t)n * T * 4 * H1 * 4);
+    float* hp = (float*)ar.get((size_t)n * 4 * H1 * 4);
+    float* h1 = (float*)ar.get((size_t)n * T * H1 * 4);
+    float* c1 = (float*)ar.get((size_t)n * H1 * 4);
+    float* xp2 = (float*)ar.get((size_t)n * T * 4 * H2 * 4);
+    float* h2 = (float*)ar.get((size_t)n * H2 * 4);
+    float* c2 = (float*)ar.get((size_t)n * H2 * 4);
+    if (!c2) return set_err(ctx, AVCER_ENOMEM, "dynamic workspace arithmetic");
+    Net net{ctx, ctx->dyn, 0, st};
+    net.gemm(linear_desc((long)n * T, I, 4 * H1, 0), "lstm1.wih.w", nullptr, net.F("lstm1.b"), windows, nullptr, xp1, false, false);
+    for (int t = 0; t < T; ++t) {
+        if (t > 0) {
+            avcer_conv_desc d = linear_desc(n, H1, 4 * H1, 0);
+            d.x_stride_b = (int64_t)T * H1;  // rows of h_{t-1} inside the [n, T, H1] sequence buffer
+            net.gemm(d, "lstm1.whh.w", nullptr, nullptr, h1 + (size_t)(t - 1) * H1, nullptr, hp, false, false);
+        }
+        net.chk(k_lstm_cell(ctx, xp1 + (size_t)t * 4 * H1, (int64_t)T * 4 * H1, hp, c1, h1 + (size_t)t * H1,
+                            (int64_t)T * H1, n, H1, t == 0, st));
+    }
+    net.gemm(linear_desc((long)n * T, H1, 4 * H2, 0), "lstm2.wih.w", nullptr, net.F("lstm2.b"), h1, nullptr, xp2, false, false);
+    for (int t = 0; t < T; ++t) {
+        if (t > 0) net.gemm(linear_desc(n, H2, 4 * H2, 0), "lstm2.whh.w", nullptr, nullptr, h2, nullptr, hp, false, false);
+        net.chk(k_lstm_cell(ctx, xp2 + (size_t)t * 4 * H2, (int64_t)T * 4 * H2, hp, c2, h2, H2, n, H2, t == 0, st));
+    }
+    net.chk(k_small_linear(ctx, h2, net.F("fc.w"), net.F("fc.b"), logits, nullptr, n, H2, 7, 0, st));
+    return net.err;
+}
+
+// ------------------------------------------------------------------------------------------------ audio model
+// ref: architectures/audio_8_cl.py:131-190; transformers 4.36.2 Wav2Vec2Model with feat_extract_norm="layer",
+// do_stable_layer_norm=True (third party); architectures/attention_layers.py:221-267.
+// Residual streams stay f32 in both modes; in bf16 mode only MFMA operands (and the wide conv-extractor
+// activations) are bf16.
+extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int t, int normalize, int mode,
+                                   float* logits, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (!ctx->aud.loaded) return set_err(ctx, AVCER_ESTATE, "audio weights not loaded");
+    if (!wav || !logits || n <= 0) return set_err(ctx, AVCER_EINVAL, "audio_forward: bad arguments");
+    if (mode != AVCER_MODE_FP32 && mode != AVCER_MODE_BF16) return set_err(ctx, AVCER_EINVAL, "audio_forward: mode %d", mode);
+    static const int ck[7] = {10, 3, 3, 3, 3, 2, 2}, cs[7] = {5, 2, 2, 2, 2, 2, 2};
+    int len[8];
+    len[0] = t;
+    for (int i = 0; i < 7; ++i) {
+        if (len[i] < ck[i]) return set_err(ctx, AVCER_EINVAL, "audio_forward: %d samples is too short", t);
+        len[i + 1] = (len[i] - ck[i]) / cs[i] + 1;
+    }
+    const int S = len[7];
+    if (S > 256) return set_err(ctx, AVCER_EINVAL, "audio_forward: %d tokens > 256 (window longer than ~5 s)", S);
+    const int L1 = (S - 2 * 4 - 1) / 3 + 1;  // Conv1d k5 s3 dil2
+    const int L2 = L1 / 5;                   // MaxPool1d(5)
+    const int L3 = L2 - 2;                   // Conv1d k3
+    if (S < 9 || L2 < 3) return set_err(ctx, AVCER_EINVAL, "audio_forward: %d tokens is too short for the head", S);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int bf = mode == AVCER_MODE_BF16;
+    if (bf) TRY(ensure_all_bf16(ctx, ctx->aud, st));
+    const size_t es = bf ? 2 : 4;
+    const int C = 512, E = 1024, FF = 4096;
+    const int NB = std::min(n, 128);
+    const size_t rows = (size_t)NB * S;
+    const size_t e0 = (size_t)NB * len[1] * C * es, e1 = (size_t)NB * len[2] * C * es;
+    const size_t total = (size_t)NB * t * 4 + e0 + 2 * e1 + rows * E * 4 * 4 + rows * E * 2 * 2 + rows * 3 * E * es +
+                         rows * FF * es + rows * E * es + (size_t)NB * (L1 + L2 + L3 + 1) * E * 4 + 32 * 256;
+    void* wsp = nullptr;
+    TRY(ws_reserve(ctx, 2, total, &wsp));
+    Arena ar(wsp, ctx->ws[2].cap);
+    float* wn = (float*)ar.get((size_t)NB * t * 4);
+    void* EA = ar.get(e0);
+    void* EB = ar.get(e1);
+    void* TMP = ar.get(e1);
+    float* Hf = (float*)ar.get(rows * E * 4);   // residual stream
+    float* Of = (float*)ar.get(rows * E * 4);
+    float* Xf = (float*)ar.get(rows * E * 4);
+    float* Yf = (float*)ar.get(rows * E * 4);
+    bf16_t* Xb = (bf16_t*)ar.get(rows * E * 2);
+    bf16_t* Yb = (bf16_t*)ar.get(rows * E * 2);
+    void* QKV = ar.get(rows * 3 * E * es);
+    void* FFB = ar.get(rows * FF * es);
+    void* ATT = ar.get(rows * E * es);
+    float* c1o = (float*)ar.get((size_t)NB * L1 * E * 4);
+    float* mp = (float*)ar.get((size_t)NB * L2 * E * 4);
+    float* c2o = (float*)ar.get((size_t)NB * L3 * E * 4);
+    float* pooled = (float*)ar.get((size_t)NB * E * 4);
+    if (!pooled) return set_err(ctx, AVCER_ENOMEM, "audio workspace arithmetic");
+    const int ncls = ctx->aud_classes;
+
+    Net net{ctx, ctx->aud, bf, st};
+    // LN output helper: activation-typed operand (f32 in parity mode, bf16 in throughput mode)
+    auto ln_act = [&](const void* x, bool x_bf16, const std::string& p, void* y, long r, int c, int act) {
+        net.chk(k_layernorm(ctx, x, nullptr, net.F(p + ".g"), net.F(p + ".b"), bf ? nullptr : y, bf ? y : nullptr, r, c,
+                            1e-5f, act, x_bf16, 0, st));
+    };
+    for (int s0 = 0; s0 < n; s0 += NB) {
+        const int nb = std::min(NB, n - s0);
+        const long r = (long)nb * S;
+        const float* x0 = wav + (size_t)s0 * t;
+        if (normalize) {
+            net.chk(k_wav_normalize(ctx, x0, wn, nb, t, st));
+            x0 = wn;
+        }
+        // ---- conv feature extractor: 7 x (Conv1d -> LN(512) -> GELU)
+        net.chk(k_conv0_ln_gelu(ctx, x0, net.F("fe0.w"), net.F("fe0.cb"), net.F("fe0.ln.g"), net.F("fe0.ln.b"), EA, nb, t,
+                                len[1], bf, st));
+        net.tap("norm", x0, (size_t)nb * t * 4);
+        net.tap("conv0", EA, (size_t)nb * len[1] * C * es);
+        void* cur = EA;
+        void* nxt = EB;
+        for (int i = 1; i < 7; ++i) {
+            const std::string p = "fe" + std::to_string(i);
+            net.gemm(conv1d_desc(nb, len[i], C, ck[i], cs[i], 0, 1, len[i + 1], C, 0), p + ".w", nullptr, net.F(p + ".cb"),
+                     cur, nullptr, TMP, bf, bf);
+            ln_act(TMP, bf, p + ".ln", nxt, (long)nb * len[i + 1], C, 2);
+            std::swap(cur, nxt);
+            if (i == 1) nxt = EA;  // EA (largest) is free once layer 1 has consumed it
+        }
+        net.tap("extract", cur, (size_t)r * C * es);
+        // ---- feature projection: LN(512) -> Linear 512 -> 1024
+        ln_act(cur, bf, "fp.ln", TMP, r, C, 0);
+        net.gemm(linear_desc(r, C, E, 0), "fp.w", nullptr, net.F("fp.b"), TMP, nullptr, Hf, bf, false);
+        net.tap("proj", Hf, (size_t)r * E * 4);
+        // ---- positional conv embedding (k=128, groups=16, pad 64, drop last, GELU) added to the stream
+        const void* pin = Hf;
+        if (bf) {
+            net.chk(k_f32_to_bf16(ctx, Hf, Xb, (size_t)r * E, st));
+            pin = Xb;
+        }
+        for (int g = 0; g < 16; ++g) {
+            avcer_conv_desc d = conv1d_desc(nb, S, 64, 128, 1, 64, 1, S, 64, 2);
+            d.x_stride_b = (int64_t)S * E; d.x_stride_h = E; d.x_stride_w = E;
+            d.x_coff = g * 64;
+            d.y_ld = E; d.y_coff = g * 64; d.r_ld = E; d.r_coff = g * 64;
+            d.res_after_act = 1;
+            net.gemm(d, "pos.g" + std::to_string(g) + ".w", nullptr, net.F("pos.b") ? net.F("pos.b") + g * 64 : nullptr, pin,
+                     Hf, Of, bf, false);
+        }
+        float* h = Of;
+        net.tap("posconv", h, (size_t)r * E * 4);
+        // ---- 12 pre-LN encoder layers
+        for (int l = 0; l < 12; ++l) {
+            const std::string p = "enc" + std::to_string(l);
+            ln_act(h, false, p + ".ln1", TMP, r, E, 0);
+            net.gemm(linear_desc(r, E, 3 * E, 0), p + ".qkv.w", nullptr, net.F(p + ".qkv.b"), TMP, nullptr, QKV, bf, bf);
+            net.chk(k_attention(ctx, QKV, ATT, nb, S, 16, 64, 0.125f, bf, st));
+            net.gemm(linear_desc(r, E, E, 0), p + ".o.w", nullptr, net.F(p + ".o.b"), ATT, h, h, bf, false);
+            ln_act(h, false, p + ".ln2", TMP, r, E, 0);
+            net.gemm(linear_desc(r, E, FF, 2), p + ".ff1.w", nullptr, net.F(p + ".ff1.b"), TMP, nullptr, FFB, bf, bf);
+            net.gemm(linear_desc(r, FF, E, 0), p + ".ff2.w", nullptr, net.F(p + ".ff2.b"), FFB, h, h, bf, false);
+            net.tap(("layer" + std::to_string(l)).c_str(), h, (size_t)r * E * 4);
+        }
+        net.chk(k_layernorm(ctx, h, nullptr, net.F("enc.ln.g"), net.F("enc.ln.b"), Xf, nullptr, r, E, 1e-5f, 0, 0, 0, st));
+        net.tap("w2v", Xf, (size_t)r * E * 4);
+        // ---- two first-party TransformerLayers (32 x 32 and 16 x 64 heads)
+        float* xin = Xf;
+        for (int l = 1; l <= 2; ++l) {
+            const std::string p = "tl" + std::to_string(l);
+            const int heads = l == 1 ? 32 : 16, dh = E / heads;
+            net.chk(k_add_pe(ctx, xin, net.F("pe"), Yf, bf ? Yb : nullptr, nb, S, E, st));  // x + PE: operand and residual
+            net.gemm(linear_desc(r, E, 3 * E, 0), p + ".qkv.w", nullptr, nullptr, bf ? (void*)Yb : (void*)Yf, nullptr, QKV, bf, bf);
+            net.chk(k_attention(ctx, QKV, ATT, nb, S, heads, dh, 1.0f / sqrtf((float)dh), bf, st));
+            net.gemm(linear_desc(r, E, E, 0), p + ".o.w", nullptr, nullptr, ATT, Yf, Hf, bf, false);
+            net.chk(k_layernorm(ctx, Hf, nullptr, net.F(p + ".ln1.g"), net.F(p + ".ln1.b"), Yf, bf ? Yb : nullptr, r, E, 1e-5f,
+                                0, 0, 0, st));
+            net.gemm(linear_desc(r, E, E, 1), p + ".ff1.w", nullptr, net.F(p + ".ff1.b"), bf ? (void*)Yb : (void*)Yf, nullptr,
+                     FFB, bf, bf);
+            net.gemm(linear_desc(r, E, E, 0), p + ".ff2.w", nullptr, net.F(p + ".ff2.b"), FFB, Yf, Hf, bf, false);
+            net.chk(k_layernorm(ctx, Hf, nullptr, net.F(p + ".ln2.g"), net.F(p + ".ln2.b"), Xf, bf ? Xb : nullptr, r, E, 1e-5f,
+                                0, 0, 0, st));
+            xin = Xf;
+            net.tap(p.c_str(), Xf, (size_t)r * E * 4);
+        }
+        // ---- head: Conv1d k5 s3 dil2 + BN -> MaxPool(5) -> ReLU -> Conv1d k3 + BN -> mean -> ReLU -> Linear
+        net.gemm(conv1d_desc(nb, S, E, 5, 3, 0, 2, L1, E, 0), "td0.w", net.F("td0.s"), net.F("td0.b"),
+                 bf ? (void*)Xb : (void*)Xf, nullptr, c1o, bf, false);
+        net.chk(k_maxpool1d_relu(ctx, c1o, mp, nb, L1, L2, E, 5, st));
+        net.gemm(conv1d_desc(nb, L2, E, 3, 1, 0, 1, L3, E, 0), "td4.w", net.F("td4.s"), net.F("td4.b"), mp, nullptr, c2o,
+                 false, false);
+        net.tap("td0", c1o, (size_t)nb * L1 * E * 4);
+        net.tap("mp", mp, (size_t)nb * L2 * E * 4);
+        net.tap("td4", c2o, (size_t)nb * L3 * E * 4);
+        net.chk(k_mean_time_relu(ctx, c2o, pooled, nb, L3, E, st));
+        net.tap("pooled", pooled, (size_t)nb * E * 4);
+        net.chk(k_small_linear(ctx, pooled, net.F("fd.w"), net.F("fd.b"), logits + (size_t)s0 * ncls, nullptr, nb, E, ncls, 0, st));
+        if (net.err != AVCER_OK) return net.err;
+    }
+    return net.err;
+}
+
+// ------------------------------------------------------------------------------------------------ fusion
+extern "C" int avcer_audio_frame_mean(avcer_ctx* ctx, const float* win_logits, const int32_t* frame_lo,
+                                      const int32_t* frame_hi, int n_win, int c, int n_frames, float* out,
+                                      int32_t* count, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (!win_logits || !frame_lo || !frame_hi || !out || n_win < 0 || c <= 0 || n_frames <= 0)
+        return set_err(ctx, AVCER_EINVAL, "audio_frame_mean: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return k_frame_mean(ctx, win_logits, frame_lo, frame_hi, n_win, c, n_frames, out, count, (hipStream_t)stream);
+}
+
+extern "C" int avcer_fuse(avcer_ctx* ctx, const float* stat, const float* dyn_logits, const float* aud_mean, int n,
+                          int n_aud, int aud_c, const double* w1, const double* w2, int ce_weights_type, int ce_mask,
+                          double* comp_prob, int32_t* comp_argmax, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (!stat || !dyn_logits || !aud_mean || !comp_prob || !comp_argmax || n <= 0 || n_aud <= 0 || aud_c < 7)
+        return set_err(ctx, AVCER_EINVAL, "fuse: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double w[21];
+    if (w1)
+        for (int m = 0; m < 3; ++m)
+            for (int k = 0; k < 7; ++k) w[m * 7 + k] = w1[m * 7 + k] * (w2 ? w2[m] : 1.0);  // run.py:109-111
+    return k_fuse(ctx, stat, dyn_logits, aud_mean, n, std::min(n_aud, n), aud_c, w1 ? w : nullptr, w1 != nullptr,
+                  ce_weights_type, ce_mask, comp_prob, comp_argmax, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ kernel-level entry
+extern "C" int avcer_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, const void* x, const void* w,
+                               const float* scale, const float* bias, const void* residual, void* y,
+                               avcer_stream_t stream) {
+    if (!ctx || !d) return AVCER_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_conv_gemm(ctx, *d, dtype, x, w, scale, bias, residual, y, (hipStream_t)stream);
+}
+
+extern "C" int avcer_debug_tap(avcer_ctx* ctx, const char* name, void* dst_dev, size_t bytes) {
+    if (!ctx || !name) return AVCER_EINVAL;
+    ctx->tap_name = name;
+    ctx->tap_dst = dst_dev;
+    ctx->tap_bytes = bytes;
+    ctx->tap_copied = -1;
+    return AVCER_OK;
+}
+
+extern "C" int64_t avcer_debug_tap_copied(const avcer_ctx* ctx) { return ctx ? ctx->tap_copied : -1; }
+
+extern "C" int avcer_gemm_stats(avcer_ctx* ctx, int64_t* launches, double* flops, int reset) {
+    if (!ctx) return AVCER_EINVAL;
+    if (launches) *launches = ctx->gemm_launches;
+    if (flops) *flops = ctx->gemm_flops;
+    if (reset) {
+        ctx->gemm_launches = 0;
+        ctx->gemm_flops = 0.0;
+    }
+    return AVCER_OK;
+}

@@ -1,0 +1,105 @@
+// Internal declarations shared by the translation units of libavcer_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/avcer_hip.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+// One packed tensor of a weight blob, resident on the device in f32 and (lazily) in bf16.
+struct Tensor {
+    float* f32 = nullptr;
+    bf16_t* bf16 = nullptr;
+    size_t numel = 0;
+    int64_t dims[4] = {0, 0, 0, 0};
+    int ndim = 0;
+};
+
+struct Model {
+    bool loaded = false;
+    std::map<std::string, Tensor> t;
+    std::vector<void*> allocs;
+};
+
+struct avcer_ctx {
+    int device = 0;
+    char err[512] = {0};
+    Model stat, dyn, aud;
+    int aud_classes = 0;
+    // grow-only workspace arenas (activations), one per pipeline
+    DevBuf ws[8];
+    int64_t gemm_launches = 0;
+    double gemm_flops = 0.0;
+    // one-shot debug tap (avcer_debug_tap): copy the named intermediate activation to a caller buffer
+    std::string tap_name;
+    void* tap_dst = nullptr;
+    size_t tap_bytes = 0;
+    int64_t tap_copied = -1;
+};
+
+int set_err(avcer_ctx* ctx, int code, const char* fmt, ...);
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return set_err((ctx), AVCER_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                           __FILE__, __LINE__);                                                    \
+    } while (0)
+
+#define TRY(expr)                  \
+    do {                           \
+        int _r = (expr);           \
+        if (_r != AVCER_OK) return _r; \
+    } while (0)
+
+int ws_reserve(avcer_ctx* ctx, int slot, size_t bytes, void** out);
+const Tensor* find_tensor(avcer_ctx* ctx, const Model& m, const char* name);
+int ensure_bf16(avcer_ctx* ctx, Model& m, const char* name);
+
+// ---- gemm.hip
+int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const void* x, const void* w,
+                     const float* scale, const float* bias, const void* residual, void* y, hipStream_t st);
+
+// ---- kernels.hip (element-wise / reduction kernels; T selects f32 (0) or bf16 (1) activations)
+int k_preprocess(avcer_ctx*, const uint8_t* frames, int n, int in_h, int in_w, void* out, int bf16, hipStream_t);
+int k_maxpool3s2(avcer_ctx*, const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int bf16, hipStream_t);
+int k_avgpool_hw(avcer_ctx*, const void* x, float* y, int n, int hw, int c, int bf16, hipStream_t);
+int k_small_linear(avcer_ctx*, const float* x, const float* w, const float* b, float* logits, float* probs, int m,
+                   int k, int n, int relu_in, hipStream_t);
+int k_lstm_cell(avcer_ctx*, const float* xproj, int64_t xproj_ld, const float* hproj, float* c, float* h_out,
+                int64_t h_ld, int n, int hid, int first, hipStream_t);
+int k_wav_normalize(avcer_ctx*, const float* x, float* y, int n, int t, hipStream_t);
+int k_conv0_ln_gelu(avcer_ctx*, const float* x, const float* w, const float* b, const float* g, const float* beta,
+                    void* y, int n, int t_in, int t_out, int bf16, hipStream_t);
+int k_layernorm(avcer_ctx*, const void* x, const void* res, const float* g, const float* b, void* yf, void* yb,
+                int64_t rows, int c, float eps, int act, int in_bf16, int unused, hipStream_t);
+int k_add_pe(avcer_ctx*, const float* x, const float* pe, float* yf, bf16_t* yb, int n, int s, int c, hipStream_t);
+int k_attention(avcer_ctx*, const void* qkv, void* out, int n, int s, int heads, int d, float scale, int bf16,
+                hipStream_t);
+int k_maxpool1d_relu(avcer_ctx*, const float* x, float* y, int n, int t_in, int t_out, int c, int k, hipStream_t);
+int k_mean_time_relu(avcer_ctx*, const float* x, float* y, int n, int t, int c, hipStream_t);
+int k_f32_to_bf16(avcer_ctx*, const float* x, bf16_t* y, size_t n, hipStream_t);
+int k_frame_mean(avcer_ctx*, const float* win_logits, const int32_t* lo, const int32_t* hi, int n_win, int c,
+                 int n_frames, float* out, int32_t* count, hipStream_t);
+int k_fuse(avcer_ctx*, const float* stat, const float* dyn, const float* aud, int n, int n_aud, int aud_c,
+           const double* w /*[21] device-side by value*/, int has_w1, int cwt, int cmask, double* comp_prob,
+           int32_t* comp_argmax, hipStream_t);
+int k_pack_nchw(avcer_ctx*, const float* x, int n, void* out, int bf16, hipStream_t);
+int k_gather_windows(avcer_ctx*, const float* feats, const int32_t* idx, int nwin, float* out, hipStream_t);
+int k_audio_chunks(avcer_ctx*, const float* wav, const int32_t* starts, const int32_t* ends, int n, int window, int mode,
+                   float* out, hipStream_t);

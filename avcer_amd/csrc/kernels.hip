@@ -1,0 +1,791 @@
+// Element-wise, normalisation, pooling, attention and fusion kernels of the AVCER hot path (gfx950).
+// All of these are HBM/LDS-bound: 16-byte vector accesses, one 64-lane wave per row for reductions,
+// f32 statistics regardless of the activation storage type.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float relu_nan(float v) { return v > 0.f ? v : (v != v ? v : 0.f); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p, long i);
+template <> __device__ __forceinline__ float ldf<float>(const float* p, long i) { return p[i]; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p, long i) { return bf2f(p[i]); }
+template <typename T> __device__ __forceinline__ void stf(T* p, long i, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, long i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, long i, float v) { p[i] = f2bf(v); }
+
+// load / store 4 consecutive elements
+template <typename T> __device__ __forceinline__ void ld4(const T* p, long i, float* v);
+template <> __device__ __forceinline__ void ld4<float>(const float* p, long i, float* v) {
+    const float4 t = *reinterpret_cast<const float4*>(p + i);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, long i, float* v) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p + i);
+    v[0] = bf2f((bf16_t)(t.x & 0xffff)); v[1] = bf2f((bf16_t)(t.x >> 16));
+    v[2] = bf2f((bf16_t)(t.y & 0xffff)); v[3] = bf2f((bf16_t)(t.y >> 16));
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, long i, const float* v);
+template <> __device__ __forceinline__ void st4<float>(float* p, long i, const float* v) {
+    *reinterpret_cast<float4*>(p + i) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, long i, const float* v) {
+    uint2 t;
+    t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p + i) = t;
+}
+
+// ------------------------------------------------------------------------------------------------ preprocess
+// data/utils.py:19-39.  u8 [n,in_h,in_w,3] RGB -> zero-bordered [n,230,230,4] (BGR - mean, 4th channel 0).
+// The border materialises Conv2dSame's asymmetric padding (video.py:68-80: 2 before, 3 after) plus one extra
+// row/column so that the stem runs as an un-padded 8x8-tap convolution with 32 contiguous values per tap row.
+constexpr int PP = 230;
+template <typename T>
+__global__ void preprocess_kernel(const uint8_t* __restrict__ in, T* __restrict__ out, int n, int in_h, int in_w) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n * PP * PP;
+    if (idx >= total) return;
+    const int x = idx % PP;
+    const int y = (idx / PP) % PP;
+    const int b = idx / ((long)PP * PP);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (y >= 2 && y < 226 && x >= 2 && x < 226) {
+        int sy = y - 2, sx = x - 2;
+        if (in_h != 224 || in_w != 224) {  // PIL NEAREST: src = floor((dst + 0.5) * in / out)
+            sy = min((int)(((double)sy + 0.5) * ((double)in_h / 224.0)), in_h - 1);
+            sx = min((int)(((double)sx + 0.5) * ((double)in_w / 224.0)), in_w - 1);
+        }
+        const uint8_t* px = in + (((long)b * in_h + sy) * in_w + sx) * 3;
+        v[0] = (float)px[2] - 91.4953f;
+        v[1] = (float)px[1] - 103.8827f;
+        v[2] = (float)px[0] - 131.0912f;
+    }
+    st4<T>(out, idx * 4, v);
+}
+
+// Same zero-bordered image from an ALREADY preprocessed float tensor [n,3,224,224] (the tensor the reference's
+// pth_model_static is called with, get_prob_video.py:103-109).
+template <typename T>
+__global__ void pack_nchw_kernel(const float* __restrict__ in, T* __restrict__ out, int n) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n * PP * PP;
+    if (idx >= total) return;
+    const int x = idx % PP;
+    const int y = (idx / PP) % PP;
+    const int b = idx / ((long)PP * PP);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (y >= 2 && y < 226 && x >= 2 && x < 226) {
+        const long o = (long)b * 3 * 224 * 224 + (long)(y - 2) * 224 + (x - 2);
+        v[0] = in[o]; v[1] = in[o + 224 * 224]; v[2] = in[o + 2 * 224 * 224];
+    }
+    st4<T>(out, idx * 4, v);
+}
+
+// get_prob_video.py:115-123: window rows = relu(features) gathered by index into [nwin, 10, 512]
+__global__ void gather_windows_kernel(const float* __restrict__ feats, const int32_t* __restrict__ idx, float* __restrict__ out,
+                                      long total4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const long row = i / 128;  // 512 / 4 vectors per feature row
+    const int c = (i % 128) * 4;
+    float v[4];
+    ld4<float>(feats, (long)idx[row] * 512 + c, v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = relu_nan(v[j]);
+    st4<float>(out, row * 512 + c, v);
+}
+
+// get_prob_audio_8_cl.py:79-86 + data/utils.py:63-89: chunk = wav[start:end] padded to `window` samples with the
+// chunk mean (mode 0; NaN for an empty chunk, like torch.mean of an empty tensor), zeros (1) or by tiling (2).
+__global__ void audio_chunks_kernel(const float* __restrict__ wav, const int32_t* __restrict__ starts,
+                                    const int32_t* __restrict__ ends, int window, int mode, float* __restrict__ out) {
+    __shared__ float red[8];
+    __shared__ float bc;
+    const int c = blockIdx.x;
+    const int s = starts[c], len = ends[c] - starts[c];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+    float fill = 0.f;
+    if (mode == 0) {
+        float a = 0.f;
+        for (int i = tid; i < len; i += blockDim.x) a += wav[s + i];
+        a = wave_sum(a);
+        if (lane == 0) red[wv] = a;
+        __syncthreads();
+        if (tid == 0) { float t = 0.f; for (int i = 0; i < nw; ++i) t += red[i]; bc = t / (float)len; }
+        __syncthreads();
+        fill = bc;
+    }
+    float* o = out + (long)c * window;
+    for (int i = tid; i < window; i += blockDim.x) {
+        float v;
+        if (i < len) v = wav[s + i];
+        else if (mode == 2) v = wav[s + i % len];
+        else v = fill;
+        o[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pooling
+// video.py:103,117: MaxPool2d(3, stride 2), no padding; NHWC.
+template <typename T>
+__global__ void maxpool3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c, int oh, int ow) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = c / 4;
+    const long total = (long)n * oh * ow * c4;
+    if (idx >= total) return;
+    const int cc = (idx % c4) * 4;
+    long t = idx / c4;
+    const int ox = t % ow; t /= ow;
+    const int oy = t % oh;
+    const int b = t / oh;
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    bool nan[4] = {false, false, false, false};
+    for (int dy = 0; dy < 3; ++dy)
+        for (int dx = 0; dx < 3; ++dx) {
+            float v[4];
+            ld4<T>(x, (((long)b * h + oy * 2 + dy) * w + ox * 2 + dx) * c + cc, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { m[j] = fmaxf(m[j], v[j]); nan[j] |= v[j] != v[j]; }
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (nan[j]) m[j] = NAN;
+    st4<T>(y, (((long)b * oh + oy) * ow + ox) * c + cc, m);
+}
+
+// video.py:110,124: AdaptiveAvgPool2d((1,1)) over hw positions of an NHWC tensor -> f32 [n,c]
+template <typename T>
+__global__ void avgpool_kernel(const T* __restrict__ x, float* __restrict__ y, int n, int hw, int c) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)n * c) return;
+    const int cc = idx % c;
+    const int b = idx / c;
+    float s = 0.f;
+    for (int i = 0; i < hw; ++i) s += ldf<T>(x, ((long)b * hw + i) * c + cc);
+    y[idx] = s / (float)hw;
+}
+
+// ------------------------------------------------------------------------------------------------ tiny heads
+// out[m, j] = sum_k f(x[m,k]) * w[j,k] + b[j], n <= 16 outputs; optional ReLU on the input, optional softmax.
+// video.py:131-132 (relu1 -> fc2) + get_prob_video.py:107-109 (softmax dim=1); LSTM fc (video.py:184);
+// audio feature_downsample (audio_8_cl.py:189).  One wave per row.
+__global__ void small_linear_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                    float* __restrict__ logits, float* __restrict__ probs, int m, int k, int n,
+                                    int relu_in) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= m) return;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int kk = lane; kk < k; kk += 64) {
+        float xv = x[(long)row * k + kk];
+        if (relu_in) xv = relu_nan(xv);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < n) acc[j] += xv * w[(long)j * k + kk];
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < n) {
+            acc[j] = wave_sum(acc[j]) + b[j];
+            mx = fmaxf(mx, acc[j]);
+        }
+    if (lane == 0) {
+        float den = 0.f;
+        float e[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < n) {
+                if (logits) logits[(long)row * n + j] = acc[j];
+                e[j] = expf(acc[j] - mx);
+                den += e[j];
+            }
+        if (probs)
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < n) probs[(long)row * n + j] = e[j] / den;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LSTM cell
+// torch.nn.LSTM cell (video.py:173-178), gate order i,f,g,o.  xproj already holds x W_ih^T + b_ih + b_hh.
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__global__ void lstm_cell_kernel(const float* __restrict__ xproj, long xproj_ld, const float* __restrict__ hproj,
+                                 float* __restrict__ c, float* __restrict__ h_out, long h_ld, int n, int hid, int first) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)n * hid) return;
+    const int j = idx % hid;
+    const int r = idx / hid;
+    const float* xp = xproj + (long)r * xproj_ld;
+    float gi = xp[j], gf = xp[hid + j], gg = xp[2 * hid + j], go = xp[3 * hid + j];
+    float cp = 0.f;
+    if (!first) {
+        const float* hp = hproj + (long)r * 4 * hid;
+        gi += hp[j]; gf += hp[hid + j]; gg += hp[2 * hid + j]; go += hp[3 * hid + j];
+        cp = c[idx];
+    }
+    const float cn = sigmoidf_(gf) * cp + sigmoidf_(gi) * tanhf(gg);
+    c[idx] = cn;
+    h_out[(long)r * h_ld + j] = sigmoidf_(go) * tanhf(cn);
+}
+
+// ------------------------------------------------------------------------------------------------ audio front end
+// HF Wav2Vec2FeatureExtractor.zero_mean_unit_var_norm (call site get_prob_audio_8_cl.py:88-89):
+// (x - mean) / sqrt(var + 1e-7), population variance, per row.  One block per row.
+__global__ void wav_normalize_kernel(const float* __restrict__ x, float* __restrict__ y, int t) {
+    __shared__ float red[8];
+    __shared__ float bc;
+    const float* xr = x + (long)blockIdx.x * t;
+    float* yr = y + (long)blockIdx.x * t;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+    float s = 0.f;
+    for (int i = tid; i < t; i += blockDim.x) s += xr[i];
+    s = wave_sum(s);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    if (tid == 0) { float a = 0.f; for (int i = 0; i < nw; ++i) a += red[i]; bc = a / (float)t; }
+    __syncthreads();
+    const float mean = bc;
+    float q = 0.f;
+    for (int i = tid; i < t; i += blockDim.x) { const float d = xr[i] - mean; q += d * d; }
+    q = wave_sum(q);
+    __syncthreads();
+    if (lane == 0) red[wv] = q;
+    __syncthreads();
+    if (tid == 0) { float a = 0.f; for (int i = 0; i < nw; ++i) a += red[i]; bc = sqrtf(a / (float)t + 1e-7f); }
+    __syncthreads();
+    const float sd = bc;
+    for (int i = tid; i < t; i += blockDim.x) yr[i] = (xr[i] - mean) / sd;
+}
+
+// wav2vec2 feature-extractor layer 0: Conv1d(1 -> 512, k=10, stride 5, bias) -> LayerNorm(512) -> GELU, fused.
+// Output [n, t_out, 512] time-major.  One wave per time step, each lane owns 8 consecutive channels whose
+// 10-tap filters stay in registers for the whole block; the write (2 KiB contiguous per wave) is the cost.
+template <typename T>
+__global__ void __launch_bounds__(256) conv0_ln_gelu_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, const float* __restrict__ g,
+                                                         const float* __restrict__ beta, T* __restrict__ y, int t_in,
+                                                         int t_out, int steps_per_block) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c0 = lane * 8;
+    float wr[8][10], br[8], gr[8], ber[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) wr[j][k] = w[(c0 + j) * 10 + k];
+        br[j] = b[c0 + j]; gr[j] = g[c0 + j]; ber[j] = beta[c0 + j];
+    }
+    const int row = blockIdx.y;
+    const float* xr = x + (long)row * t_in;
+    const int t_begin = blockIdx.x * steps_per_block;
+    const int t_end = min(t_begin + steps_per_block, t_out);
+    for (int t = t_begin + wv; t < t_end; t += 4) {
+        float xv[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) xv[k] = xr[t * 5 + k];
+        float v[8];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) a += xv[k] * wr[j][k];
+            v[j] = a + br[j];
+            s += v[j];
+        }
+        const float mean = wave_sum(s) * (1.f / 512.f);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[j] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) * (1.f / 512.f) + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_erf((v[j] - mean) * rstd * gr[j] + ber[j]);
+        const long o = ((long)row * t_out + t) * 512 + c0;
+        st4<T>(y, o, v);
+        st4<T>(y, o + 4, v + 4);
+    }
+}
+
+// LayerNorm over the last dimension (c in {512, 1024}), optional residual add in front, optional GELU behind,
+// dual output (f32 residual-stream copy and/or bf16 GEMM-operand copy).  One wave per row.
+template <typename TI, int C>
+__global__ void __launch_bounds__(256) layernorm_kernel(const TI* __restrict__ x, const TI* __restrict__ res,
+                                                      const float* __restrict__ g, const float* __restrict__ b,
+                                                      float* __restrict__ yf, bf16_t* __restrict__ yb, long rows,
+                                                      float eps, int act) {
+    constexpr int PER = C / 64;  // 8 or 16 consecutive elements per lane
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const long base = row * C + lane * PER;
+    float v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i += 4) ld4<TI>(x, base + i, v + i);
+    if (res) {
+        float r[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i += 4) ld4<TI>(res, base + i, r + i);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) v[i] += r[i];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s += v[i];
+    const float mean = wave_sum(s) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const float d = v[i] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.f / C) + eps);
+#pragma unroll
+    for (int i = 0; i < PER; i += 4) {
+        const float4 gg = *reinterpret_cast<const float4*>(g + lane * PER + i);
+        const float4 bb = *reinterpret_cast<const float4*>(b + lane * PER + i);
+        v[i + 0] = (v[i + 0] - mean) * rstd * gg.x + bb.x;
+        v[i + 1] = (v[i + 1] - mean) * rstd * gg.y + bb.y;
+        v[i + 2] = (v[i + 2] - mean) * rstd * gg.z + bb.z;
+        v[i + 3] = (v[i + 3] - mean) * rstd * gg.w + bb.w;
+    }
+    if (act == 2) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) v[i] = gelu_erf(v[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; i += 4) {
+        if (yf) st4<float>(yf, base + i, v + i);
+        if (yb) st4<bf16_t>(yb, base + i, v + i);
+    }
+}
+
+// attention_layers.py:206-211,249-254: x + pe[:, :S]; writes f32 (residual) and/or bf16 (GEMM operand).
+__global__ void add_pe_kernel(const float* __restrict__ x, const float* __restrict__ pe, float* __restrict__ yf,
+                              bf16_t* __restrict__ yb, long total4, int s, int c) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total4) return;
+    const long e = idx * 4;
+    const int cc = e % c;
+    const int ss = (e / c) % s;
+    float v[4], p[4];
+    ld4<float>(x, e, v);
+    ld4<float>(pe, (long)ss * c + cc, p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += p[j];
+    if (yf) st4<float>(yf, e, v);
+    if (yb) st4<bf16_t>(yb, e, v);
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+// softmax(q k^T * scale) v for one (batch, head) per workgroup; S <= 256, d in {32, 64}.
+// wav2vec2 encoder self-attention (16 x 64) and attention_layers.py:10-38 (32 x 32, 16 x 64).
+// K (rows padded by 4 floats: conflict-free b128 row reads) and V live in LDS as f32; each wave owns query rows.
+template <typename T, int D>
+__global__ void __launch_bounds__(256) attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int s, int heads,
+                                                      float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int KP = D + 4;
+    float* ks = reinterpret_cast<float*>(smem_raw);           // [s][KP]
+    float* vs = ks + (long)s * KP;                            // [s][D]
+    float* ps = vs + (long)s * D;                             // [4][256]
+    float* qs = ps + 4 * 256;                                 // [4][D]
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int e = heads * D;
+    const long rowstride = 3L * e;
+    const T* base = qkv + (long)b * s * rowstride + h * D;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < s * (D / 4); i += 256) {
+        const int r = i / (D / 4), c4 = (i % (D / 4)) * 4;
+        float kv[4], vv[4];
+        ld4<T>(base, (long)r * rowstride + e + c4, kv);
+        ld4<T>(base, (long)r * rowstride + 2 * e + c4, vv);
+        *reinterpret_cast<float4*>(ks + r * KP + c4) = make_float4(kv[0], kv[1], kv[2], kv[3]);
+        *reinterpret_cast<float4*>(vs + r * D + c4) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    }
+    __syncthreads();
+    float* pw = ps + wv * 256;
+    float* qw = qs + wv * D;
+    for (int qi = wv; qi < s; qi += 4) {
+        if (lane < D) qw[lane] = ldf<T>(base, (long)qi * rowstride + lane) * scale;
+        __builtin_amdgcn_wave_barrier();
+        float sc[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = jj * 64 + lane;
+            float a = -INFINITY;
+            if (j < s) {
+                a = 0.f;
+#pragma unroll
+                for (int c = 0; c < D; c += 4) {
+                    const float4 kk = *reinterpret_cast<const float4*>(ks + j * KP + c);
+                    const float4 qq = *reinterpret_cast<const float4*>(qw + c);
+                    a += qq.x * kk.x + qq.y * kk.y + qq.z * kk.z + qq.w * kk.w;
+                }
+            }
+            sc[jj] = a;
+            mx = fmaxf(mx, a);
+        }
+        mx = wave_max(mx);
+        float den = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = jj * 64 + lane;
+            const float pv = j < s ? expf(sc[jj] - mx) : 0.f;
+            pw[j] = pv;
+            den += pv;
+        }
+        den = wave_sum(den);
+        __builtin_amdgcn_wave_barrier();
+        float o = 0.f;
+        if constexpr (D == 64) {
+            for (int j = 0; j < s; ++j) o += pw[j] * vs[j * D + lane];
+        } else {
+            const int c = lane & 31, half = lane >> 5;
+            for (int j = half; j < s; j += 2) o += pw[j] * vs[j * D + c];
+            o += __shfl_xor(o, 32, 64);
+        }
+        if (lane < D) stf<T>(out, ((long)b * s + qi) * e + h * D + lane, o / den);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ audio head
+// audio_8_cl.py:151-152: MaxPool1d(5) (stride 5, floor) then ReLU over time of [n, t_in, c].
+__global__ void maxpool1d_relu_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int t_in, int t_out,
+                                      int c, int k) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)n * t_out * c) return;
+    const int cc = idx % c;
+    const int t = (idx / c) % t_out;
+    const int b = idx / ((long)c * t_out);
+    float m = -INFINITY;
+    bool nan = false;
+    for (int i = 0; i < k; ++i) {
+        const float v = x[((long)b * t_in + t * k + i) * c + cc];
+        m = fmaxf(m, v);
+        nan |= v != v;
+    }
+    y[idx] = nan ? NAN : relu_nan(m);
+}
+
+// audio_8_cl.py:155-156: AdaptiveAvgPool1d(1) then ReLU: [n, t, c] -> [n, c]
+__global__ void mean_time_relu_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int t, int c) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)n * c) return;
+    const int cc = idx % c;
+    const int b = idx / c;
+    float s = 0.f;
+    for (int i = 0; i < t; ++i) s += x[((long)b * t + i) * c + cc];
+    y[idx] = relu_nan(s / (float)t);
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = f2bf(x[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ fusion
+// get_prob_audio_8_cl.py:94-101 + run.py:90: frame f's audio logits = mean over the windows whose frame span
+// [lo, hi) contains f (pandas float32 group mean).
+__global__ void frame_mean_kernel(const float* __restrict__ win, const int32_t* __restrict__ lo,
+                                  const int32_t* __restrict__ hi, int n_win, int c, int n_frames, float* __restrict__ out,
+                                  int32_t* __restrict__ count) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_frames * c) return;
+    const int f = idx / c, j = idx % c;
+    double s = 0.0;
+    int cnt = 0;
+    for (int w = 0; w < n_win; ++w)
+        if (lo[w] <= f && f < hi[w]) { s += (double)win[(long)w * c + j]; ++cnt; }
+    out[idx] = cnt ? (float)(s / cnt) : 0.f;
+    if (j == 0 && count) count[f] = cnt;
+}
+
+struct FuseParams {
+    double w[21];  // weights_1[m][k] * weights_2[m]
+    double pair_w[14];
+    int has_w1, cmask;
+};
+
+__device__ __forceinline__ void softmax7(const float* in, float* out) {
+    float mx = in[0];
+#pragma unroll
+    for (int k = 1; k < 7; ++k) mx = fmaxf(mx, in[k]);  // NaN handling below
+    bool nan = false;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) nan |= in[k] != in[k];
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { out[k] = expf(in[k] - mx); den += out[k]; }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) out[k] = nan ? NAN : out[k] / den;
+}
+
+// run.py:85-165 + data/utils.py:222-241.  One thread per frame; float32 tables promoted to float64 at the
+// weight multiply exactly like numpy does for `float32 ndarray * python list`.
+__global__ void fuse_kernel(const float* __restrict__ stat, const float* __restrict__ dyn, const float* __restrict__ aud,
+                            int n, int n_aud, int aud_c, FuseParams fp, double* __restrict__ comp_prob,
+                            int32_t* __restrict__ comp_argmax) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    const int order[7] = {0, 6, 5, 4, 1, 2, 3};  // video column -> audio order (get_prob_video.py:56-64, run.py:56-65)
+    const int p1[7] = {3, 4, 5, 2, 1, 3, 1}, p2[7] = {6, 6, 6, 6, 6, 5, 5};  // run.py:66-74
+    float s[7], dl[7], d[7], al[7], a[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { s[k] = stat[(long)f * 7 + order[k]]; dl[k] = dyn[(long)f * 7 + order[k]]; }
+    softmax7(dl, d);
+    const int fa = f < n_aud ? f : n_aud - 1;  // run.py:99-103 tail padding with the last audio row
+#pragma unroll
+    for (int k = 0; k < 7; ++k) al[k] = aud[(long)fa * aud_c + k];
+    softmax7(al, a);
+    if (fp.has_w1) {
+        // float32 table * python list -> float64 (run.py:108-111)
+        double pm[4][7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            pm[1][k] = (double)s[k] * fp.w[k];
+            pm[2][k] = (double)d[k] * fp.w[7 + k];
+            pm[3][k] = (double)a[k] * fp.w[14 + k];
+            pm[0][k] = pm[1][k] + pm[2][k] + pm[3][k];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            double q[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) q[k] = fp.cmask ? (pm[m][k] > 1.0 / 7.0 ? pm[m][k] : 0.0) : pm[m][k];
+            double best = 0.0;
+            int bi = 0;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) {
+                const double v = q[p1[c]] * fp.pair_w[2 * c] + q[p2[c]] * fp.pair_w[2 * c + 1];
+                comp_prob[((long)m * n + f) * 7 + c] = v;
+                if (c == 0) { best = v; bi = 0; }
+                else if (!(best != best) && (v > best || v != v)) { best = v; bi = c; }  // numpy argmax: first NaN wins
+            }
+            comp_argmax[(long)m * n + f] = bi;
+        }
+    } else {
+        // run.py:113-114: np.sum of float32 tables / 3 stays float32, and so does get_compound_expression's
+        // arithmetic (python scalars are weak); only the store into the float64 `prob` array widens.
+        float pm[4][7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            pm[1][k] = s[k]; pm[2][k] = d[k]; pm[3][k] = a[k];
+            pm[0][k] = ((s[k] + d[k]) + a[k]) / 3.0f;
+        }
+        const float thr = (float)(1.0 / 7.0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float q[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) q[k] = fp.cmask ? (pm[m][k] > thr ? pm[m][k] : 0.0f) : pm[m][k];
+            float best = 0.0f;
+            int bi = 0;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) {
+                const float v = q[p1[c]] * (float)fp.pair_w[2 * c] + q[p2[c]] * (float)fp.pair_w[2 * c + 1];
+                comp_prob[((long)m * n + f) * 7 + c] = (double)v;
+                if (c == 0) { best = v; bi = 0; }
+                else if (!(best != best) && (v > best || v != v)) { best = v; bi = c; }
+            }
+            comp_argmax[(long)m * n + f] = bi;
+        }
+    }
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace
+
+#define CHECK_LAUNCH(ctx, name)                                                                      \
+    do {                                                                                             \
+        hipError_t _e = hipGetLastError();                                                           \
+        if (_e != hipSuccess) return set_err((ctx), AVCER_EHIP, name " launch: %s", hipGetErrorString(_e)); \
+    } while (0)
+
+int k_preprocess(avcer_ctx* ctx, const uint8_t* frames, int n, int in_h, int in_w, void* out, int bf16, hipStream_t st) {
+    const long total = (long)n * PP * PP;
+    if (bf16) preprocess_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>(frames, (bf16_t*)out, n, in_h, in_w);
+    else preprocess_kernel<float><<<cdiv(total, 256), 256, 0, st>>>(frames, (float*)out, n, in_h, in_w);
+    CHECK_LAUNCH(ctx, "preprocess");
+    return AVCER_OK;
+}
+
+int k_maxpool3s2(avcer_ctx* ctx, const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int bf16, hipStream_t st) {
+    const long total = (long)n * oh * ow * (c / 4);
+    if (bf16) maxpool3s2_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, n, h, w, c, oh, ow);
+    else maxpool3s2_kernel<float><<<cdiv(total, 256), 256, 0, st>>>((const float*)x, (float*)y, n, h, w, c, oh, ow);
+    CHECK_LAUNCH(ctx, "maxpool3s2");
+    return AVCER_OK;
+}
+
+int k_avgpool_hw(avcer_ctx* ctx, const void* x, float* y, int n, int hw, int c, int bf16, hipStream_t st) {
+    const long total = (long)n * c;
+    if (bf16) avgpool_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>((const bf16_t*)x, y, n, hw, c);
+    else avgpool_kernel<float><<<cdiv(total, 256), 256, 0, st>>>((const float*)x, y, n, hw, c);
+    CHECK_LAUNCH(ctx, "avgpool");
+    return AVCER_OK;
+}
+
+int k_small_linear(avcer_ctx* ctx, const float* x, const float* w, const float* b, float* logits, float* probs, int m,
+                   int k, int n, int relu_in, hipStream_t st) {
+    if (n > 16) return set_err(ctx, AVCER_EINVAL, "small_linear: n=%d > 16", n);
+    small_linear_kernel<<<cdiv(m, 4), 256, 0, st>>>(x, w, b, logits, probs, m, k, n, relu_in);
+    CHECK_LAUNCH(ctx, "small_linear");
+    return AVCER_OK;
+}
+
+int k_lstm_cell(avcer_ctx* ctx, const float* xproj, int64_t xproj_ld, const float* hproj, float* c, float* h_out,
+                int64_t h_ld, int n, int hid, int first, hipStream_t st) {
+    lstm_cell_kernel<<<cdiv((long)n * hid, 256), 256, 0, st>>>(xproj, xproj_ld, hproj, c, h_out, h_ld, n, hid, first);
+    CHECK_LAUNCH(ctx, "lstm_cell");
+    return AVCER_OK;
+}
+
+int k_wav_normalize(avcer_ctx* ctx, const float* x, float* y, int n, int t, hipStream_t st) {
+    wav_normalize_kernel<<<n, 512, 0, st>>>(x, y, t);
+    CHECK_LAUNCH(ctx, "wav_normalize");
+    return AVCER_OK;
+}
+
+int k_conv0_ln_gelu(avcer_ctx* ctx, const float* x, const float* w, const float* b, const float* g, const float* beta,
+                    void* y, int n, int t_in, int t_out, int bf16, hipStream_t st) {
+    const int spb = 64;
+    dim3 grid(cdiv(t_out, spb), n);
+    if (bf16) conv0_ln_gelu_kernel<bf16_t><<<grid, 256, 0, st>>>(x, w, b, g, beta, (bf16_t*)y, t_in, t_out, spb);
+    else conv0_ln_gelu_kernel<float><<<grid, 256, 0, st>>>(x, w, b, g, beta, (float*)y, t_in, t_out, spb);
+    CHECK_LAUNCH(ctx, "conv0_ln_gelu");
+    return AVCER_OK;
+}
+
+int k_layernorm(avcer_ctx* ctx, const void* x, const void* res, const float* g, const float* b, void* yf, void* yb,
+                int64_t rows, int c, float eps, int act, int in_bf16, int /*unused*/, hipStream_t st) {
+    const int grid = cdiv(rows, 4);
+    if (c == 512 && !in_bf16)
+        layernorm_kernel<float, 512><<<grid, 256, 0, st>>>((const float*)x, (const float*)res, g, b, (float*)yf, (bf16_t*)yb, rows, eps, act);
+    else if (c == 512)
+        layernorm_kernel<bf16_t, 512><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)res, g, b, (float*)yf, (bf16_t*)yb, rows, eps, act);
+    else if (c == 1024 && !in_bf16)
+        layernorm_kernel<float, 1024><<<grid, 256, 0, st>>>((const float*)x, (const float*)res, g, b, (float*)yf, (bf16_t*)yb, rows, eps, act);
+    else if (c == 1024)
+        layernorm_kernel<bf16_t, 1024><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)res, g, b, (float*)yf, (bf16_t*)yb, rows, eps, act);
+    else
+        return set_err(ctx, AVCER_EINVAL, "layernorm: c=%d unsupported", c);
+    CHECK_LAUNCH(ctx, "layernorm");
+    return AVCER_OK;
+}
+
+int k_add_pe(avcer_ctx* ctx, const float* x, const float* pe, float* yf, bf16_t* yb, int n, int s, int c, hipStream_t st) {
+    const long total4 = (long)n * s * c / 4;
+    add_pe_kernel<<<cdiv(total4, 256), 256, 0, st>>>(x, pe, yf, yb, total4, s, c);
+    CHECK_LAUNCH(ctx, "add_pe");
+    return AVCER_OK;
+}
+
+int k_attention(avcer_ctx* ctx, const void* qkv, void* out, int n, int s, int heads, int d, float scale, int bf16,
+                hipStream_t st) {
+    if (s > 256 || s < 1) return set_err(ctx, AVCER_EINVAL, "attention: S=%d outside [1,256]", s);
+    if (d != 32 && d != 64) return set_err(ctx, AVCER_EINVAL, "attention: head dim %d", d);
+    const size_t lds = ((size_t)s * (d + 4) + (size_t)s * d + 4 * 256 + 4 * d) * sizeof(float);
+    const int grid = n * heads;
+#define ATT(T, D)                                                                                                    \
+    do {                                                                                                             \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)attention_kernel<T, D>,                                    \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        attention_kernel<T, D><<<grid, 256, lds, st>>>((const T*)qkv, (T*)out, s, heads, scale);                     \
+    } while (0)
+    if (bf16) { if (d == 64) ATT(bf16_t, 64); else ATT(bf16_t, 32); }
+    else { if (d == 64) ATT(float, 64); else ATT(float, 32); }
+#undef ATT
+    CHECK_LAUNCH(ctx, "attention");
+    return AVCER_OK;
+}
+
+int k_maxpool1d_relu(avcer_ctx* ctx, const float* x, float* y, int n, int t_in, int t_out, int c, int k, hipStream_t st) {
+    maxpool1d_relu_kernel<<<cdiv((long)n * t_out * c, 256), 256, 0, st>>>(x, y, n, t_in, t_out, c, k);
+    CHECK_LAUNCH(ctx, "maxpool1d_relu");
+    return AVCER_OK;
+}
+
+int k_mean_time_relu(avcer_ctx* ctx, const float* x, float* y, int n, int t, int c, hipStream_t st) {
+    mean_time_relu_kernel<<<cdiv((long)n * c, 256), 256, 0, st>>>(x, y, n, t, c);
+    CHECK_LAUNCH(ctx, "mean_time_relu");
+    return AVCER_OK;
+}
+
+int k_f32_to_bf16(avcer_ctx* ctx, const float* x, bf16_t* y, size_t n, hipStream_t st) {
+    f32_to_bf16_kernel<<<cdiv((long)n, 256), 256, 0, st>>>(x, y, n);
+    CHECK_LAUNCH(ctx, "f32_to_bf16");
+    return AVCER_OK;
+}
+
+int k_frame_mean(avcer_ctx* ctx, const float* win_logits, const int32_t* lo, const int32_t* hi, int n_win, int c,
+                 int n_frames, float* out, int32_t* count, hipStream_t st) {
+    frame_mean_kernel<<<cdiv((long)n_frames * c, 128), 128, 0, st>>>(win_logits, lo, hi, n_win, c, n_frames, out, count);
+    CHECK_LAUNCH(ctx, "frame_mean");
+    return AVCER_OK;
+}
+
+int k_fuse(avcer_ctx* ctx, const float* stat, const float* dyn, const float* aud, int n, int n_aud, int aud_c,
+           const double* w, int has_w1, int cwt, int cmask, double* comp_prob, int32_t* comp_argmax, hipStream_t st) {
+    FuseParams fp;
+    for (int i = 0; i < 21; ++i) fp.w[i] = w ? w[i] : 1.0;
+    // data/utils.py:228-236 with dict_weights of run.py:116-123 (Rule 2) or 1,1
+    static const int dictw[7] = {0, 5, 6, 5, 6, 4, 2};
+    static const int p1[7] = {3, 4, 5, 2, 1, 3, 1}, p2[7] = {6, 6, 6, 6, 6, 5, 5};
+    for (int c = 0; c < 7; ++c) {
+        if (cwt) {
+            const double sw = (double)(dictw[p1[c]] + dictw[p2[c]]);
+            fp.pair_w[2 * c] = dictw[p1[c]] / sw;
+            fp.pair_w[2 * c + 1] = dictw[p2[c]] / sw;
+        } else {
+            fp.pair_w[2 * c] = 1.0;
+            fp.pair_w[2 * c + 1] = 1.0;
+        }
+    }
+    fp.has_w1 = has_w1;
+    fp.cmask = cmask;
+    fuse_kernel<<<cdiv(n, 64), 64, 0, st>>>(stat, dyn, aud, n, n_aud, aud_c, fp, comp_prob, comp_argmax);
+    CHECK_LAUNCH(ctx, "fuse");
+    return AVCER_OK;
+}
+
+int k_pack_nchw(avcer_ctx* ctx, const float* x, int n, void* out, int bf16, hipStream_t st) {
+    const long total = (long)n * PP * PP;
+    if (bf16) pack_nchw_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>(x, (bf16_t*)out, n);
+    else pack_nchw_kernel<float><<<cdiv(total, 256), 256, 0, st>>>(x, (float*)out, n);
+    CHECK_LAUNCH(ctx, "pack_nchw");
+    return AVCER_OK;
+}
+
+int k_gather_windows(avcer_ctx* ctx, const float* feats, const int32_t* idx, int nwin, float* out, hipStream_t st) {
+    const long total4 = (long)nwin * 10 * 128;
+    gather_windows_kernel<<<cdiv(total4, 256), 256, 0, st>>>(feats, idx, out, total4);
+    CHECK_LAUNCH(ctx, "gather_windows");
+    return AVCER_OK;
+}
+
+int k_audio_chunks(avcer_ctx* ctx, const float* wav, const int32_t* starts, const int32_t* ends, int n, int window,
+                   int mode, float* out, hipStream_t st) {
+    audio_chunks_kernel<<<n, 512, 0, st>>>(wav, starts, ends, window, mode, out);
+    CHECK_LAUNCH(ctx, "audio_chunks");
+    return AVCER_OK;
+}

@@ -1,0 +1,196 @@
+"""Thin object wrapper over the C ABI: one Engine = one avcer_ctx on one GPU.
+
+torch is used for device memory (tensor.data_ptr()) and the current HIP stream only; every arithmetic step of
+the hot path runs inside libavcer_hip.so.  All methods raise AvcerError on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, packing
+from ._lib import AvcerError, ConvDesc
+
+MODE_FP32 = 0
+MODE_BF16 = 1
+PAD_MODES = {"mean": 0, "constant": 1, "repeat": 2}
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("avcer_amd needs a ROCm GPU (gfx950); there is no CPU path")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        torch.zeros(1, device=self.device)  # make sure the primary context exists before the library uses it
+        ctx = _lib.c_ctx()
+        rc = self.lib.avcer_ctx_create(device, C.byref(ctx))
+        if rc != 0:
+            raise AvcerError(rc, "avcer_ctx_create failed")
+        self.ctx = ctx
+        self.audio_classes = 0
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.avcer_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, rc: int):
+        if rc != 0:
+            raise AvcerError(rc, self.lib.avcer_last_error(self.ctx).decode("utf-8", "replace"))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, t, dtype):
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t))
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def _new(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    # ------------------------------------------------------------------ weights
+    def _load(self, fn, tensors):
+        blob = packing.to_blob(tensors)
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        self._check(fn(self.ctx, C.cast(buf, C.c_void_p), len(blob)))
+
+    def load_static(self, state_dict):
+        self._load(self.lib.avcer_load_static, packing.pack_static(state_dict))
+
+    def load_dynamic(self, state_dict):
+        self._load(self.lib.avcer_load_dynamic, packing.pack_dynamic(state_dict))
+
+    def load_audio(self, state_dict):
+        self._load(self.lib.avcer_load_audio, packing.pack_audio(state_dict))
+        self.audio_classes = self.lib.avcer_audio_num_classes(self.ctx)
+
+    # ------------------------------------------------------------------ forward passes
+    def static_forward(self, frames_u8, mode: int = MODE_FP32):
+        """frames u8 [N,H,W,3] RGB -> (logits [N,7], probs [N,7], feats [N,512] pre-ReLU)."""
+        x = self._dev(frames_u8, torch.uint8)
+        if x.dim() != 4 or x.shape[-1] != 3:
+            raise ValueError(f"frames must be [N,H,W,3] uint8, got {tuple(x.shape)}")
+        n, h, w = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+        logits, probs, feats = self._new(n, 7), self._new(n, 7), self._new(n, 512)
+        self._check(self.lib.avcer_static_forward(self.ctx, _ptr(x), n, h, w, mode, _ptr(logits), _ptr(probs),
+                                                  _ptr(feats), self._stream()))
+        return logits, probs, feats
+
+    def static_forward_nchw(self, x, mode: int = MODE_FP32):
+        x = self._dev(x, torch.float32)
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, 224, 224):
+            raise ValueError(f"input must be [N,3,224,224] float32, got {tuple(x.shape)}")
+        n = int(x.shape[0])
+        logits, probs, feats = self._new(n, 7), self._new(n, 7), self._new(n, 512)
+        self._check(self.lib.avcer_static_forward_nchw(self.ctx, _ptr(x), n, mode, _ptr(logits), _ptr(probs),
+                                                       _ptr(feats), self._stream()))
+        return logits, probs, feats
+
+    def gather_windows(self, feats, idx):
+        feats = self._dev(feats, torch.float32)
+        idx = self._dev(idx, torch.int32)
+        if idx.dim() != 2 or idx.shape[1] != 10 or feats.dim() != 2 or feats.shape[1] != 512:
+            raise ValueError("gather_windows: feats [*,512], idx [nwin,10]")
+        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= feats.shape[0]):
+            raise ValueError("gather_windows: index out of range")
+        out = self._new(idx.shape[0], 10, 512)
+        self._check(self.lib.avcer_gather_windows(self.ctx, _ptr(feats), _ptr(idx), int(idx.shape[0]), _ptr(out),
+                                                  self._stream()))
+        return out
+
+    def dynamic_forward(self, windows):
+        x = self._dev(windows, torch.float32)
+        if x.dim() != 3 or tuple(x.shape[1:]) != (10, 512):
+            raise ValueError(f"windows must be [N,10,512], got {tuple(x.shape)}")
+        out = self._new(x.shape[0], 7)
+        self._check(self.lib.avcer_dynamic_forward(self.ctx, _ptr(x), int(x.shape[0]), _ptr(out), self._stream()))
+        return out
+
+    def audio_forward(self, wav, normalize: bool = True, mode: int = MODE_FP32):
+        x = self._dev(wav, torch.float32)
+        if x.dim() != 2:
+            raise ValueError(f"wav must be [N,T], got {tuple(x.shape)}")
+        out = self._new(x.shape[0], self.audio_classes)
+        self._check(self.lib.avcer_audio_forward(self.ctx, _ptr(x), int(x.shape[0]), int(x.shape[1]), int(normalize),
+                                                 mode, _ptr(out), self._stream()))
+        return out
+
+    def audio_chunks(self, wav, starts, ends, window: int, padding: str = "mean"):
+        wav = self._dev(wav, torch.float32)
+        starts = self._dev(starts, torch.int32)
+        ends = self._dev(ends, torch.int32)
+        n = int(starts.numel())
+        if wav.dim() != 1 or ends.numel() != n:
+            raise ValueError("audio_chunks: wav [L], starts/ends [n]")
+        if n and (int(starts.min()) < 0 or int(ends.max()) > wav.numel() or bool((ends < starts).any())
+                  or int((ends - starts).max()) > window):
+            raise ValueError("audio_chunks: sample ranges out of bounds")
+        if padding == "repeat" and n and int((ends - starts).min()) == 0:
+            raise ZeroDivisionError("integer division or modulo by zero")  # data/utils.py:66 on an empty chunk
+        out = self._new(n, window)
+        self._check(self.lib.avcer_audio_chunks(self.ctx, _ptr(wav), _ptr(starts), _ptr(ends), n, int(window),
+                                                PAD_MODES[padding], _ptr(out), self._stream()))
+        return out
+
+    def audio_frame_mean(self, win_logits, frame_lo, frame_hi, n_frames: int):
+        x = self._dev(win_logits, torch.float32)
+        lo, hi = self._dev(frame_lo, torch.int32), self._dev(frame_hi, torch.int32)
+        out = self._new(n_frames, x.shape[1])
+        cnt = self._new(n_frames, dtype=torch.int32)
+        self._check(self.lib.avcer_audio_frame_mean(self.ctx, _ptr(x), _ptr(lo), _ptr(hi), int(x.shape[0]),
+                                                    int(x.shape[1]), int(n_frames), _ptr(out), _ptr(cnt), self._stream()))
+        return out, cnt
+
+    def fuse(self, stat, dyn_logits, aud_mean, n_aud: int, weights_1=None, weights_2=(1, 1, 1),
+             ce_weights_type: bool = False, ce_mask: bool = True):
+        stat = self._dev(stat, torch.float32)
+        dyn = self._dev(dyn_logits, torch.float32)
+        aud = self._dev(aud_mean, torch.float32)
+        n = int(stat.shape[0])
+        if tuple(stat.shape) != (n, 7) or tuple(dyn.shape) != (n, 7) or aud.dim() != 2 or aud.shape[1] < 7:
+            raise ValueError("fuse: stat/dyn [n,7], aud [n_aud,>=7]")
+        if not (1 <= n_aud <= aud.shape[0]):
+            raise ValueError("fuse: n_aud out of range")
+        w1 = (C.c_double * 21)(*np.asarray(weights_1, dtype=np.float64).reshape(21)) if weights_1 else None
+        w2 = (C.c_double * 3)(*[float(v) for v in weights_2])
+        prob = self._new(4, n, 7, dtype=torch.float64)
+        am = self._new(4, n, dtype=torch.int32)
+        self._check(self.lib.avcer_fuse(self.ctx, _ptr(stat), _ptr(dyn), _ptr(aud), n, int(n_aud), int(aud.shape[1]),
+                                        w1, w2, int(bool(ce_weights_type)), int(bool(ce_mask)), _ptr(prob), _ptr(am),
+                                        self._stream()))
+        return prob, am
+
+    def conv_gemm(self, desc: ConvDesc, dtype: int, x, w, scale, bias, residual, y):
+        self._check(self.lib.avcer_conv_gemm(self.ctx, C.byref(desc), dtype, _ptr(x), _ptr(w), _ptr(scale), _ptr(bias),
+                                             _ptr(residual), _ptr(y), self._stream()))
+
+    def debug_tap(self, name: str, numel: int, dtype=torch.float32):
+        """Arm a one-shot tap; returns the destination tensor (filled by the next forward pass)."""
+        dst = torch.zeros(numel, dtype=dtype, device=self.device)
+        self._tap_keepalive = dst
+        self._check(self.lib.avcer_debug_tap(self.ctx, name.encode(), _ptr(dst), dst.numel() * dst.element_size()))
+        return dst
+
+    def debug_tap_copied(self) -> int:
+        return int(self.lib.avcer_debug_tap_copied(self.ctx))
+
+    def gemm_stats(self, reset: bool = True):
+        n, f = C.c_int64(0), C.c_double(0.0)
+        self._check(self.lib.avcer_gemm_stats(self.ctx, C.byref(n), C.byref(f), int(reset)))
+        return n.value, f.value

@@ -1,0 +1,178 @@
+"""state_dict -> packed weight blob for libavcer_hip.so.
+
+Accepts the reference's own state_dict key names, so a real checkpoint
+(`torch.load("FER_static_ResNet50_AffectNet.pt")`, the LSTM file, `epoch_63.pth["model_state_dict"]`) packs the
+same way as the synthetic ones.  Layout transforms done here (all in float32 numpy):
+  * conv weights OIHW -> [O][kh][kw][I] (K contiguous, matches the NHWC gather order of the kernel);
+  * inference BatchNorm folded into per-channel (scale, bias) applied in the GEMM epilogue;
+  * the 7x7 stem packed as 8 tap rows x (8 pixels x 4 channels) with zero taps (see kernels.hip preprocess);
+  * LSTM bias_ih + bias_hh summed; q/k/v projection matrices concatenated into one [3E, E] GEMM;
+  * wav2vec2 positional-conv weight-norm materialised (w = g * v / ||v||, norm over dims 0,1) and split per group.
+
+Blob: "AVCERW01", u32 count, u32 0, then `count` entries {char name[96]; u32 ndim; u32 0; i64 dims[4];
+u64 offset; u64 nbytes}, then 64-byte aligned little-endian float32 payloads.
+"""
+from __future__ import annotations
+
+import struct
+from collections import OrderedDict
+
+import numpy as np
+
+STATIC_BN_EPS = 1e-3   # architectures/video.py:21 (eps=0.001 on every BatchNorm2d)
+AUDIO_BN_EPS = 1e-5    # torch.nn.BatchNorm1d default, architectures/audio_8_cl.py:150,154
+RESNET_STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
+PE_ROWS = 256          # attention kernel limit: S <= 256 tokens
+
+
+def _np(v) -> np.ndarray:
+    if hasattr(v, "detach"):
+        v = v.detach().cpu().numpy()
+    return np.asarray(v)
+
+
+def _f32(v) -> np.ndarray:
+    return np.ascontiguousarray(_np(v), dtype=np.float32)
+
+
+def _bn_fold(sd, p, eps, conv_bias=None):
+    g, b = _f32(sd[p + ".weight"]), _f32(sd[p + ".bias"])
+    m, v = _f32(sd[p + ".running_mean"]), _f32(sd[p + ".running_var"])
+    s = (g / np.sqrt(v + np.float32(eps))).astype(np.float32)
+    shift = -m if conv_bias is None else (_f32(conv_bias) - m)
+    return s, (shift * s + b).astype(np.float32)
+
+
+def _conv_w(w) -> np.ndarray:
+    w = _f32(w)  # [O, I, kh, kw] -> [O, kh*kw*I]
+    return np.ascontiguousarray(w.transpose(0, 2, 3, 1)).reshape(w.shape[0], -1)
+
+
+def _conv1d_w(w) -> np.ndarray:
+    w = _f32(w)  # [O, I, k] -> [O, k*I]
+    return np.ascontiguousarray(w.transpose(0, 2, 1)).reshape(w.shape[0], -1)
+
+
+def pack_static(sd) -> "OrderedDict[str, np.ndarray]":
+    """ResNet50(7) state_dict (architectures/video.py:93-166)."""
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    w = _f32(sd["conv_layer_s2_same.weight"])  # [64, 3, 7, 7]
+    stem = np.zeros((64, 8, 8, 4), np.float32)
+    stem[:, :7, :7, :3] = w.transpose(0, 2, 3, 1)
+    out["stem.w"] = stem.reshape(64, 256)
+    out["stem.s"], out["stem.b"] = _bn_fold(sd, "batch_norm1", STATIC_BN_EPS)
+    for li, (planes, blocks, _) in enumerate(RESNET_STAGES, start=1):
+        for b in range(blocks):
+            src, dst = f"layer{li}.{b}", f"l{li}.{b}"
+            for i in (1, 2, 3):
+                out[f"{dst}.c{i}.w"] = _conv_w(sd[f"{src}.conv{i}.weight"])
+                out[f"{dst}.c{i}.s"], out[f"{dst}.c{i}.b"] = _bn_fold(sd, f"{src}.batch_norm{i}", STATIC_BN_EPS)
+            if b == 0:
+                out[f"{dst}.ds.w"] = _conv_w(sd[f"{src}.i_downsample.0.weight"])
+                out[f"{dst}.ds.s"], out[f"{dst}.ds.b"] = _bn_fold(sd, f"{src}.i_downsample.1", STATIC_BN_EPS)
+    out["fc1.w"], out["fc1.b"] = _f32(sd["fc1.weight"]), _f32(sd["fc1.bias"])
+    out["fc2.w"], out["fc2.b"] = _f32(sd["fc2.weight"]), _f32(sd["fc2.bias"])
+    return out
+
+
+def pack_dynamic(sd) -> "OrderedDict[str, np.ndarray]":
+    """LSTMPyTorch state_dict (architectures/video.py:169-185)."""
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name in ("lstm1", "lstm2"):
+        out[f"{name}.wih.w"] = _f32(sd[f"{name}.weight_ih_l0"])
+        out[f"{name}.whh.w"] = _f32(sd[f"{name}.weight_hh_l0"])
+        out[f"{name}.b"] = (_f32(sd[f"{name}.bias_ih_l0"]) + _f32(sd[f"{name}.bias_hh_l0"])).astype(np.float32)
+    out["fc.w"], out["fc.b"] = _f32(sd["fc.weight"]), _f32(sd["fc.bias"])
+    return out
+
+
+def pos_conv_weight(sd) -> np.ndarray:
+    p = "wav2vec2.encoder.pos_conv_embed.conv"
+    if p + ".parametrizations.weight.original0" in sd:
+        g, v = _f32(sd[p + ".parametrizations.weight.original0"]), _f32(sd[p + ".parametrizations.weight.original1"])
+    elif p + ".weight_g" in sd:
+        g, v = _f32(sd[p + ".weight_g"]), _f32(sd[p + ".weight_v"])
+    else:
+        return _f32(sd[p + ".weight"])
+    import torch
+
+    # the very function torch's weight_norm parametrisation evaluates (dim=2), so the packed weight is bit-identical
+    return torch._weight_norm(torch.from_numpy(v), torch.from_numpy(g), 2).numpy()
+
+
+def pack_audio(sd) -> "OrderedDict[str, np.ndarray]":
+    """ExprModelV3 / ExprModelV2 state_dict (architectures/audio_8_cl.py:131-190, audio_7_cl.py)."""
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    w2 = "wav2vec2."
+    for i in range(7):
+        p = f"{w2}feature_extractor.conv_layers.{i}"
+        cw = _f32(sd[p + ".conv.weight"])
+        out[f"fe{i}.w"] = cw.reshape(512, 10) if i == 0 else _conv1d_w(cw)
+        out[f"fe{i}.cb"] = _f32(sd[p + ".conv.bias"])
+        out[f"fe{i}.ln.g"], out[f"fe{i}.ln.b"] = _f32(sd[p + ".layer_norm.weight"]), _f32(sd[p + ".layer_norm.bias"])
+    p = w2 + "feature_projection."
+    out["fp.ln.g"], out["fp.ln.b"] = _f32(sd[p + "layer_norm.weight"]), _f32(sd[p + "layer_norm.bias"])
+    out["fp.w"], out["fp.b"] = _f32(sd[p + "projection.weight"]), _f32(sd[p + "projection.bias"])
+    pw = pos_conv_weight(sd)  # [1024, 64, 128] (out, in/groups, k)
+    for g in range(16):
+        out[f"pos.g{g}.w"] = _conv1d_w(pw[g * 64:(g + 1) * 64])
+    out["pos.b"] = _f32(sd[w2 + "encoder.pos_conv_embed.conv.bias"])
+    for l in range(12):
+        p = f"{w2}encoder.layers.{l}."
+        out[f"enc{l}.ln1.g"], out[f"enc{l}.ln1.b"] = _f32(sd[p + "layer_norm.weight"]), _f32(sd[p + "layer_norm.bias"])
+        a = p + "attention."
+        out[f"enc{l}.qkv.w"] = np.concatenate([_f32(sd[a + f"{n}_proj.weight"]) for n in "qkv"], axis=0)
+        out[f"enc{l}.qkv.b"] = np.concatenate([_f32(sd[a + f"{n}_proj.bias"]) for n in "qkv"], axis=0)
+        out[f"enc{l}.o.w"], out[f"enc{l}.o.b"] = _f32(sd[a + "out_proj.weight"]), _f32(sd[a + "out_proj.bias"])
+        out[f"enc{l}.ln2.g"] = _f32(sd[p + "final_layer_norm.weight"])
+        out[f"enc{l}.ln2.b"] = _f32(sd[p + "final_layer_norm.bias"])
+        f = p + "feed_forward."
+        out[f"enc{l}.ff1.w"], out[f"enc{l}.ff1.b"] = _f32(sd[f + "intermediate_dense.weight"]), _f32(sd[f + "intermediate_dense.bias"])
+        out[f"enc{l}.ff2.w"], out[f"enc{l}.ff2.b"] = _f32(sd[f + "output_dense.weight"]), _f32(sd[f + "output_dense.bias"])
+    out["enc.ln.g"], out["enc.ln.b"] = _f32(sd[w2 + "encoder.layer_norm.weight"]), _f32(sd[w2 + "encoder.layer_norm.bias"])
+    pe = _f32(sd["tl1.positional_encoding.pe"]).reshape(-1, 1024)
+    out["pe"] = np.ascontiguousarray(pe[:PE_ROWS])
+    for l in (1, 2):
+        t = f"tl{l}."
+        a = t + "self_attention."
+        out[f"tl{l}.qkv.w"] = np.concatenate(
+            [_f32(sd[a + "query_w.weight"]), _f32(sd[a + "keys_w.weight"]), _f32(sd[a + "values_w.weight"])], axis=0)
+        out[f"tl{l}.o.w"] = _f32(sd[a + "ff_layer_after_concat.weight"])
+        out[f"tl{l}.ln1.g"] = _f32(sd[t + "add_norm_after_attention.layer_norm.weight"])
+        out[f"tl{l}.ln1.b"] = _f32(sd[t + "add_norm_after_attention.layer_norm.bias"])
+        out[f"tl{l}.ff1.w"], out[f"tl{l}.ff1.b"] = _f32(sd[t + "feed_forward.layer_1.weight"]), _f32(sd[t + "feed_forward.layer_1.bias"])
+        out[f"tl{l}.ff2.w"], out[f"tl{l}.ff2.b"] = _f32(sd[t + "feed_forward.layer_2.weight"]), _f32(sd[t + "feed_forward.layer_2.bias"])
+        out[f"tl{l}.ln2.g"] = _f32(sd[t + "add_norm_after_ff.layer_norm.weight"])
+        out[f"tl{l}.ln2.b"] = _f32(sd[t + "add_norm_after_ff.layer_norm.bias"])
+        # tl{l}.feed_forward.layer_norm.* exists in the state_dict but is never applied (attention_layers.py:46,50-57)
+    out["td0.w"] = _conv1d_w(sd["time_downsample.0.weight"])
+    out["td0.s"], out["td0.b"] = _bn_fold(sd, "time_downsample.1", AUDIO_BN_EPS, sd["time_downsample.0.bias"])
+    out["td4.w"] = _conv1d_w(sd["time_downsample.4.weight"])
+    out["td4.s"], out["td4.b"] = _bn_fold(sd, "time_downsample.5", AUDIO_BN_EPS, sd["time_downsample.4.bias"])
+    out["fd.w"], out["fd.b"] = _f32(sd["feature_downsample.weight"]), _f32(sd["feature_downsample.bias"])
+    return out
+
+
+def to_blob(tensors: "OrderedDict[str, np.ndarray]") -> bytes:
+    entry = struct.Struct("<96sII4qQQ")
+    table_end = 16 + entry.size * len(tensors)
+    off = (table_end + 63) & ~63
+    recs, payload = [], []
+    for name, a in tensors.items():
+        a = np.ascontiguousarray(a, dtype="<f4")
+        if a.ndim > 4 or len(name.encode()) > 95:
+            raise ValueError(f"cannot pack {name} with shape {a.shape}")
+        dims = list(a.shape) + [0] * (4 - a.ndim)
+        recs.append(entry.pack(name.encode(), a.ndim, 0, *dims, off, a.nbytes))
+        payload.append((off, a))
+        off = (off + a.nbytes + 63) & ~63
+    buf = bytearray(off)
+    buf[0:8] = b"AVCERW01"
+    struct.pack_into("<II", buf, 8, len(tensors), 0)
+    pos = 16
+    for r in recs:
+        buf[pos:pos + entry.size] = r
+        pos += entry.size
+    for o, a in payload:
+        buf[o:o + a.nbytes] = a.tobytes()
+    return bytes(buf)

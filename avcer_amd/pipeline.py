@@ -1,0 +1,44 @@
+"""Full audio-visual path for batches of clips: static CNN + LSTM + audio model + fusion (run.py:192-268 without
+face detection, file I/O and plotting)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import synth
+from .engine import Engine, MODE_FP32
+from .fusion import WEIGHTS_AV_1, fuse_clips
+from .models import AudioModel, DynamicModel, StaticModel
+from .video_pipeline import visual_forward
+
+
+class AVPipeline:
+    def __init__(self, device: int = 0, seed: int = 42, state_dicts=None, mode: int = MODE_FP32, audio: bool = True):
+        """state_dicts = (static, dynamic, audio) in the reference's key names; None -> synthetic weights."""
+        self.engine = Engine(device)
+        self.mode = mode
+        sds = state_dicts or (synth.static_state_dict(seed), synth.dynamic_state_dict(seed),
+                              synth.audio_state_dict(seed) if audio else None)
+        self.static = StaticModel(self.engine, sds[0], mode)
+        self.dynamic = DynamicModel(self.engine, sds[1])
+        self.audio = AudioModel(self.engine, sds[2], mode) if sds[2] is not None else None
+
+    def clip_records(self, frames_u8: torch.Tensor, wav: torch.Tensor, fps: float = 25, present=None):
+        """frames_u8 [N,T,224,224,3], wav [N,L] (one window per clip).  Returns the per-clip record that is
+        all-gathered across GPUs: (static_probs [N,T,7], dyn_logits [N,T,7], audio_logits [N,C])."""
+        n, t = int(frames_u8.shape[0]), int(frames_u8.shape[1])
+        if present is None:
+            present = np.ones((n, t), dtype=bool)
+        stat, dyn = visual_forward(self.engine, frames_u8, present, fps, self.mode)
+        aud = self.engine.audio_forward(wav, normalize=True, mode=self.mode)
+        return stat, dyn, aud
+
+    def fuse_records(self, stat, dyn, aud, weights_1=WEIGHTS_AV_1, weights_2=(1, 1, 1), ce_weights_type=False,
+                     ce_mask=True):
+        return fuse_clips(self.engine, stat, dyn, aud, weights_1, weights_2, ce_weights_type, ce_mask)
+
+    def run_clips(self, frames_u8, wav, fps: float = 25, present=None):
+        stat, dyn, aud = self.clip_records(frames_u8, wav, fps, present)
+        prob, am = self.fuse_records(stat, dyn, aud)
+        return {"static_probs": stat, "dynamic_logits": dyn, "audio_logits": aud, "compound_prob": prob,
+                "compound_argmax": am}

@@ -1,0 +1,97 @@
+"""Batched counterpart of get_prob_video.preprocess_video_and_predict (get_prob_video.py:67-204).
+
+The reference walks frames one by one; its rules only decide WHICH feature rows form each LSTM window and WHICH
+result row each frame reports.  `plan_clip` restates those rules as index arithmetic on the host (no tensor data),
+the GPU then runs the static CNN once over all present frames, gathers the windows, runs the LSTM once, and the
+per-frame tables are assembled by row gathers.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from .engine import Engine, MODE_FP32
+
+DICT_EMO_VIDEO = ("Neutral", "Happiness", "Sadness", "Surprise", "Fear", "Disgust", "Anger")  # get_prob_video.py:56-64
+
+
+def lstm_step(fps: float) -> int:
+    """get_prob_video.py:77 (Python's round: banker's rounding)."""
+    return round((5 * fps) / 25)
+
+
+@dataclass
+class ClipPlan:
+    static_src: list = field(default_factory=list)  # per frame: row of the feature/prob table, -1 = zeros
+    dyn_src: list = field(default_factory=list)     # per frame: row of the LSTM output table, -1 = zeros
+    windows: list = field(default_factory=list)     # per LSTM evaluation: 10 feature-table rows
+
+
+def plan_clip(present, fps: float, feat_base: int = 0, win_base: int = 0) -> ClipPlan:
+    """Hold / zero / reset rules of get_prob_video.py:91-178 for one clip.  `present[i]` = a face crop exists."""
+    step = lstm_step(fps)
+    if step <= 0:
+        raise ZeroDivisionError("integer division or modulo by zero")  # `curr_idx_frame % step`, get_prob_video.py:114
+    plan = ClipPlan()
+    window: list[int] = []
+    last = None
+    nfeat = 0
+    for i, p in enumerate(present):
+        if p:
+            s = feat_base + nfeat
+            nfeat += 1
+            if i % step == 0:
+                window = [s] * 10 if not window else window[1:] + [s]   # :117-120
+                plan.windows.append(list(window))
+                last = win_base + len(plan.windows) - 1
+                d = last
+            else:
+                d = last if last is not None else -1                      # :157-162
+            plan.static_src.append(s)
+            plan.dyn_src.append(d)
+        else:
+            window = []                                                   # :169
+            if last is not None:                                          # :170-173
+                plan.static_src.append(plan.static_src[-1])
+                plan.dyn_src.append(plan.dyn_src[-1])
+            else:                                                         # :175-178
+                plan.static_src.append(-1)
+                plan.dyn_src.append(-1)
+    return plan
+
+
+def visual_forward(engine: Engine, frames_u8: torch.Tensor, present, fps: float, mode: int = MODE_FP32):
+    """frames_u8 [N,T,H,W,3] (or [T,H,W,3]) RGB tiles, present [N,T] bool.
+    Returns (static_probs [N,T,7], dynamic_logits [N,T,7]) float32 in VIDEO column order (DICT_EMO_VIDEO).
+    The reference's tables turn float64 when they contain a zero placeholder row; the values are the same."""
+    single = frames_u8.dim() == 4
+    if single:
+        frames_u8 = frames_u8[None]
+    present = np.asarray(present, dtype=bool).reshape(frames_u8.shape[0], frames_u8.shape[1])
+    n, t = present.shape
+    plans, fb, wb = [], 0, 0
+    for c in range(n):
+        p = plan_clip(present[c], fps, fb, wb)
+        fb += int(present[c].sum())
+        wb += len(p.windows)
+        plans.append(p)
+    dev = engine.device
+    flat = frames_u8.reshape(n * t, *frames_u8.shape[2:])
+    stat = torch.zeros(n * t, 7, device=dev)
+    dyn = torch.zeros(n * t, 7, device=dev)
+    if fb:
+        sel = torch.from_numpy(np.nonzero(present.reshape(-1))[0]).to(dev)
+        frames_sel = flat.to(dev) if fb == n * t else flat.to(dev).index_select(0, sel)
+        _, probs, feats = engine.static_forward(frames_sel, mode)
+        zero_row = torch.zeros(1, 7, device=dev)
+        s_src = torch.tensor([i if i >= 0 else fb for p in plans for i in p.static_src], device=dev)
+        stat = torch.cat([probs, zero_row]).index_select(0, s_src)
+        if wb:
+            idx = torch.tensor([w for p in plans for w in p.windows], dtype=torch.int32, device=dev)
+            dl = engine.dynamic_forward(engine.gather_windows(feats, idx))
+            d_src = torch.tensor([i if i >= 0 else wb for p in plans for i in p.dyn_src], device=dev)
+            dyn = torch.cat([dl, zero_row]).index_select(0, d_src)
+    stat, dyn = stat.view(n, t, 7), dyn.view(n, t, 7)
+    return (stat[0], dyn[0]) if single else (stat, dyn)

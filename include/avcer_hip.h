@@ -1,0 +1,160 @@
+/*
+ * libavcer_hip.so -- C ABI of the MI355X (gfx950) implementation of AVCER's inference hot path.
+ *
+ * AVCER (github.com/ElenaRyumina/AVCER) has no FFI/plugin layer: its seam is the Python call surface
+ * of four callables and two numpy functions.  Each entry point below replaces one
+ * of them; the reference location it stands in for is cited as  ref: <file>:<lines>  relative to the
+ * reference's src/ directory.  The Python mirror with the reference's own call signatures lives in
+ * avcer_amd/ (static_model.py, dynamic_model.py, audio_model.py, fusion.py) and binds these symbols
+ * with ctypes; INTEGRATION.md shows the stub a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative AVCER_E* code and never throws;
+ *     avcer_last_error(ctx) returns a human-readable message for the last failure on that context;
+ *   - all tensor pointers are DEVICE pointers owned by the caller unless marked "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous on it;
+ *   - weights and workspace are owned by the context (hipMalloc at load / first use; a call that has to
+ *     grow the workspace synchronises the device once);
+ *   - one context per (device, host thread): a context is not re-entrant.
+ */
+#ifndef AVCER_HIP_H
+#define AVCER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct avcer_ctx avcer_ctx;
+typedef void* avcer_stream_t;
+
+enum {
+    AVCER_OK = 0,
+    AVCER_EINVAL = -1,   /* bad argument / shape */
+    AVCER_ENOMEM = -2,   /* device allocation failed */
+    AVCER_EHIP = -3,     /* HIP runtime error (message holds hipGetErrorString) */
+    AVCER_ESTATE = -4,   /* weights for this model not loaded */
+    AVCER_EFORMAT = -5   /* packed weight blob malformed */
+};
+
+/* arithmetic mode of the MFMA contractions */
+enum {
+    AVCER_MODE_FP32 = 0, /* f32 operands, v_mfma_f32_32x32x2_f32: parity mode (<=1e-4 on probabilities) */
+    AVCER_MODE_BF16 = 1  /* bf16 operands / f32 accumulate, v_mfma_f32_16x16x32_bf16: throughput mode */
+};
+
+int avcer_abi_version(void);
+
+int avcer_ctx_create(int device, avcer_ctx** out);
+void avcer_ctx_destroy(avcer_ctx* ctx);
+const char* avcer_last_error(const avcer_ctx* ctx);
+
+/* Packed weights (host pointers; the library copies them to the device and owns the copy).
+ * Blob layout: see avcer_amd/packing.py (header "AVCERW01", tensor table, 64-byte aligned f32 payloads).
+ *   ref: get_prob_video.py:22-25 (ResNet50 state_dict), :51-54 (LSTM state_dict),
+ *        get_prob_audio_8_cl.py:52-66 (ExprModelV3 state_dict) */
+int avcer_load_static(avcer_ctx* ctx, const void* blob_host, size_t nbytes);
+int avcer_load_dynamic(avcer_ctx* ctx, const void* blob_host, size_t nbytes);
+int avcer_load_audio(avcer_ctx* ctx, const void* blob_host, size_t nbytes);
+
+/* Static visual model on face tiles.
+ *   ref: data/utils.py:19-39 (pth_processing: NEAREST resize to 224, u8 HWC -> f32, RGB->BGR, mean subtract)
+ *        architectures/video.py:115-133 (ResNet.extract_features / forward)
+ *        get_prob_video.py:47-49,103-112 (fc1 forward hook "features", softmax(dim=1))
+ * frames_hwc  u8 [n, in_h, in_w, 3] RGB.   logits/probs f32 [n,7] (video class order), feats f32 [n,512]
+ * (fc1 output BEFORE ReLU).  Any of the three outputs may be NULL. */
+int avcer_static_forward(avcer_ctx* ctx, const uint8_t* frames_hwc, int n, int in_h, int in_w, int mode,
+                         float* logits, float* probs, float* feats, avcer_stream_t stream);
+
+/* The same model on an already preprocessed tensor, i.e. the exact argument of the reference's
+ * `pth_model_static(x)`:  x f32 [n,3,224,224] (BGR, mean-subtracted).   ref: get_prob_video.py:103-109 */
+int avcer_static_forward_nchw(avcer_ctx* ctx, const float* x, int n, int mode, float* logits, float* probs,
+                              float* feats, avcer_stream_t stream);
+
+/* LSTM window assembly: out[w, s, :] = relu(feats[idx[w, s], :]).
+ *   ref: get_prob_video.py:115-123 (F.relu(features), 10-deep sliding window, first feature replicated x10)
+ * feats f32 [*,512], idx i32 [nwin,10] (device), out f32 [nwin,10,512]. */
+int avcer_gather_windows(avcer_ctx* ctx, const float* feats, const int32_t* idx, int nwin, float* out,
+                         avcer_stream_t stream);
+
+/* Dynamic visual model on windows of 10 ReLU'd fc1 features.
+ *   ref: architectures/video.py:169-185 (LSTMPyTorch.forward), get_prob_video.py:122-129
+ * windows f32 [n,10,512] -> logits f32 [n,7] (raw logits, no softmax). Always f32 arithmetic. */
+int avcer_dynamic_forward(avcer_ctx* ctx, const float* windows, int n, float* logits, avcer_stream_t stream);
+
+/* Audio model on padded waveform windows.
+ *   ref: get_prob_audio_8_cl.py:87-92 (HF feature-extractor normalisation + audio_model(x))
+ *        architectures/audio_8_cl.py:179-190 (ExprModelV3.forward), architectures/attention_layers.py:221-267
+ *        transformers==4.36.2 Wav2Vec2Model (third party, config of audeering/wav2vec2-large-robust-12-ft-emotion-msp-dim)
+ * wav f32 [n,t] (already padded to the window), normalize != 0 applies (x-mean)/sqrt(var+1e-7) per row first.
+ * logits f32 [n, n_classes] raw logits (n_classes = 8 for ExprModelV3, 7 for ExprModelV2 weights). */
+int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int t, int normalize, int mode,
+                        float* logits, avcer_stream_t stream);
+int avcer_audio_num_classes(const avcer_ctx* ctx);
+
+/* Window slicing + padding of one waveform.
+ *   ref: get_prob_audio_8_cl.py:78-86, data/utils.py:63-71 (pad_wav, "repeat"), :74-89 (pad_wav_zeros, "mean"/"constant")
+ * wav f32 [len]; starts/ends i32 [n] (device) sample ranges; out f32 [n, window];
+ * mode 0 = pad with the chunk mean (NaN for an empty chunk, as torch.mean does), 1 = zeros, 2 = repeat. */
+int avcer_audio_chunks(avcer_ctx* ctx, const float* wav, const int32_t* starts, const int32_t* ends, int n,
+                       int window, int mode, float* out, avcer_stream_t stream);
+
+/* Per-frame mean of window logits.
+ *   ref: get_prob_audio_8_cl.py:94-101 (logits replicated for frames [lo,hi) of each window),
+ *        run.py:90 (audio_df.groupby("frames").mean())
+ * win_logits f32 [n_win, c], frame_lo/hi i32 [n_win]; out f32 [n_frames, c]; count i32 [n_frames]
+ * (count 0 -> row left as zeros: no window covers that frame). */
+int avcer_audio_frame_mean(avcer_ctx* ctx, const float* win_logits, const int32_t* frame_lo, const int32_t* frame_hi,
+                           int n_win, int c, int n_frames, float* out, int32_t* count, avcer_stream_t stream);
+
+/* Probability fusion and compound-expression rule.
+ *   ref: run.py:25-165 (get_c_expr_db_pred), data/utils.py:125-127 (softmax), :222-241 (get_compound_expression)
+ * stat f32 [n,7] softmaxed static probs and dyn_logits f32 [n,7], both in VIDEO column order;
+ * aud_mean f32 [n_aud, c>=7] per-frame mean audio logits in audio order, rows >= n_aud repeat row n_aud-1 (run.py:99-103);
+ * w1 host f64 [3,7] or NULL (plain mean, run.py:113-114), w2 host f64 [3];
+ * comp_prob f64 [4,n,7] and comp_argmax i32 [4,n] in the order AV, VS, VD, A. */
+int avcer_fuse(avcer_ctx* ctx, const float* stat, const float* dyn_logits, const float* aud_mean, int n, int n_aud,
+               int aud_c, const double* w1_host, const double* w2_host, int ce_weights_type, int ce_mask,
+               double* comp_prob, int32_t* comp_argmax, avcer_stream_t stream);
+
+/* The contraction kernel itself (implicit-GEMM convolution with fused epilogue), exported for kernel-level
+ * parity tests and micro-benchmarks:  Y[m, n] = act(scale[n] * sum_k A[m,k] * W[n,k] + bias[n] (+ R[m,n]))
+ * where A is gathered from an NHWC tensor.  See avcer_conv_desc. dtype: 0 = f32 in/out, 1 = bf16 in/out,
+ * 2 = bf16 in / f32 out. */
+typedef struct avcer_conv_desc {
+    int32_t batch, in_h, in_w;       /* input extents used for bounds (zero padding outside) */
+    int32_t out_h, out_w;            /* M = batch*out_h*out_w */
+    int32_t cin;                     /* contiguous channels per tap (multiple of 8; of 4 for f32) */
+    int32_t kh, kw;                  /* taps; K = kh*kw*cin */
+    int32_t stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
+    int64_t x_stride_b, x_stride_h, x_stride_w; /* element strides of the input */
+    int32_t x_coff;                  /* channel offset into the input pixel */
+    int32_t n;                       /* output channels (multiple of 64) */
+    int64_t y_ld; int32_t y_coff;    /* output row stride (elements) and channel offset */
+    int64_t r_ld; int32_t r_coff;    /* residual row stride / offset (if residual != NULL) */
+    int32_t act;                     /* 0 none, 1 relu, 2 gelu(erf) */
+    int32_t res_after_act;           /* 0: act(v + r), 1: act(v) + r */
+} avcer_conv_desc;
+
+int avcer_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, const void* x, const void* w,
+                    const float* scale, const float* bias, const void* residual, void* y, avcer_stream_t stream);
+
+/* Last launch statistics of the dominant kernel (for bench.py's roofline object): number of conv_gemm
+ * launches and their summed algorithmic FLOPs since the previous call to this function. */
+int avcer_gemm_stats(avcer_ctx* ctx, int64_t* launches, double* flops, int reset);
+
+/* Debug aid for parity tests: arm a one-shot tap; the next forward pass copies up to `bytes` raw bytes of the
+ * named intermediate activation (first sub-batch) into dst_dev.  Names: static "pre", "stem_conv", "stem",
+ * "l1b0_c1", "l1b0_c2", "l1b0_ds", "l1b0", "layer1".."layer4", "avgpool"; audio "norm", "conv0", "extract", "proj",
+ * "posconv", "layer0".."layer11", "w2v", "tl1", "tl2", "td0", "mp", "td4", "pooled".  Activations are NHWC / time-major,
+ * f32 in AVCER_MODE_FP32 and bf16 in AVCER_MODE_BF16 (residual streams "proj".."tl2" and the head are always f32).
+ * avcer_debug_tap_copied returns the number of bytes copied (-1 if the tap did not fire). */
+int avcer_debug_tap(avcer_ctx* ctx, const char* name, void* dst_dev, size_t bytes);
+int64_t avcer_debug_tap_copied(const avcer_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVCER_HIP_H */

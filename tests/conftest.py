@@ -40,3 +40,33 @@ def sd_dynamic():
 def sd_audio():
     from avcer_amd import synth
     return synth.to_torch(synth.audio_state_dict(42))
+
+
+# ----------------------------------------------------------------------------- GPU fixtures (used only by -m gpu tests)
+@pytest.fixture(scope="session")
+def engine():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from avcer_amd.engine import Engine
+
+    return Engine(0)
+
+
+@pytest.fixture(scope="session")
+def engine_static(engine, sd_static):
+    engine.load_static(sd_static)
+    return engine
+
+
+@pytest.fixture(scope="session")
+def engine_dynamic(engine, sd_dynamic):
+    engine.load_dynamic(sd_dynamic)
+    return engine
+
+
+@pytest.fixture(scope="session")
+def engine_audio(engine, sd_audio):
+    engine.load_audio(sd_audio)
+    return engine

@@ -1,0 +1,65 @@
+"""world_size-2 gloo test of the clip sharding + the one collective of the path (runs on CPU)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from avcer_amd import dist as adist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t, c = 16, 8
+    g = torch.Generator().manual_seed(0)
+    stat = torch.rand(n, t, 7, generator=g)
+    dyn = torch.rand(n, t, 7, generator=g)
+    aud = torch.rand(n, c, generator=g)
+    lo, hi = adist.shard_range(n, rank, world)
+    rec = adist.pack_records(stat[lo:hi], dyn[lo:hi], aud[lo:hi])
+    full = adist.all_gather_records(rec, n)
+    s2, d2, a2 = adist.unpack_records(full, t, c)
+    ok = bool(torch.equal(s2, stat) and torch.equal(d2, dyn) and torch.equal(a2, aud))
+    q.put((rank, ok, tuple(full.shape)))
+    dist.destroy_process_group()
+
+
+def _run(n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    return res
+
+
+def test_all_gather_records_even_and_uneven():
+    for n in (8, 7):
+        res = _run(n)
+        assert all(ok for _, ok, _ in res), res
+        assert all(shape == (n, 16 * 7 * 2 + 8) for _, _, shape in res)
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 8, 1024, 1023):
+        for w in (1, 2, 4, 8):
+            rs = [adist.shard_range(n, r, w) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 1

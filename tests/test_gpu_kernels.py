@@ -1,0 +1,157 @@
+"""Kernel-level parity of the contraction kernel (avcer_conv_gemm) against a float64 torch reference."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from avcer_amd._lib import ConvDesc
+
+pytestmark = pytest.mark.gpu
+
+
+def _desc(**kw):
+    d = ConvDesc()
+    base = dict(batch=1, in_h=1, in_w=1, out_h=1, out_w=1, cin=32, kh=1, kw=1, stride_h=1, stride_w=1, pad_h=0, pad_w=0,
+                dil_h=1, dil_w=1, x_stride_b=0, x_stride_h=0, x_stride_w=0, x_coff=0, n=64, y_ld=64, y_coff=0, r_ld=64,
+                r_coff=0, act=0, res_after_act=0)
+    base.update(kw)
+    for k, v in base.items():
+        setattr(d, k, int(v))
+    return d
+
+
+def _act(v, act):
+    return F.relu(v) if act == 1 else (F.gelu(v) if act == 2 else v)
+
+
+def _run(engine, d, dtype, x, w, scale, bias, res, y):
+    tin = torch.float32 if dtype == 0 else torch.bfloat16
+    tout = torch.float32 if dtype in (0, 2) else torch.bfloat16
+    dev = engine.device
+    xd, wd = x.to(dev, tin).contiguous(), w.to(dev, tin).contiguous()
+    sd_ = None if scale is None else scale.to(dev, torch.float32)
+    bd = None if bias is None else bias.to(dev, torch.float32)
+    rd = None if res is None else res.to(dev, tout).contiguous()
+    yd = y.to(dev, tout).contiguous()
+    engine.conv_gemm(d, dtype, xd, wd, sd_, bd, rd, yd)
+    torch.cuda.synchronize()
+    return yd.float().cpu(), xd.double().cpu(), wd.double().cpu(), (None if rd is None else rd.double().cpu())
+
+
+def _tol(dtype, ref):
+    scale = float(ref.abs().max()) + 1e-6
+    return (2e-5 if dtype == 0 else (1.2e-2 if dtype == 1 else 2e-4)) * scale
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2])
+def test_identity_times_asymmetric_weight(engine, dtype):
+    """A = I with an ASYMMETRIC W catches a row/col swap of the accumulator layout (exact small integers)."""
+    k = 32 if dtype == 0 else 64
+    m, n = 128, 128
+    x = torch.zeros(m, k)
+    x[torch.arange(k), torch.arange(k)] = 1.0
+    w = (torch.arange(n)[:, None] * 2 + torch.arange(k)[None, :] % 7).float()  # W[n,k], < 256+7: exact in bf16? no ->
+    w = (torch.arange(n)[:, None] % 16 * 8 + torch.arange(k)[None, :] % 8).float()  # <= 127: exact in bf16
+    d = _desc(batch=m, cin=k, x_stride_b=k, x_stride_h=k, x_stride_w=k, n=n, y_ld=n, r_ld=n)
+    y, _, _, _ = _run(engine, d, dtype, x, w, None, None, None, torch.full((m, n), -1.0))
+    ref = x @ w.t()
+    assert torch.equal(y, ref), (y - ref).abs().max()
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("m,k,n", [(300, 128, 192), (129, 64, 256), (1, 256, 64), (1000, 2048, 128)])
+def test_linear(engine, dtype, m, k, n):
+    g = torch.Generator().manual_seed(m + k + n)
+    x, w = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5
+    scale, bias = torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g)
+    res = torch.randn(m, n, generator=g)
+    d = _desc(batch=m, cin=k, x_stride_b=k, x_stride_h=k, x_stride_w=k, n=n, y_ld=n, r_ld=n, act=1)
+    y, xd, wd, rd = _run(engine, d, dtype, x, w, scale, bias, res, torch.zeros(m, n))
+    ref = F.relu((xd @ wd.t()) * scale.double() + bias.double() + rd)
+    assert (y.double() - ref).abs().max() < _tol(dtype, ref)
+
+
+CONVS = [
+    # b, h, w, c, kh, kw, stride, pad, dil, n, act
+    (2, 9, 9, 64, 3, 3, 1, 1, 1, 64, 1),
+    (3, 7, 7, 64, 1, 1, 2, 0, 1, 128, 0),
+    (2, 14, 14, 128, 3, 3, 1, 1, 1, 128, 1),
+    (1, 55, 55, 64, 3, 3, 1, 1, 1, 64, 1),
+    (2, 31, 1, 64, 5, 1, 3, 0, 2, 64, 0),    # Conv1d k5 s3 dil2 (audio head)
+    (2, 40, 1, 64, 2, 1, 2, 0, 1, 64, 2),    # Conv1d k2 s2 + gelu (feature extractor)
+]
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv(engine, dtype, cfg):
+    b, h, w_, c, kh, kw, s, p, dil, n, act = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(b, h, w_, c, generator=g)
+    w = torch.randn(n, kh, kw, c, generator=g) / (kh * kw * c) ** 0.5
+    scale, bias = torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g)
+    sw, pw, dw = (1, 0, 1) if w_ == 1 else (s, p, dil)
+    oh = (h + 2 * p - dil * (kh - 1) - 1) // s + 1
+    ow = (w_ + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    res = torch.randn(b, oh, ow, n, generator=g)
+    d = _desc(batch=b, in_h=h, in_w=w_, out_h=oh, out_w=ow, cin=c, kh=kh, kw=kw, stride_h=s, stride_w=sw, pad_h=p,
+              pad_w=pw, dil_h=dil, dil_w=dw, x_stride_b=h * w_ * c, x_stride_h=w_ * c, x_stride_w=c, n=n, y_ld=n, r_ld=n,
+              act=act)
+    y, xd, wd, rd = _run(engine, d, dtype, x, w.reshape(n, -1), scale, bias, res, torch.zeros(b, oh, ow, n))
+    ref = F.conv2d(xd.permute(0, 3, 1, 2), wd.reshape(n, kh, kw, c).permute(0, 3, 1, 2), None, (s, sw), (p, pw), (dil, dw))
+    ref = ref.permute(0, 2, 3, 1) * scale.double() + bias.double() + rd
+    ref = _act(ref, act)
+    assert (y.double() - ref).abs().max() < _tol(dtype, ref)
+
+
+@pytest.mark.parametrize("dtype", [0, 2])
+def test_grouped_slices_and_residual_after_act(engine, dtype):
+    """pos-conv shape: one group of a [B,S,C] tensor, zero padding in time, output/residual written into a channel
+    slice, y = gelu(conv + bias) + residual."""
+    b, s, ctot, g0, cin, k = 2, 50, 256, 64, 64, 8
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(b, s, ctot, generator=gen)
+    w = torch.randn(64, k, cin, generator=gen) / (k * cin) ** 0.5
+    bias = torch.randn(64, generator=gen)
+    res = torch.randn(b, s, ctot, generator=gen)
+    y0 = torch.full((b, s, ctot), 7.0)
+    d = _desc(batch=b, in_h=s, in_w=1, out_h=s, out_w=1, cin=cin, kh=k, kw=1, pad_h=k // 2, x_stride_b=s * ctot,
+              x_stride_h=ctot, x_stride_w=ctot, x_coff=g0, n=64, y_ld=ctot, y_coff=128, r_ld=ctot, r_coff=128, act=2,
+              res_after_act=1)
+    y, xd, wd, rd = _run(engine, d, dtype, x, w.reshape(64, -1), None, bias, res, y0)
+    xg = xd[:, :, g0:g0 + cin].permute(0, 2, 1)
+    ref = F.conv1d(xg, wd.reshape(64, k, cin).permute(0, 2, 1), bias.double(), padding=k // 2)[:, :, :s]
+    ref = F.gelu(ref).permute(0, 2, 1) + rd[:, :, 128:192]
+    assert (y[:, :, 128:192].double() - ref).abs().max() < _tol(dtype, ref)
+    assert torch.equal(y[:, :, :128], y0[:, :, :128]) and torch.equal(y[:, :, 192:], y0[:, :, 192:])
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_stem_layout(engine, dtype):
+    """7x7/2 stem as 8 tap rows x (8 pixels x 4 channels) over a zero-bordered 230x230x4 image."""
+    from avcer_amd import packing, synth
+
+    sd = synth.static_state_dict(42)
+    wp = torch.from_numpy(packing.pack_static(sd)["stem.w"])
+    gen = torch.Generator().manual_seed(9)
+    img = torch.zeros(2, 230, 230, 4)
+    img[:, 2:226, 2:226, :3] = torch.randn(2, 224, 224, 3, generator=gen) * 50
+    d = _desc(batch=2, in_h=230, in_w=230, out_h=112, out_w=112, cin=32, kh=8, kw=1, stride_h=2, stride_w=2,
+              x_stride_b=230 * 230 * 4, x_stride_h=230 * 4, x_stride_w=4, n=64, y_ld=64, r_ld=64)
+    y, xd, wd, _ = _run(engine, d, dtype, img, wp, None, None, None, torch.zeros(2, 112, 112, 64))
+    w = wd.reshape(64, 8, 8, 4)[:, :7, :7, :3].permute(0, 3, 1, 2)
+    x = F.pad(xd[:, 2:226, 2:226, :3].permute(0, 3, 1, 2), [2, 3, 2, 3])
+    ref = F.conv2d(x, w, None, 2).permute(0, 2, 3, 1)
+    assert (y.double() - ref).abs().max() < _tol(dtype, ref)
+
+
+def test_bad_shapes_are_rejected(engine):
+    from avcer_amd._lib import AvcerError
+
+    x = torch.zeros(4, 32, device=engine.device)
+    d = _desc(batch=4, cin=32, x_stride_b=32, x_stride_h=32, x_stride_w=32, n=48, y_ld=48)
+    with pytest.raises(AvcerError):
+        engine.conv_gemm(d, 0, x, x, None, None, None, x)
+    d = _desc(batch=4, cin=24, x_stride_b=24, x_stride_h=24, x_stride_w=24, n=64, y_ld=64)
+    with pytest.raises(AvcerError):
+        engine.conv_gemm(d, 0, x, x, None, None, None, x)

