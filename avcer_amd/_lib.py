@@ -53,6 +53,8 @@ SIGNATURES = {
     "avcer_conv_gemm": (C.c_int, [c_ctx, C.POINTER(ConvDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, c_stream]),
     "avcer_gemm_stats": (C.c_int, [c_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
+    "avcer_profile_enable": (C.c_int, [c_ctx, C.c_int]),
+    "avcer_profile_read": (C.c_int, [c_ctx, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "avcer_debug_tap": (C.c_int, [c_ctx, C.c_char_p, C.c_void_p, C.c_size_t]),
     "avcer_debug_tap_copied": (C.c_int64, [c_ctx]),
 }

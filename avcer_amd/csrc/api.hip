@@ -261,6 +261,7 @@ extern "C" void avcer_ctx_destroy(avcer_ctx* ctx) {
     free_model(ctx->aud);
     for (auto& b : ctx->ws)
         if (b.p) (void)hipFree(b.p);
+    for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -646,6 +647,30 @@ extern "C" int avcer_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc* d, int dty
     if (!ctx || !d) return AVCER_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return launch_conv_gemm(ctx, *d, dtype, x, w, scale, bias, residual, y, (hipStream_t)stream);
+}
+
+extern "C" int avcer_profile_enable(avcer_ctx* ctx, int on) {
+    if (!ctx) return AVCER_EINVAL;
+    ctx->prof = on != 0;
+    ctx->prof_used = 0;
+    return AVCER_OK;
+}
+
+// Sum of the HIP-event durations of the conv_gemm launches recorded since avcer_profile_enable; synchronises.
+extern "C" int avcer_profile_read(avcer_ctx* ctx, double* total_ms, int64_t* launches) {
+    if (!ctx) return AVCER_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->prof_ev[i + 1]));
+        float t = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->prof_ev[i], ctx->prof_ev[i + 1]));
+        ms += t;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = (int64_t)(ctx->prof_used / 2);
+    ctx->prof_used = 0;
+    return AVCER_OK;
 }
 
 extern "C" int avcer_debug_tap(avcer_ctx* ctx, const char* name, void* dst_dev, size_t bytes) {

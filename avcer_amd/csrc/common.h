@@ -44,6 +44,10 @@ struct avcer_ctx {
     DevBuf ws[8];
     int64_t gemm_launches = 0;
     double gemm_flops = 0.0;
+    // live HIP-event timing of conv_gemm launches (avcer_profile_*): pairs of events on the launch stream
+    bool prof = false;
+    std::vector<hipEvent_t> prof_ev;
+    size_t prof_used = 0;
     // one-shot debug tap (avcer_debug_tap): copy the named intermediate activation to a caller buffer
     std::string tap_name;
     void* tap_dst = nullptr;

@@ -331,9 +331,23 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
     p.ldY = d.y_ld; p.yoff = d.y_coff; p.ldR = d.r_ld; p.roff = d.r_coff;
     p.act = d.act; p.res_after = d.res_after_act;
     p.ntn = 0; p.nwg = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ctx->prof) {
+        if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
+            for (int i = 0; i < 512; ++i) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) return set_err(ctx, AVCER_EHIP, "hipEventCreate failed");
+                ctx->prof_ev.push_back(e);
+            }
+        }
+        ev0 = ctx->prof_ev[ctx->prof_used++];
+        ev1 = ctx->prof_ev[ctx->prof_used++];
+        (void)hipEventRecord(ev0, st);
+    }
     if (dtype == 0) launch_t<float, float>(p, st);
     else if (dtype == 1) launch_t<bf16_t, bf16_t>(p, st);
     else launch_t<bf16_t, float>(p, st);
+    if (ev1) (void)hipEventRecord(ev1, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "conv_gemm launch: %s", hipGetErrorString(e));
     ctx->gemm_launches += 1;

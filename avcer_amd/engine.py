@@ -180,6 +180,15 @@ class Engine:
         self._check(self.lib.avcer_conv_gemm(self.ctx, C.byref(desc), dtype, _ptr(x), _ptr(w), _ptr(scale), _ptr(bias),
                                              _ptr(residual), _ptr(y), self._stream()))
 
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.avcer_profile_enable(self.ctx, int(on)))
+
+    def profile_read(self):
+        """(summed conv_gemm kernel time in ms, number of launches) since the last read; synchronises."""
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        self._check(self.lib.avcer_profile_read(self.ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def debug_tap(self, name: str, numel: int, dtype=torch.float32):
         """Arm a one-shot tap; returns the destination tensor (filled by the next forward pass)."""
         dst = torch.zeros(numel, dtype=dtype, device=self.device)

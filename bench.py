@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/s of the full AV hot path (static CNN + LSTM + audio model + fusion) on synthetic
+clips of 16 x 224x224 frames + 2 s @ 16 kHz (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of `--clips` clips per GPU (weak scaling; 128 clips/GPU = BASELINE
+config 5 at 8 GPUs, static CNN in sub-batches of 256 frames = config 2's batch).  Inputs are resident in HBM before
+the timed region.  Rank 0 prints ONE JSON line.  The headline `value` is measured in the parity-green arithmetic
+mode (--mode fp32: f32 MFMA, probabilities within 1e-4 of the CPU oracle); the bf16-MFMA throughput mode is measured
+next to it and reported under "bf16" together with ITS measured max |dprob| (it does not meet the 1e-4 gate).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from avcer_amd import dist as adist  # noqa: E402
+from avcer_amd import synth  # noqa: E402
+from avcer_amd.engine import MODE_BF16, MODE_FP32  # noqa: E402
+
+T_FRAMES, T_AUDIO, FPS = 16, 32000, 25
+# Algorithmic work (forward hooks on the imported reference; 1 MAC = 2 FLOP)
+GFLOP_STATIC_FRAME = 7.667          # ResNet-50 224x224 + fc
+GFLOP_LSTM_EVAL = 0.0577
+GFLOP_AUDIO_CHUNK = 44.891          # ExprModelV3 at 2 s
+GFLOP_AUDIO_NOT_GEMM = 0.482 + 0.080 + 0.0655 + 0.0000164  # attention matmuls, conv layer 0, final Linear
+LSTM_EVALS_PER_CLIP = 4             # frames 0,5,10,15 at 25 fps
+GFLOP_CLIP = T_FRAMES * GFLOP_STATIC_FRAME + LSTM_EVALS_PER_CLIP * GFLOP_LSTM_EVAL + GFLOP_AUDIO_CHUNK
+GFLOP_CLIP_GEMM = GFLOP_CLIP - GFLOP_AUDIO_NOT_GEMM - 2 * 512 * 7 * T_FRAMES * 1e-9  # through conv_gemm
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # MI355X_MICROARCH.md: dense MFMA peaks (f32-in MFMA; bf16)
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores() -> int:
+    """CPU threads this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, 64))
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clips", type=int, default=128, help="clips per GPU per step")
+    ap.add_argument("--mode", choices=["fp32", "bf16"], default="fp32", help="arithmetic of the headline value")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other arithmetic mode")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-clips", type=int, default=8, help="bounded sample for the CPU baseline")
+    ap.add_argument("--parity-clips", type=int, default=2)
+    return ap.parse_args()
+
+
+def make_inputs(n_clips, rank, device):
+    frames = torch.from_numpy(synth.face_frames(1234 + rank, n_clips * T_FRAMES))
+    frames = frames.reshape(n_clips, T_FRAMES, 224, 224, 3).to(device)
+    wav = torch.from_numpy(synth.waveforms(5678 + rank, n_clips, T_AUDIO)).to(device)
+    return frames, wav
+
+
+def one_step(pipe, frames, wav, n_total):
+    """shard-local records -> one all-gather -> replicated fusion (avcer_amd/dist.py)."""
+    stat, dyn, aud = pipe.clip_records(frames, wav, FPS)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        rec = adist.all_gather_records(adist.pack_records(stat, dyn, aud), n_total)
+        stat, dyn, aud = adist.unpack_records(rec, T_FRAMES, aud.shape[1])
+    return pipe.fuse_records(stat.contiguous(), dyn.contiguous(), aud.contiguous())
+
+
+def timed(pipe, frames, wav, n_total, steps, warmup, device, profile):
+    for _ in range(warmup):
+        one_step(pipe, frames, wav, n_total)
+    torch.cuda.synchronize(device)
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    pipe.engine.gemm_stats(reset=True)
+    if profile:
+        pipe.engine.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step(pipe, frames, wav, n_total)
+    torch.cuda.synchronize(device)
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    kern_ms, launches = pipe.engine.profile_read() if profile else (0.0, 0)
+    pipe.engine.profile_enable(False)
+    if dist.is_initialized():
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, kern_ms, launches
+
+
+def parity(pipe, n_clips):
+    """max |dprob| of this arithmetic mode against the CPU oracle on a few clips (checker only)."""
+    from oracle import audio as oa
+    from oracle import fusion as of
+    from oracle import video as ov
+
+    sds = [synth.to_torch(f(42)) for f in (synth.static_state_dict, synth.dynamic_state_dict, synth.audio_state_dict)]
+    frames = synth.face_frames(4242, n_clips * T_FRAMES).reshape(n_clips, T_FRAMES, 224, 224, 3)
+    wav = synth.waveforms(4243, n_clips, T_AUDIO)
+    out = pipe.run_clips(torch.from_numpy(frames), torch.from_numpy(wav), FPS)
+    worst, same = 0.0, True
+    for c in range(n_clips):
+        st, dy = ov.visual_forward(sds[0], sds[1], frames[c], np.ones(T_FRAMES, bool), FPS, batched=True)
+        with torch.no_grad():
+            lg = oa.expr_model_v3_forward(sds[2], torch.from_numpy(oa.normalize(wav[c:c + 1]))).numpy().reshape(1, -1)
+        rows, fr = oa.replicate_per_frame(lg, [(0, T_AUDIO, 0, T_FRAMES)])
+        prob, am = of.fuse(st.astype(np.float32), dy.astype(np.float32), rows, fr)
+        p_aud = of.softmax(lg[:, :7])
+        g_aud = of.softmax(out["audio_logits"][c:c + 1, :7].cpu().numpy())
+        worst = max(worst, float(np.abs(out["static_probs"][c].cpu().numpy() - st).max()),
+                    float(np.abs(of.softmax(out["dynamic_logits"][c].cpu().numpy()) - of.softmax(dy.astype(np.float32))).max()),
+                    float(np.abs(g_aud - p_aud).max()),
+                    float(np.abs(out["compound_prob"][:, c].cpu().numpy() - prob).max()))
+        same = same and bool(np.array_equal(out["compound_argmax"][:, c].cpu().numpy(), am))
+    return worst, same
+
+
+def cpu_baseline(n_clips):
+    """The oracle (CPU restatement of the reference, kind = "port") timed on this box's host cores on a bounded
+    sample of the same workload: batched static CNN over a clip's 16 frames, 4 LSTM evaluations, one audio window."""
+    from oracle import audio as oa
+    from oracle import fusion as of
+    from oracle import video as ov
+
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
+    sds = [synth.to_torch(f(42)) for f in (synth.static_state_dict, synth.dynamic_state_dict, synth.audio_state_dict)]
+    frames = synth.face_frames(1234, n_clips * T_FRAMES).reshape(n_clips, T_FRAMES, 224, 224, 3)
+    wav = synth.waveforms(5678, n_clips, T_AUDIO)
+
+    def clip(c):
+        st, dy = ov.visual_forward(sds[0], sds[1], frames[c], np.ones(T_FRAMES, bool), FPS, batched=True)
+        with torch.no_grad():
+            lg = oa.expr_model_v3_forward(sds[2], torch.from_numpy(oa.normalize(wav[c:c + 1]))).numpy().reshape(1, -1)
+        rows, fr = oa.replicate_per_frame(lg, [(0, T_AUDIO, 0, T_FRAMES)])
+        return of.fuse(st.astype(np.float32), dy.astype(np.float32), rows, fr)
+
+    t0 = time.perf_counter()
+    clip(0)  # warm-up
+    warm = time.perf_counter() - t0
+    if warm > 8.0:  # slow host: shrink the sample so the default run stays within minutes
+        n_clips = max(1, min(n_clips, int(30.0 / warm)))
+    t0 = time.perf_counter()
+    for c in range(n_clips):
+        clip(c)
+    dt = time.perf_counter() - t0
+    return {"value": n_clips / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{n_clips} clips (16 frames batched + 4 LSTM evals + one 2 s window each), torch-CPU fp32 oracle, "
+                      f"{dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    device = torch.device("cuda", local_rank)
+
+    from avcer_amd.pipeline import AVPipeline
+
+    modes = {"fp32": MODE_FP32, "bf16": MODE_BF16}
+    torch.set_num_threads(min(usable_cores(), 16))
+    log(f"rank {rank}/{world}: building pipeline (synthetic weights, seed 42)")
+    pipe = AVPipeline(device=local_rank, seed=42, mode=modes[args.mode])
+    log("generating inputs")
+    frames, wav = make_inputs(args.clips, rank, device)
+    n_total = args.clips * world
+
+    def measure(mode_name, steps, warmup):
+        pipe.mode = pipe.static.mode = pipe.audio.mode = modes[mode_name]
+        dt, kern_ms, launches = timed(pipe, frames, wav, n_total, steps, warmup, device, profile=True)
+        key = "f32" if mode_name == "fp32" else "bf16"
+        flops_gemm = GFLOP_CLIP_GEMM * 1e9 * args.clips * steps  # algorithmic FLOPs this rank pushed through conv_gemm
+        res = {
+            "clips_per_s": n_total * steps / dt,
+            "ms_per_step": dt / steps * 1e3,
+            "roofline": {
+                "bound": "mfma", "kernel": f"conv_gemm_kernel<{key}>",
+                "achieved": flops_gemm / (kern_ms * 1e-3) / 1e12 if kern_ms else None,
+                "peak": PEAK_TFLOPS[key], "unit": "TFLOP/s",
+                "frac": (flops_gemm / (kern_ms * 1e-3) / 1e12 / PEAK_TFLOPS[key]) if kern_ms else None,
+                "traffic": None,
+                "launches_per_step": launches / steps if steps else 0,
+                "avg_launch_us": kern_ms * 1e3 / launches if launches else None,
+                "alg_gflop_per_launch": flops_gemm / launches / 1e9 if launches else None,
+                "kernel_time_share": kern_ms * 1e-3 / dt if dt else None,
+            },
+        }
+        return res
+
+    log(f"timing {args.mode}: {args.warmup} warm-up + {args.steps} steps of {args.clips} clips/GPU")
+    head = measure(args.mode, args.steps, args.warmup)
+    log(f"{args.mode}: {head['clips_per_s']:.1f} clips/s, {head['ms_per_step']:.1f} ms/step")
+    other_name = "bf16" if args.mode == "fp32" else "fp32"
+    other = None if args.no_secondary else measure(other_name, args.steps, args.warmup)
+    if other:
+        log(f"{other_name}: {other['clips_per_s']:.1f} clips/s, {other['ms_per_step']:.1f} ms/step")
+
+    out = None
+    if rank == 0:
+        pipe.mode = pipe.static.mode = pipe.audio.mode = modes[args.mode]
+        log("parity check against the CPU oracle")
+        dprob, same = parity(pipe, args.parity_clips)
+        out = {
+            "metric": "clips/sec (224x224x16f + 2s@16kHz), full AV path: static CNN + LSTM + wav2vec2 audio model + fusion",
+            "value": head["clips_per_s"], "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.mode == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": "full AV clips (BASELINE configs[3]/[4]): 16 u8 224x224 RGB face tiles + 32000 f32 "
+                                   "samples per clip, synthetic weights (ResNet-50 + LSTM + wav2vec2-large-robust-12 "
+                                   "ExprModelV3)", "clips_per_gpu": args.clips, "global_clips": n_total,
+                       "frames_per_clip": T_FRAMES, "audio_samples_per_clip": T_AUDIO, "fps": FPS,
+                       "static_sub_batch": 256, "parallelism": f"clip-sharded x{world} + 1 all-gather of per-clip records"},
+            "max_dprob_vs_cpu_oracle": dprob, "argmax_identical": same, "gflop_per_clip": GFLOP_CLIP,
+            "roofline": head["roofline"],
+        }
+        if other is not None:
+            pipe.mode = pipe.static.mode = pipe.audio.mode = modes[other_name]
+            d2, s2 = parity(pipe, args.parity_clips)
+            out[other_name] = {"value": other["clips_per_s"], "unit": "clips/s", "ms_per_step": other["ms_per_step"],
+                               "max_dprob_vs_cpu_oracle": d2, "argmax_identical": s2, "roofline": other["roofline"],
+                               "note": "bf16-MFMA throughput mode: does NOT meet the 1e-4 probability gate"
+                               if other_name == "bf16" else "f32-MFMA parity mode"}
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_clips)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

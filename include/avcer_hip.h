@@ -145,6 +145,12 @@ int avcer_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, const v
  * launches and their summed algorithmic FLOPs since the previous call to this function. */
 int avcer_gemm_stats(avcer_ctx* ctx, int64_t* launches, double* flops, int reset);
 
+/* Live timing of the dominant kernel for bench.py's roofline object: while enabled, every conv_gemm launch is
+ * bracketed by a pair of HIP events on its launch stream; avcer_profile_read synchronises, returns the summed
+ * event durations (ms) and the number of launches since the last read, and rewinds the event pool. */
+int avcer_profile_enable(avcer_ctx* ctx, int on);
+int avcer_profile_read(avcer_ctx* ctx, double* total_ms, int64_t* launches);
+
 /* Debug aid for parity tests: arm a one-shot tap; the next forward pass copies up to `bytes` raw bytes of the
  * named intermediate activation (first sub-batch) into dst_dev.  Names: static "pre", "stem_conv", "stem",
  * "l1b0_c1", "l1b0_c2", "l1b0_ds", "l1b0", "layer1".."layer4", "avgpool"; audio "norm", "conv0", "extract", "proj",

@@ -86,15 +86,20 @@ def test_expr_model_bf16_reports(engine_audio, golden):
 
 
 def test_chunked_video_audio_matches_oracle_including_nan_tail(engine_audio, sd_audio):
-    wav = torch.from_numpy(synth.waveforms(77, 1, 24000)[0])  # 1.5 s: windows at 0, 0.5, 1.0 s + an EMPTY tail window
-    logits, lo, hi = audio_pipeline.audio_forward(engine_audio, wav, 16000, 25, window=2, step=0.5, padding="mean")
-    rows, frames = audio_pipeline.replicate_per_frame(logits.cpu().numpy(), lo, hi)
-    ref_rows, ref_frames = oa.audio_forward(sd_audio, wav, 16000, 25, window=2, step=0.5, padding="mean")
-    np.testing.assert_array_equal(frames, ref_frames)
-    assert np.isnan(ref_rows[-1]).all() and np.isnan(rows[-1]).all()
-    ok = ~np.isnan(ref_rows).any(axis=1)
-    assert np.array_equal(ok, ~np.isnan(rows).any(axis=1))
-    assert np.abs(rows[ok] - ref_rows[ok]).max() < 2e-3
+    # 1.0 s: windows at 0 and 0.5 s + an EMPTY tail window that owns frame 25 (NaN logits in the reference);
+    # 1.5 s: the empty tail window maps to frames [38, 38) = none (Python's round-half-even)
+    for n_samples in (16000, 24000):
+        wav = torch.from_numpy(synth.waveforms(77, 1, n_samples)[0])
+        logits, lo, hi = audio_pipeline.audio_forward(engine_audio, wav, 16000, 25, window=2, step=0.5, padding="mean")
+        assert torch.isnan(logits[-1]).all() and not torch.isnan(logits[:-1]).any()
+        rows, frames = audio_pipeline.replicate_per_frame(logits.cpu().numpy(), lo, hi)
+        ref_rows, ref_frames = oa.audio_forward(sd_audio, wav, 16000, 25, window=2, step=0.5, padding="mean")
+        np.testing.assert_array_equal(frames, ref_frames)
+        if n_samples == 16000:
+            assert frames[-1] == 25 and np.isnan(ref_rows[-1]).all() and np.isnan(rows[-1]).all()
+        ok = ~np.isnan(ref_rows).any(axis=1)
+        assert np.array_equal(ok, ~np.isnan(rows).any(axis=1))
+        assert np.abs(rows[ok] - ref_rows[ok]).max() < 2e-3
 
 
 def test_audio_batch_invariance_128(engine_audio):
