@@ -140,11 +140,38 @@ int ensure_all_bf16(avcer_ctx* ctx, Model& m, hipStream_t st) {
     return AVCER_OK;
 }
 
+// split-bf16 copies (k_split_weights) of every GEMM weight whose K is a multiple of 32, made on the first x3 call
+int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
+    auto wanted = [](const std::string& k, const Tensor& t) {
+        return !t.x3 && k.size() > 2 && k.compare(k.size() - 2, 2, ".w") == 0 && t.ndim == 2 && t.dims[1] % 32 == 0 &&
+               t.dims[0] % 64 == 0;
+    };
+    size_t total = 0;
+    for (auto& kv : m.t)
+        if (wanted(kv.first, kv.second)) total += (kv.second.numel * 4 + 255) & ~(size_t)255;
+    if (!total) return AVCER_OK;
+    void* dev = nullptr;
+    if (hipMalloc(&dev, total) != hipSuccess) {
+        (void)hipGetLastError();
+        return set_err(ctx, AVCER_ENOMEM, "hipMalloc(%zu) for split-bf16 weights failed", total);
+    }
+    m.allocs.push_back(dev);
+    size_t off = 0;
+    for (auto& kv : m.t)
+        if (wanted(kv.first, kv.second)) {
+            kv.second.x3 = (bf16_t*)((char*)dev + off);
+            TRY(k_split_weights(ctx, kv.second.f32, kv.second.x3, kv.second.numel, st));
+            off += (kv.second.numel * 4 + 255) & ~(size_t)255;
+        }
+    return AVCER_OK;
+}
+
 struct Net {
     avcer_ctx* ctx;
     Model& m;
     int bf16;  // activation / weight type of the MFMA contractions
     hipStream_t st;
+    int x3 = 0;  // f32 activations, split-bf16 MFMA (AVCER_MODE_BF16X3)
     int err = AVCER_OK;
 
     const Tensor* T(const std::string& name) {
@@ -171,6 +198,10 @@ struct Net {
             if (out_bf16) { err = set_err(ctx, AVCER_EINVAL, "gemm %s: f32 in / bf16 out unsupported", wname.c_str()); return; }
             dtype = 0;
             wp = w->f32;
+            if (x3 && w->x3) {
+                dtype = 3;
+                wp = w->x3;
+            }
         } else {
             dtype = out_bf16 ? 1 : 2;
             wp = w->bf16;
@@ -296,11 +327,12 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     if (!ctx) return AVCER_EINVAL;
     if (!ctx->stat.loaded) return set_err(ctx, AVCER_ESTATE, "static weights not loaded");
     if ((!frames && !nchw) || n <= 0 || in_h <= 0 || in_w <= 0) return set_err(ctx, AVCER_EINVAL, "static_forward: bad arguments");
-    if (mode != AVCER_MODE_FP32 && mode != AVCER_MODE_BF16) return set_err(ctx, AVCER_EINVAL, "static_forward: mode %d", mode);
+    if (mode < AVCER_MODE_FP32 || mode > AVCER_MODE_BF16X3) return set_err(ctx, AVCER_EINVAL, "static_forward: mode %d", mode);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int bf = mode == AVCER_MODE_BF16;
     if (bf) TRY(ensure_all_bf16(ctx, ctx->stat, st));
+    if (mode == AVCER_MODE_BF16X3) TRY(ensure_all_x3(ctx, ctx->stat, st));
     const size_t es = bf ? 2 : 4;
     const int NB = std::min(n, 256);
     const size_t act_elems = (size_t)NB * 112 * 112 * 64;  // largest activation (stem output)
@@ -316,7 +348,7 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     float* feat_ws = (float*)ar.get((size_t)NB * 512 * 4);
     if (!feat_ws) return set_err(ctx, AVCER_ENOMEM, "static workspace arithmetic");
 
-    Net net{ctx, ctx->stat, bf, st};
+    Net net{ctx, ctx->stat, bf, st, mode == AVCER_MODE_BF16X3};
     for (int s0 = 0; s0 < n; s0 += NB) {
         const int nb = std::min(NB, n - s0);
         if (frames) net.chk(k_preprocess(ctx, frames + (size_t)s0 * in_h * in_w * 3, nb, in_h, in_w, P, bf, st));
@@ -465,7 +497,7 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
     if (!ctx) return AVCER_EINVAL;
     if (!ctx->aud.loaded) return set_err(ctx, AVCER_ESTATE, "audio weights not loaded");
     if (!wav || !logits || n <= 0) return set_err(ctx, AVCER_EINVAL, "audio_forward: bad arguments");
-    if (mode != AVCER_MODE_FP32 && mode != AVCER_MODE_BF16) return set_err(ctx, AVCER_EINVAL, "audio_forward: mode %d", mode);
+    if (mode < AVCER_MODE_FP32 || mode > AVCER_MODE_BF16X3) return set_err(ctx, AVCER_EINVAL, "audio_forward: mode %d", mode);
     static const int ck[7] = {10, 3, 3, 3, 3, 2, 2}, cs[7] = {5, 2, 2, 2, 2, 2, 2};
     int len[8];
     len[0] = t;
@@ -483,6 +515,7 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int bf = mode == AVCER_MODE_BF16;
     if (bf) TRY(ensure_all_bf16(ctx, ctx->aud, st));
+    if (mode == AVCER_MODE_BF16X3) TRY(ensure_all_x3(ctx, ctx->aud, st));
     const size_t es = bf ? 2 : 4;
     const int C = 512, E = 1024, FF = 4096;
     const int NB = std::min(n, 128);
@@ -513,7 +546,7 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
     if (!pooled) return set_err(ctx, AVCER_ENOMEM, "audio workspace arithmetic");
     const int ncls = ctx->aud_classes;
 
-    Net net{ctx, ctx->aud, bf, st};
+    Net net{ctx, ctx->aud, bf, st, mode == AVCER_MODE_BF16X3};
     // LN output helper: activation-typed operand (f32 in parity mode, bf16 in throughput mode)
     auto ln_act = [&](const void* x, bool x_bf16, const std::string& p, void* y, long r, int c, int act) {
         net.chk(k_layernorm(ctx, x, nullptr, net.F(p + ".g"), net.F(p + ".b"), bf ? nullptr : y, bf ? y : nullptr, r, c,
@@ -683,6 +716,13 @@ extern "C" int avcer_debug_tap(avcer_ctx* ctx, const char* name, void* dst_dev, 
 }
 
 extern "C" int64_t avcer_debug_tap_copied(const avcer_ctx* ctx) { return ctx ? ctx->tap_copied : -1; }
+
+extern "C" int avcer_split_weights(avcer_ctx* ctx, const float* w, void* out, size_t numel, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (!w || !out || numel % 32) return set_err(ctx, AVCER_EINVAL, "split_weights: numel must be a multiple of 32");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return k_split_weights(ctx, w, (bf16_t*)out, numel, (hipStream_t)stream);
+}
 
 extern "C" int avcer_gemm_stats(avcer_ctx* ctx, int64_t* launches, double* flops, int reset) {
     if (!ctx) return AVCER_EINVAL;

@@ -24,6 +24,7 @@ struct DevBuf {
 struct Tensor {
     float* f32 = nullptr;
     bf16_t* bf16 = nullptr;
+    bf16_t* x3 = nullptr;  // split-bf16 (hi/lo per 32-element K group) copy for AVCER_MODE_BF16X3
     size_t numel = 0;
     int64_t dims[4] = {0, 0, 0, 0};
     int ndim = 0;
@@ -107,3 +108,4 @@ int k_pack_nchw(avcer_ctx*, const float* x, int n, void* out, int bf16, hipStrea
 int k_gather_windows(avcer_ctx*, const float* feats, const int32_t* idx, int nwin, float* out, hipStream_t);
 int k_audio_chunks(avcer_ctx*, const float* wav, const int32_t* starts, const int32_t* ends, int n, int window, int mode,
                    float* out, hipStream_t);
+int k_split_weights(avcer_ctx*, const float* w, bf16_t* out, size_t n, hipStream_t);

@@ -13,10 +13,11 @@
 // Design (CDNA4):
 //   * 256 threads = 4 waves (2x2); block tile 128(m) x BN(n), BN in {128, 64}; one K-step = 128 bytes per row
 //     (32 f32 or 64 bf16), so the global->LDS staging pattern is identical for both element types.
-//   * A and W tiles are staged through registers (the A gather needs zero fill at image borders) into a
-//     double-buffered LDS image of 128-byte rows whose 16-byte chunks are XOR-swizzled with (row>>1)&7:
-//     conflict-free for the ds_read_b128 fragment reads of both MFMA shapes (MI355X LDS: 64 banks x 4 B,
-//     b128 reads served in 16-lane groups).
+//   * A and W tiles go global -> LDS by DMA (buffer_load_dwordx4 ... lds, no VGPR staging, no ds_write); the
+//     hardware bounds check of the buffer descriptor supplies the zeros of image borders and of rows past M.
+//     The double-buffered LDS image has 128-byte rows whose 16-byte chunks are XOR-swizzled with (row>>1)&7
+//     (applied on the source address, since the DMA destination is lane-linear): conflict-free for the
+//     ds_read_b128 fragment reads of both MFMA shapes (MI355X LDS: 64 banks x 4 B, b128 reads in 16-lane groups).
 //   * MFMA operands are swapped (weights = A operand, activations = B operand) so that each lane's accumulator
 //     registers hold 4 CONSECUTIVE output channels of one position: NHWC stores and the per-channel
 //     scale/bias loads become 16-byte (f32) / 8-byte (bf16) vector accesses.
@@ -25,6 +26,7 @@
 //   * blockIdx is remapped so that the 8 XCDs (private L2 each) get contiguous runs of tiles.
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -43,6 +45,7 @@ struct GemmParams {
     const float* bias;
     const char* R;
     char* Y;
+    unsigned x_bytes, w_bytes;  // buffer extents for the hardware bounds check (reads past them return 0)
     int M, N, K;
     int OH, OW, H, Wd, Cin, KW;
     int sh, sw, ph, pw, dh, dw;
@@ -54,22 +57,35 @@ struct GemmParams {
     int roff;
     int act, res_after;
     int ntn, nwg;
+    int ablate;  // test-only (env AVCER_GEMM_ABLATE): 1 = skip MFMA, 2 = skip global loads, 3 = and LDS stores
 };
 
-__device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+constexpr unsigned OOB = 0xFFFFFF00u;  // voffset that always fails the buffer bounds check -> load returns 0
+
+// 16 bytes per lane, global -> LDS (wave-uniform LDS base + lane * 16); zeros when voff fails the bounds check
+template <typename Rsrc>
+__device__ __forceinline__ void dma16(Rsrc rs, char* lds_wave_base, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+#endif
+}
+
+// XOR swizzle of the 16-byte chunks of a 128-byte tile row.  The key f((row>>1)&7) with f = (0,1,4,5,6,7,2,3) was
+// found by exhaustive search: it makes every ds_read_b128 fragment pattern used below (bf16 16x16x32, f32 32x32x2 and
+// the two-chunk f32 row read of the split-bf16 mode) conflict-free under the MI355X 16-lane-group banking.
+__device__ __forceinline__ int swz_key(int row) { return (int)((0x32765410u >> (((row >> 1) & 7) * 4)) & 7u); }
+__device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ swz_key(row)) << 4); }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == 1) return v > 0.f ? v : (v != v ? v : 0.f);  // relu keeps NaN like torch
-    if (act == 2) return gelu_erf(v);
-    return v;
-}
+__device__ __forceinline__ float relu_nan(float v) { return v > 0.f ? v : (v != v ? v : 0.f); }  // keeps NaN like torch
 
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
 
-template <typename OutT>
+// ACT: 0 = none, 1 = relu, 2 = gelu (compile-time so that erff is only expanded in the GELU instantiation)
+template <typename OutT, int ACT>
 __device__ __forceinline__ void epilogue4(const GemmParams& p, long m, int n0, float v0, float v1, float v2, float v3) {
     float v[4] = {v0, v1, v2, v3};
     float r[4] = {0.f, 0.f, 0.f, 0.f};
@@ -86,8 +102,10 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, long m, int n0, f
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (p.res_after) v[j] = apply_act(v[j], p.act) + r[j];
-        else v[j] = apply_act(v[j] + r[j], p.act);
+        float x = p.res_after ? v[j] : v[j] + r[j];
+        if constexpr (ACT == 1) x = relu_nan(x);
+        if constexpr (ACT == 2) x = gelu_erf(x);
+        v[j] = p.res_after ? x + r[j] : x;
     }
     char* yp = p.Y + (m * p.ldY + p.yoff + n0) * (long)sizeof(OutT);
     if constexpr (sizeof(OutT) == 4) {
@@ -100,14 +118,68 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, long m, int n0, f
     }
 }
 
-template <typename T, typename OutT, int BN>
-__global__ void __launch_bounds__(256) conv_gemm_kernel(const GemmParams p) {
-    constexpr bool IS_F32 = sizeof(T) == 4;
-    constexpr int ES = sizeof(T);
+template <int MODE, typename OutT, int BN, int ACT, typename AccT, int NFN, int NFM>
+__device__ __forceinline__ void epilogue_all(const GemmParams& p, AccT (&acc)[NFN][NFM], int m_base, int n_base, int wm,
+                                             int wn, int lane) {
+    constexpr bool IS_F32 = MODE == 0;
+    constexpr int WN = BN / 2;
+    if constexpr (IS_F32) {
+#pragma unroll
+        for (int fn = 0; fn < NFN; ++fn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n0 = n_base + wn * WN + fn * 32 + 8 * g + 4 * (lane >> 5);
+                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n0);
+                if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + n0);
+#pragma unroll
+                for (int fm = 0; fm < NFM; ++fm) {
+                    const int m = m_base + wm * 64 + fm * 32 + (lane & 31);
+                    if (m < p.M)
+                        epilogue4<OutT, ACT>(p, m, n0, acc[fn][fm][4 * g + 0] * sc.x + bi.x,
+                                             acc[fn][fm][4 * g + 1] * sc.y + bi.y, acc[fn][fm][4 * g + 2] * sc.z + bi.z,
+                                             acc[fn][fm][4 * g + 3] * sc.w + bi.w);
+                }
+            }
+    } else {
+#pragma unroll
+        for (int fn = 0; fn < NFN; ++fn) {
+            const int n0 = n_base + wn * WN + fn * 16 + 4 * (lane >> 4);
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n0);
+            if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + n0);
+#pragma unroll
+            for (int fm = 0; fm < NFM; ++fm) {
+                const int m = m_base + wm * 64 + fm * 16 + (lane & 15);
+                if (m < p.M)
+                    epilogue4<OutT, ACT>(p, m, n0, acc[fn][fm][0] * sc.x + bi.x, acc[fn][fm][1] * sc.y + bi.y,
+                                         acc[fn][fm][2] * sc.z + bi.z, acc[fn][fm][3] * sc.w + bi.w);
+            }
+        }
+    }
+}
+
+// bf16 <-> f32 split used by MODE 2: x = hi + lo + O(2^-17 |x|) with hi, lo bf16 (round to nearest even)
+__device__ __forceinline__ void split8(const float4 x, const float4 y, bf16x8_t& hi, bf16x8_t& lo) {
+    const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(v[j] - (float)h);
+    }
+}
+
+// MODE 0: f32 operands, v_mfma_f32_32x32x2_f32.  MODE 1: bf16 operands, v_mfma_f32_16x16x32_bf16.
+// MODE 2 ("bf16x3"): f32 activations split on the fly into bf16 hi+lo, weights pre-split (per 32-element K group:
+// 32 hi then 32 lo bf16), a.w ~= ah.wh + ah.wl + al.wh on the bf16 MFMA with f32 accumulation -- f32-grade
+// results (relative error ~2^-17 per product) at a third of the bf16 MFMA rate instead of a sixteenth.
+template <int MODE, typename OutT, int BN>
+__global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
+    constexpr bool IS_F32 = MODE == 0;
+    constexpr int ES = MODE == 1 ? 2 : 4;
     constexpr int VEC = 16 / ES;
     constexpr int BK = ROWB / ES;
-    constexpr int A_VPT = BM / 32;
-    constexpr int B_VPT = BN / 32;
     constexpr int TILE_BYTES = (BM + BN) * ROWB;
     constexpr int WN = BN / 2;
     __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
@@ -129,14 +201,24 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const GemmParams p) {
     const int m_base = tile_m * BM;
     const int n_base = tile_n * BN;
 
-    const int chunk = tid & 7;
-    const int rbase = tid >> 3;
+    // hardware-bounds-checked buffer descriptors: an out-of-range voffset returns zeros without a branch
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.X), (short)0, (int)p.x_bytes, 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W), (short)0, (int)p.w_bytes, 0x00020000);
 
-    long a_base[A_VPT];
-    int a_iy[A_VPT], a_ix[A_VPT];
+    // Global -> LDS by DMA (buffer_load_dwordx4 ... lds): one wave-instruction fills 1 KiB = 8 tile rows x 128 B,
+    // lane i landing at (row i>>3, 16-byte slot i&7).  The XOR swizzle of the LDS image is therefore applied to the
+    // SOURCE: lane i fetches data chunk c = slot ^ ((row>>1)&7) of its row.  Padding taps / rows past M use an
+    // out-of-range offset, for which the buffer load writes zeros.
+    constexpr int A_ISS = BM / 32;  // DMA instructions per wave per K-step for the A tile
+    constexpr int B_ISS = BN / 32;
+    const int lrow8 = lane >> 3;
+    const int slot = lane & 7;
+    unsigned a_off[A_ISS];  // byte offset of (b, iy0, ix0, coff) of this lane's row in issue j
+    int a_iy[A_ISS], a_ix[A_ISS], a_kc[A_ISS];
 #pragma unroll
-    for (int i = 0; i < A_VPT; ++i) {
-        const int m = m_base + rbase + 32 * i;
+    for (int j = 0; j < A_ISS; ++j) {
+        const int lrow = wave * (A_ISS * 8) + j * 8 + lrow8;
+        const int m = m_base + lrow;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
         const int ox = mm % p.OW;
@@ -145,50 +227,46 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const GemmParams p) {
         const int b = t / p.OH;
         const int iy = oy * p.sh - p.ph;
         const int ix = ox * p.sw - p.pw;
-        a_iy[i] = ok ? iy : -(1 << 28);  // out-of-range rows fail the bounds test below
-        a_ix[i] = ix;
-        a_base[i] = (long)b * p.sB + (long)iy * p.sH + (long)ix * p.sW + p.coff;
+        a_iy[j] = ok ? iy : -(1 << 28);  // rows past M fail the bounds test below
+        a_ix[j] = ix;
+        a_off[j] = (unsigned)(((long)b * p.sB + (long)iy * p.sH + (long)ix * p.sW + p.coff) * ES);
+        a_kc[j] = (slot ^ swz_key(lrow)) * VEC;
     }
-    int kc = chunk * VEC, kx = 0, ky = 0;
-    while (kc >= p.Cin) {
-        kc -= p.Cin;
-        if (++kx == p.KW) { kx = 0; ++ky; }
+    unsigned w_off[B_ISS];
+#pragma unroll
+    for (int j = 0; j < B_ISS; ++j) {
+        const int lrow = wave * (B_ISS * 8) + j * 8 + lrow8;
+        w_off[j] = (unsigned)(((long)(n_base + lrow) * p.K + (slot ^ swz_key(lrow)) * VEC) * ES);
     }
-    const char* wptr = p.W + ((long)(n_base + rbase) * p.K + chunk * VEC) * ES;
-    const long w_rowstep = (long)32 * p.K * ES;
+    int kc = 0, kx = 0, ky = 0;  // (channel, tap) of the first element of the current K-step
 
-    uint4 ra[A_VPT], rb[B_VPT];
-    auto load_tiles = [&]() {
-        const int dy = ky * p.dh, dx = kx * p.dw;
-        const long toff = (long)dy * p.sH + (long)dx * p.sW + kc;
-#pragma unroll
-        for (int i = 0; i < A_VPT; ++i) {
-            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (ok) v = *reinterpret_cast<const uint4*>(p.X + (a_base[i] + toff) * ES);
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < B_VPT; ++i) rb[i] = *reinterpret_cast<const uint4*>(wptr + i * w_rowstep);
-        wptr += ROWB;
-        kc += BK;
-        while (kc >= p.Cin) {
-            kc -= p.Cin;
-            if (++kx == p.KW) { kx = 0; ++ky; }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-        char* sa = smem + buf * TILE_BYTES;
-        char* sb = sa + BM * ROWB;
-#pragma unroll
-        for (int i = 0; i < A_VPT; ++i) *reinterpret_cast<uint4*>(sa + swz(rbase + 32 * i, chunk)) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_VPT; ++i) *reinterpret_cast<uint4*>(sb + swz(rbase + 32 * i, chunk)) = rb[i];
-    };
+#define AVCER_ISSUE_TILES(buf)                                                                                      \
+    do {                                                                                                            \
+        char* sa_ = smem + (buf) * TILE_BYTES + wave * (A_ISS * 1024);                                              \
+        char* sb_ = smem + (buf) * TILE_BYTES + BM * ROWB + wave * (B_ISS * 1024);                                  \
+        _Pragma("unroll") for (int j = 0; j < A_ISS; ++j) {                                                         \
+            int kk = kc + a_kc[j], kxx = kx, kyy = ky;                                                              \
+            if (kk >= p.Cin) { kk -= p.Cin; if (++kxx == p.KW) { kxx = 0; ++kyy; } }                                \
+            const int dy = kyy * p.dh, dx = kxx * p.dw;                                                             \
+            const int iy = a_iy[j] + dy, ix = a_ix[j] + dx;                                                         \
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd && p.ablate < 2;          \
+            const unsigned vo = a_off[j] + (unsigned)(((long)dy * p.sH + (long)dx * p.sW + kk) * ES);               \
+            dma16(xrs, sa_ + j * 1024, ok ? vo : OOB);                                                             \
+        }                                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < B_ISS; ++j) {                                                         \
+            dma16(wrs, sb_ + j * 1024, p.ablate < 2 ? w_off[j] : OOB);                                             \
+            w_off[j] += ROWB;                                                                                       \
+        }                                                                                                           \
+        kc += BK;                                                                                                   \
+        while (kc >= p.Cin) {                                                                                       \
+            kc -= p.Cin;                                                                                            \
+            if (++kx == p.KW) { kx = 0; ++ky; }                                                                     \
+        }                                                                                                           \
+    } while (0)
 
     constexpr int NFN = IS_F32 ? WN / 32 : WN / 16;
     constexpr int NFM = IS_F32 ? 2 : 4;
+    static_assert(MODE != 2 || sizeof(OutT) == 4, "split-bf16 mode writes f32");
     using acc_t = typename std::conditional<IS_F32, f32x16_t, f32x4_t>::type;
     acc_t acc[NFN][NFM];
 #pragma unroll
@@ -197,16 +275,16 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const GemmParams p) {
         for (int b = 0; b < NFM; ++b) acc[a][b] = acc_t{0};
 
     const int nk = p.K / BK;
-    load_tiles();
-    store_tiles(0);
-    __syncthreads();
+    AVCER_ISSUE_TILES(0);
+    __syncthreads();  // hipcc puts the s_waitcnt vmcnt(0) of the in-flight DMA in front of the barrier
     int cur = 0;
     for (int step = 0; step < nk; ++step) {
-        const bool more = step + 1 < nk;
-        if (more) load_tiles();
+        if (step + 1 < nk) AVCER_ISSUE_TILES(cur ^ 1);  // next K-step lands while this one is multiplied
         const char* sa = smem + cur * TILE_BYTES;
         const char* sb = sa + BM * ROWB;
-        if constexpr (IS_F32) {
+        if (p.ablate == 1) {
+            // ablation: no fragment reads / MFMA
+        } else if constexpr (IS_F32) {
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) {
                 const int ch = kq * 2 + (lane >> 5);
@@ -227,6 +305,28 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const GemmParams p) {
                         acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[fn].w, af[fm].w, acc[fn][fm], 0, 0, 0);
                     }
             }
+        } else if constexpr (MODE == 2) {
+            const int g = lane >> 4;
+            bf16x8_t ahi[NFM], alo[NFM];
+#pragma unroll
+            for (int fm = 0; fm < NFM; ++fm) {
+                const int row = wm * 64 + fm * 16 + (lane & 15);
+                const float4 x = *reinterpret_cast<const float4*>(sa + swz(row, 2 * g));
+                const float4 y = *reinterpret_cast<const float4*>(sa + swz(row, 2 * g + 1));
+                split8(x, y, ahi[fm], alo[fm]);
+            }
+#pragma unroll
+            for (int fn = 0; fn < NFN; ++fn) {
+                const int row = wn * WN + fn * 16 + (lane & 15);
+                const bf16x8_t whi = *reinterpret_cast<const bf16x8_t*>(sb + swz(row, g));
+                const bf16x8_t wlo = *reinterpret_cast<const bf16x8_t*>(sb + swz(row, 4 + g));
+#pragma unroll
+                for (int fm = 0; fm < NFM; ++fm) {
+                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, ahi[fm], acc[fn][fm], 0, 0, 0);
+                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, alo[fm], acc[fn][fm], 0, 0, 0);
+                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, ahi[fm], acc[fn][fm], 0, 0, 0);
+                }
+            }
         } else {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -245,59 +345,29 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const GemmParams p) {
                         acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], af[fm], acc[fn][fm], 0, 0, 0);
             }
         }
-        if (more) store_tiles(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
+#undef AVCER_ISSUE_TILES
 
     // epilogue: accumulator register group g of a lane = 4 consecutive output channels of one position
-    if constexpr (IS_F32) {
-#pragma unroll
-        for (int fn = 0; fn < NFN; ++fn)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n0 = n_base + wn * WN + fn * 32 + 8 * g + 4 * (lane >> 5);
-                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n0);
-                if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + n0);
-#pragma unroll
-                for (int fm = 0; fm < NFM; ++fm) {
-                    const int m = m_base + wm * 64 + fm * 32 + (lane & 31);
-                    if (m < p.M)
-                        epilogue4<OutT>(p, m, n0, acc[fn][fm][4 * g + 0] * sc.x + bi.x, acc[fn][fm][4 * g + 1] * sc.y + bi.y,
-                                        acc[fn][fm][4 * g + 2] * sc.z + bi.z, acc[fn][fm][4 * g + 3] * sc.w + bi.w);
-                }
-            }
-    } else {
-#pragma unroll
-        for (int fn = 0; fn < NFN; ++fn) {
-            const int n0 = n_base + wn * WN + fn * 16 + 4 * (lane >> 4);
-            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n0);
-            if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + n0);
-#pragma unroll
-            for (int fm = 0; fm < NFM; ++fm) {
-                const int m = m_base + wm * 64 + fm * 16 + (lane & 15);
-                if (m < p.M)
-                    epilogue4<OutT>(p, m, n0, acc[fn][fm][0] * sc.x + bi.x, acc[fn][fm][1] * sc.y + bi.y,
-                                    acc[fn][fm][2] * sc.z + bi.z, acc[fn][fm][3] * sc.w + bi.w);
-            }
-        }
-    }
+    if (p.act == 2) epilogue_all<MODE, OutT, BN, 2>(p, acc, m_base, n_base, wm, wn, lane);
+    else if (p.act == 1) epilogue_all<MODE, OutT, BN, 1>(p, acc, m_base, n_base, wm, wn, lane);
+    else epilogue_all<MODE, OutT, BN, 0>(p, acc, m_base, n_base, wm, wn, lane);
 }
 
-template <typename T, typename OutT>
+template <int MODE, typename OutT>
 void launch_t(const GemmParams& p0, hipStream_t st) {
     GemmParams p = p0;
     const int ntm = (p.M + BM - 1) / BM;
     if (p.N % 128 == 0) {
         p.ntn = p.N / 128;
         p.nwg = ntm * p.ntn;
-        conv_gemm_kernel<T, OutT, 128><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
+        conv_gemm_kernel<MODE, OutT, 128><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
     } else {
         p.ntn = p.N / 64;
         p.nwg = ntm * p.ntn;
-        conv_gemm_kernel<T, OutT, 64><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
+        conv_gemm_kernel<MODE, OutT, 64><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
     }
 }
 
@@ -305,10 +375,10 @@ void launch_t(const GemmParams& p0, hipStream_t st) {
 
 int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const void* x, const void* w,
                      const float* scale, const float* bias, const void* residual, void* y, hipStream_t st) {
-    if (dtype < 0 || dtype > 2) return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d", dtype);
-    const int es = dtype == 0 ? 4 : 2;
+    if (dtype < 0 || dtype > 3) return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d", dtype);
+    const int es = (dtype == 0 || dtype == 3) ? 4 : 2;
     const int vec = 16 / es;
-    const int bk = ROWB / es;
+    const int bk = ROWB / es;  // 32 elements (f32, split-bf16) or 64 (bf16) per K-step
     const long M = (long)d.batch * d.out_h * d.out_w;
     const long K = (long)d.kh * d.kw * d.cin;
     if (M <= 0 || M > 0x7fffff00L) return set_err(ctx, AVCER_EINVAL, "conv_gemm: M=%ld out of range", M);
@@ -330,7 +400,16 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
     p.sB = d.x_stride_b; p.sH = d.x_stride_h; p.sW = d.x_stride_w; p.coff = d.x_coff;
     p.ldY = d.y_ld; p.yoff = d.y_coff; p.ldR = d.r_ld; p.roff = d.r_coff;
     p.act = d.act; p.res_after = d.res_after_act;
+    const long x_extent = ((long)(d.batch - 1) * d.x_stride_b + (long)(d.in_h - 1) * d.x_stride_h +
+                           (long)(d.in_w - 1) * d.x_stride_w + d.x_coff + d.cin) * es;
+    const long w_extent = (long)d.n * K * es;
+    if (x_extent >= (long)OOB || w_extent >= (long)OOB)
+        return set_err(ctx, AVCER_EINVAL, "conv_gemm: operand larger than 4 GiB (%ld / %ld bytes): split the batch", x_extent,
+                       w_extent);
+    p.x_bytes = (unsigned)x_extent; p.w_bytes = (unsigned)w_extent;
     p.ntn = 0; p.nwg = 0;
+    static const int ablate = getenv("AVCER_GEMM_ABLATE") ? atoi(getenv("AVCER_GEMM_ABLATE")) : 0;
+    p.ablate = ablate;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ctx->prof) {
         if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
@@ -344,9 +423,10 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
         ev1 = ctx->prof_ev[ctx->prof_used++];
         (void)hipEventRecord(ev0, st);
     }
-    if (dtype == 0) launch_t<float, float>(p, st);
-    else if (dtype == 1) launch_t<bf16_t, bf16_t>(p, st);
-    else launch_t<bf16_t, float>(p, st);
+    if (dtype == 0) launch_t<0, float>(p, st);
+    else if (dtype == 1) launch_t<1, bf16_t>(p, st);
+    else if (dtype == 2) launch_t<1, float>(p, st);
+    else launch_t<2, float>(p, st);
     if (ev1) (void)hipEventRecord(ev1, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "conv_gemm launch: %s", hipGetErrorString(e));

@@ -493,6 +493,18 @@ __global__ void mean_time_relu_kernel(const float* __restrict__ x, float* __rest
     y[idx] = relu_nan(s / (float)t);
 }
 
+// Offline weight split for the split-bf16 contraction: per group of 32 K-elements, 32 hi bf16 then 32 lo bf16
+// (w = hi + lo + O(2^-17 |w|)); same 4 bytes per element as f32, so the DMA addressing is unchanged.
+__global__ void split_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = w[i];
+    const bf16_t h = f2bf(v);
+    const size_t g = i >> 5, j = i & 31;
+    out[g * 64 + j] = h;
+    out[g * 64 + 32 + j] = f2bf(v - bf2f(h));
+}
+
 __global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = f2bf(x[i]);
@@ -787,5 +799,11 @@ int k_audio_chunks(avcer_ctx* ctx, const float* wav, const int32_t* starts, cons
                    int mode, float* out, hipStream_t st) {
     audio_chunks_kernel<<<n, 512, 0, st>>>(wav, starts, ends, window, mode, out);
     CHECK_LAUNCH(ctx, "audio_chunks");
+    return AVCER_OK;
+}
+
+int k_split_weights(avcer_ctx* ctx, const float* w, bf16_t* out, size_t n, hipStream_t st) {
+    split_weights_kernel<<<cdiv((long)n, 256), 256, 0, st>>>(w, out, n);
+    CHECK_LAUNCH(ctx, "split_weights");
     return AVCER_OK;
 }

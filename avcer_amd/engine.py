@@ -15,6 +15,7 @@ from ._lib import AvcerError, ConvDesc
 
 MODE_FP32 = 0
 MODE_BF16 = 1
+MODE_BF16X3 = 2
 PAD_MODES = {"mean": 0, "constant": 1, "repeat": 2}
 
 
@@ -198,6 +199,13 @@ class Engine:
 
     def debug_tap_copied(self) -> int:
         return int(self.lib.avcer_debug_tap_copied(self.ctx))
+
+    def split_weights(self, w):
+        """f32 [N,K] -> split-bf16 layout for conv_gemm dtype 3 (returned as an int16 tensor of 2*N*K entries)."""
+        w = self._dev(w, torch.float32)
+        out = torch.empty(w.numel() * 2, dtype=torch.int16, device=self.device)
+        self._check(self.lib.avcer_split_weights(self.ctx, _ptr(w), _ptr(out), w.numel(), self._stream()))
+        return out
 
     def gemm_stats(self, reset: bool = True):
         n, f = C.c_int64(0), C.c_double(0.0)

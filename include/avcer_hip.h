@@ -42,7 +42,9 @@ enum {
 /* arithmetic mode of the MFMA contractions */
 enum {
     AVCER_MODE_FP32 = 0, /* f32 operands, v_mfma_f32_32x32x2_f32: parity mode (<=1e-4 on probabilities) */
-    AVCER_MODE_BF16 = 1  /* bf16 operands / f32 accumulate, v_mfma_f32_16x16x32_bf16: throughput mode */
+    AVCER_MODE_BF16 = 1, /* bf16 operands / f32 accumulate, v_mfma_f32_16x16x32_bf16: throughput mode */
+    AVCER_MODE_BF16X3 = 2 /* f32 activations and results; each product as ah*wh + ah*wl + al*wh on the bf16 MFMA
+                             (operands split into bf16 hi+lo, ~2^-17 relative error): parity-grade, 3 MFMAs per product */
 };
 
 int avcer_abi_version(void);
@@ -122,7 +124,7 @@ int avcer_fuse(avcer_ctx* ctx, const float* stat, const float* dyn_logits, const
 /* The contraction kernel itself (implicit-GEMM convolution with fused epilogue), exported for kernel-level
  * parity tests and micro-benchmarks:  Y[m, n] = act(scale[n] * sum_k A[m,k] * W[n,k] + bias[n] (+ R[m,n]))
  * where A is gathered from an NHWC tensor.  See avcer_conv_desc. dtype: 0 = f32 in/out, 1 = bf16 in/out,
- * 2 = bf16 in / f32 out. */
+ * 2 = bf16 in / f32 out, 3 = split-bf16: f32 in/out with w pre-split by avcer_split_weights. */
 typedef struct avcer_conv_desc {
     int32_t batch, in_h, in_w;       /* input extents used for bounds (zero padding outside) */
     int32_t out_h, out_w;            /* M = batch*out_h*out_w */
@@ -140,6 +142,10 @@ typedef struct avcer_conv_desc {
 
 int avcer_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, const void* x, const void* w,
                     const float* scale, const float* bias, const void* residual, void* y, avcer_stream_t stream);
+
+/* Weight layout of dtype 3: for every group of 32 K-elements, 32 bf16 "hi" values then 32 bf16 "lo" values with
+ * w = hi + lo (+ O(2^-17 |w|)).  w f32 [n*k] (k a multiple of 32) -> out, same size in bytes. Both device pointers. */
+int avcer_split_weights(avcer_ctx* ctx, const float* w, void* out, size_t numel, avcer_stream_t stream);
 
 /* Last launch statistics of the dominant kernel (for bench.py's roofline object): number of conv_gemm
  * launches and their summed algorithmic FLOPs since the previous call to this function. */

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from avcer_amd import audio_pipeline, synth
-from avcer_amd.engine import MODE_BF16, MODE_FP32
+from avcer_amd.engine import MODE_BF16, MODE_BF16X3, MODE_FP32
 from oracle import audio as oa
 
 pytestmark = pytest.mark.gpu
@@ -73,6 +73,17 @@ def test_audio_model_mirror_squeezes_like_reference(engine_audio, sd_audio, gold
     m.engine, m.mode = engine_audio, MODE_FP32
     x = torch.from_numpy(oa.normalize(synth.waveforms(5679, 1, 64000)))
     assert tuple(m(x).shape) == (8,) == tuple(golden("audio_model")["t64000_logits"].shape)
+
+
+def test_expr_model_split_bf16_meets_parity_gate(engine_audio, golden):
+    g = golden("audio_model")
+    out = engine_audio.audio_forward(torch.from_numpy(synth.waveforms(5678, 2, 32000)), normalize=True, mode=MODE_BF16X3)
+    got, ref = out.cpu().numpy(), g["t32000_logits"]
+    p_got = torch.softmax(torch.from_numpy(got[:, :7]), 1).numpy()
+    p_ref = torch.softmax(torch.from_numpy(ref[:, :7]), 1).numpy()
+    print("audio split-bf16 max|dlogit|", np.abs(got - ref).max(), "max|dprob|", np.abs(p_got - p_ref).max())
+    assert np.abs(p_got - p_ref).max() < 1e-4
+    assert (got.argmax(1) == ref.argmax(1)).all()
 
 
 def test_expr_model_bf16_reports(engine_audio, golden):

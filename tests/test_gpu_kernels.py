@@ -25,28 +25,29 @@ def _act(v, act):
 
 
 def _run(engine, d, dtype, x, w, scale, bias, res, y):
-    tin = torch.float32 if dtype == 0 else torch.bfloat16
-    tout = torch.float32 if dtype in (0, 2) else torch.bfloat16
+    tin = torch.float32 if dtype in (0, 3) else torch.bfloat16
+    tout = torch.float32 if dtype in (0, 2, 3) else torch.bfloat16
     dev = engine.device
     xd, wd = x.to(dev, tin).contiguous(), w.to(dev, tin).contiguous()
+    w_arg = engine.split_weights(wd) if dtype == 3 else wd  # dtype 3: bf16 hi/lo split of the f32 weights
     sd_ = None if scale is None else scale.to(dev, torch.float32)
     bd = None if bias is None else bias.to(dev, torch.float32)
     rd = None if res is None else res.to(dev, tout).contiguous()
     yd = y.to(dev, tout).contiguous()
-    engine.conv_gemm(d, dtype, xd, wd, sd_, bd, rd, yd)
+    engine.conv_gemm(d, dtype, xd, w_arg, sd_, bd, rd, yd)
     torch.cuda.synchronize()
     return yd.float().cpu(), xd.double().cpu(), wd.double().cpu(), (None if rd is None else rd.double().cpu())
 
 
 def _tol(dtype, ref):
     scale = float(ref.abs().max()) + 1e-6
-    return (2e-5 if dtype == 0 else (1.2e-2 if dtype == 1 else 2e-4)) * scale
+    return {0: 2e-5, 1: 1.2e-2, 2: 2e-4, 3: 6e-5}[dtype] * scale
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 def test_identity_times_asymmetric_weight(engine, dtype):
     """A = I with an ASYMMETRIC W catches a row/col swap of the accumulator layout (exact small integers)."""
-    k = 32 if dtype == 0 else 64
+    k = 32 if dtype in (0, 3) else 64
     m, n = 128, 128
     x = torch.zeros(m, k)
     x[torch.arange(k), torch.arange(k)] = 1.0
@@ -58,7 +59,7 @@ def test_identity_times_asymmetric_weight(engine, dtype):
     assert torch.equal(y, ref), (y - ref).abs().max()
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("m,k,n", [(300, 128, 192), (129, 64, 256), (1, 256, 64), (1000, 2048, 128)])
 def test_linear(engine, dtype, m, k, n):
     g = torch.Generator().manual_seed(m + k + n)
@@ -82,7 +83,7 @@ CONVS = [
 ]
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("cfg", CONVS)
 def test_conv(engine, dtype, cfg):
     b, h, w_, c, kh, kw, s, p, dil, n, act = cfg
@@ -104,7 +105,7 @@ def test_conv(engine, dtype, cfg):
     assert (y.double() - ref).abs().max() < _tol(dtype, ref)
 
 
-@pytest.mark.parametrize("dtype", [0, 2])
+@pytest.mark.parametrize("dtype", [0, 2, 3])
 def test_grouped_slices_and_residual_after_act(engine, dtype):
     """pos-conv shape: one group of a [B,S,C] tensor, zero padding in time, output/residual written into a channel
     slice, y = gelu(conv + bias) + residual."""
@@ -126,7 +127,7 @@ def test_grouped_slices_and_residual_after_act(engine, dtype):
     assert torch.equal(y[:, :, :128], y0[:, :, :128]) and torch.equal(y[:, :, 192:], y0[:, :, 192:])
 
 
-@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("dtype", [0, 1, 3])
 def test_stem_layout(engine, dtype):
     """7x7/2 stem as 8 tap rows x (8 pixels x 4 channels) over a zero-bordered 230x230x4 image."""
     from avcer_amd import packing, synth
@@ -155,3 +156,18 @@ def test_bad_shapes_are_rejected(engine):
     d = _desc(batch=4, cin=24, x_stride_b=24, x_stride_h=24, x_stride_w=24, n=64, y_ld=64)
     with pytest.raises(AvcerError):
         engine.conv_gemm(d, 0, x, x, None, None, None, x)
+
+
+def test_split_bf16_is_far_more_accurate_than_bf16(engine):
+    """The split-bf16 contraction must sit at f32-grade error, two orders below plain bf16."""
+    g = torch.Generator().manual_seed(3)
+    m, k, n = 512, 1024, 256
+    x, w = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5
+    d = _desc(batch=m, cin=k, x_stride_b=k, x_stride_h=k, x_stride_w=k, n=n, y_ld=n, r_ld=n)
+    ref = x.double() @ w.double().t()
+    errs = {}
+    for dtype in (0, 2, 3):
+        y, *_ = _run(engine, d, dtype, x, w, None, None, None, torch.zeros(m, n))
+        errs[dtype] = float((y.double() - ref).abs().max())
+    print("max|err| f32 / bf16 / split-bf16:", errs)
+    assert errs[3] < 30 * errs[0] + 1e-6 and errs[3] < errs[2] / 50

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from avcer_amd import synth, video_pipeline
-from avcer_amd.engine import MODE_BF16, MODE_FP32
+from avcer_amd.engine import MODE_BF16, MODE_BF16X3, MODE_FP32
 from oracle import video as ov
 
 pytestmark = pytest.mark.gpu
@@ -56,6 +56,16 @@ def test_static_matches_golden_and_oracle_fp32(engine_static, sd_static, golden)
     # the preprocessed-tensor entry point (exact argument of pth_model_static) gives the same numbers
     l2, p2, f2 = engine_static.static_forward_nchw(ov.pth_processing(frames), MODE_FP32)
     assert torch.equal(l2.cpu(), torch.from_numpy(logits)) and torch.equal(f2.cpu(), torch.from_numpy(feats))
+
+
+def test_static_split_bf16_meets_parity_gate(engine_static, golden):
+    """AVCER_MODE_BF16X3 (bf16 MFMA on hi/lo-split operands) must satisfy the same 1e-4 gate as the f32 mode."""
+    g = golden("static")
+    frames = synth.face_frames(1234, 8)
+    logits, probs, feats = [t.cpu().numpy() for t in engine_static.static_forward(torch.from_numpy(frames), MODE_BF16X3)]
+    print("static split-bf16 max|dprob|", np.abs(probs - g["probs"]).max(), "max|dlogit|", np.abs(logits - g["logits"]).max())
+    assert np.abs(probs - g["probs"]).max() < PROB_TOL
+    assert (probs.argmax(1) == g["probs"].argmax(1)).all()
 
 
 def test_static_bf16_reports_and_keeps_argmax(engine_static, golden):
