@@ -84,24 +84,29 @@ __device__ __forceinline__ float relu_nan(float v) { return v > 0.f ? v : (v != 
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
 
-// ACT: 0 = none, 1 = relu, 2 = gelu (compile-time so that erff is only expanded in the GELU instantiation)
+// Epilogue, staged through LDS so that HBM sees whole 128-byte lines: every wave first parks its scaled/biased
+// accumulators in an f32 [128][BN] image (16-byte chunks XOR-swizzled with row&7 against write conflicts), then the
+// 256 threads walk the image row-major, 8 consecutive channels per thread: residual add, activation, one 16-byte
+// (bf16) or two 16-byte (f32) stores.  ACT: 0 none, 1 relu, 2 gelu (compile-time: erff only in the GELU variant).
 template <typename OutT, int ACT>
-__device__ __forceinline__ void epilogue4(const GemmParams& p, long m, int n0, float v0, float v1, float v2, float v3) {
-    float v[4] = {v0, v1, v2, v3};
-    float r[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ void finish8(const GemmParams& p, long m, int n0, const float4 a, const float4 b) {
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (p.R) {
         const char* rp = p.R + (m * p.ldR + p.roff + n0) * (long)sizeof(OutT);
         if constexpr (sizeof(OutT) == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(rp);
-            r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+            const float4 t0 = *reinterpret_cast<const float4*>(rp);
+            const float4 t1 = *reinterpret_cast<const float4*>(rp + 16);
+            r[0] = t0.x; r[1] = t0.y; r[2] = t0.z; r[3] = t0.w; r[4] = t1.x; r[5] = t1.y; r[6] = t1.z; r[7] = t1.w;
         } else {
-            const uint2 t = *reinterpret_cast<const uint2*>(rp);
-            r[0] = bf2f((bf16_t)(t.x & 0xffff)); r[1] = bf2f((bf16_t)(t.x >> 16));
-            r[2] = bf2f((bf16_t)(t.y & 0xffff)); r[3] = bf2f((bf16_t)(t.y >> 16));
+            const uint4 t = *reinterpret_cast<const uint4*>(rp);
+            const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { r[2 * j] = bf2f((bf16_t)(w[j] & 0xffff)); r[2 * j + 1] = bf2f((bf16_t)(w[j] >> 16)); }
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 8; ++j) {
         float x = p.res_after ? v[j] : v[j] + r[j];
         if constexpr (ACT == 1) x = relu_nan(x);
         if constexpr (ACT == 2) x = gelu_erf(x);
@@ -110,51 +115,72 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, long m, int n0, f
     char* yp = p.Y + (m * p.ldY + p.yoff + n0) * (long)sizeof(OutT);
     if constexpr (sizeof(OutT) == 4) {
         *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(yp + 16) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
-        uint2 t;
+        uint4 t;
         t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
         t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        *reinterpret_cast<uint2*>(yp) = t;
+        t.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+        t.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        *reinterpret_cast<uint4*>(yp) = t;
     }
 }
 
-template <int MODE, typename OutT, int BN, int ACT, typename AccT, int NFN, int NFM>
-__device__ __forceinline__ void epilogue_all(const GemmParams& p, AccT (&acc)[NFN][NFM], int m_base, int n_base, int wm,
-                                             int wn, int lane) {
-    constexpr bool IS_F32 = MODE == 0;
+template <int BN>
+__device__ __forceinline__ int stage_off(int row, int chunk) { return row * (BN * 4) + ((chunk ^ (row & 7)) << 4); }
+
+template <int MODE, int BN, typename AccT, int NFN, int NFM>
+__device__ __forceinline__ void stage_acc(const GemmParams& p, char* smem, AccT (&acc)[NFN][NFM], int n_base, int wm, int wn,
+                                          int lane) {
     constexpr int WN = BN / 2;
-    if constexpr (IS_F32) {
+    if constexpr (MODE == 0) {
 #pragma unroll
         for (int fn = 0; fn < NFN; ++fn)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n0 = n_base + wn * WN + fn * 32 + 8 * g + 4 * (lane >> 5);
+                const int nl = wn * WN + fn * 32 + 8 * g + 4 * (lane >> 5);
                 float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n0);
-                if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + n0);
+                if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n_base + nl);
+                if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + n_base + nl);
 #pragma unroll
                 for (int fm = 0; fm < NFM; ++fm) {
-                    const int m = m_base + wm * 64 + fm * 32 + (lane & 31);
-                    if (m < p.M)
-                        epilogue4<OutT, ACT>(p, m, n0, acc[fn][fm][4 * g + 0] * sc.x + bi.x,
-                                             acc[fn][fm][4 * g + 1] * sc.y + bi.y, acc[fn][fm][4 * g + 2] * sc.z + bi.z,
-                                             acc[fn][fm][4 * g + 3] * sc.w + bi.w);
+                    const int ml = wm * 64 + fm * 32 + (lane & 31);
+                    *reinterpret_cast<float4*>(smem + stage_off<BN>(ml, nl >> 2)) =
+                        make_float4(acc[fn][fm][4 * g + 0] * sc.x + bi.x, acc[fn][fm][4 * g + 1] * sc.y + bi.y,
+                                    acc[fn][fm][4 * g + 2] * sc.z + bi.z, acc[fn][fm][4 * g + 3] * sc.w + bi.w);
                 }
             }
     } else {
 #pragma unroll
         for (int fn = 0; fn < NFN; ++fn) {
-            const int n0 = n_base + wn * WN + fn * 16 + 4 * (lane >> 4);
+            const int nl = wn * WN + fn * 16 + 4 * (lane >> 4);
             float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n0);
-            if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + n0);
+            if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + n_base + nl);
+            if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + n_base + nl);
 #pragma unroll
             for (int fm = 0; fm < NFM; ++fm) {
-                const int m = m_base + wm * 64 + fm * 16 + (lane & 15);
-                if (m < p.M)
-                    epilogue4<OutT, ACT>(p, m, n0, acc[fn][fm][0] * sc.x + bi.x, acc[fn][fm][1] * sc.y + bi.y,
-                                         acc[fn][fm][2] * sc.z + bi.z, acc[fn][fm][3] * sc.w + bi.w);
+                const int ml = wm * 64 + fm * 16 + (lane & 15);
+                *reinterpret_cast<float4*>(smem + stage_off<BN>(ml, nl >> 2)) =
+                    make_float4(acc[fn][fm][0] * sc.x + bi.x, acc[fn][fm][1] * sc.y + bi.y, acc[fn][fm][2] * sc.z + bi.z,
+                                acc[fn][fm][3] * sc.w + bi.w);
             }
+        }
+    }
+}
+
+template <typename OutT, int BN, int ACT>
+__device__ __forceinline__ void drain_stage(const GemmParams& p, const char* smem, int m_base, int n_base, int tid) {
+    constexpr int TPR = BN / 8;          // threads per row (8 channels each)
+    constexpr int RPP = 256 / TPR;       // rows per pass
+    const int c8 = tid % TPR, r0 = tid / TPR;
+#pragma unroll 4
+    for (int pass = 0; pass < BM / RPP; ++pass) {
+        const int row = pass * RPP + r0;
+        const long m = (long)m_base + row;
+        if (m < p.M) {
+            const float4 a = *reinterpret_cast<const float4*>(smem + stage_off<BN>(row, 2 * c8));
+            const float4 b = *reinterpret_cast<const float4*>(smem + stage_off<BN>(row, 2 * c8 + 1));
+            finish8<OutT, ACT>(p, m, n_base + c8 * 8, a, b);
         }
     }
 }
@@ -350,10 +376,12 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
     }
 #undef AVCER_ISSUE_TILES
 
-    // epilogue: accumulator register group g of a lane = 4 consecutive output channels of one position
-    if (p.act == 2) epilogue_all<MODE, OutT, BN, 2>(p, acc, m_base, n_base, wm, wn, lane);
-    else if (p.act == 1) epilogue_all<MODE, OutT, BN, 1>(p, acc, m_base, n_base, wm, wn, lane);
-    else epilogue_all<MODE, OutT, BN, 0>(p, acc, m_base, n_base, wm, wn, lane);
+    // epilogue through LDS (the tile buffers are free: the loop ended on a barrier)
+    stage_acc<MODE, BN>(p, smem, acc, n_base, wm, wn, lane);
+    __syncthreads();
+    if (p.act == 2) drain_stage<OutT, BN, 2>(p, smem, m_base, n_base, tid);
+    else if (p.act == 1) drain_stage<OutT, BN, 1>(p, smem, m_base, n_base, tid);
+    else drain_stage<OutT, BN, 0>(p, smem, m_base, n_base, tid);
 }
 
 template <int MODE, typename OutT>
@@ -388,8 +416,9 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: cin/coff/strides must be multiples of %d", vec);
     if (d.x_stride_w % vec && !(d.kw == 1 && d.pad_w == 0 && (d.stride_w * d.x_stride_w) % vec == 0))
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: x_stride_w=%ld breaks 16-byte alignment", (long)d.x_stride_w);
-    if (d.y_ld % 4 || d.y_coff % 4 || (residual && (d.r_ld % 4 || d.r_coff % 4)))
-        return set_err(ctx, AVCER_EINVAL, "conv_gemm: output/residual leading dims must be multiples of 4");
+    const int ovec = 16 / ((dtype == 1) ? 2 : 4);  // 16-byte output / residual vectors
+    if (d.y_ld % ovec || d.y_coff % ovec || (residual && (d.r_ld % ovec || d.r_coff % ovec)))
+        return set_err(ctx, AVCER_EINVAL, "conv_gemm: output/residual leading dims and offsets must be multiples of %d", ovec);
     if (!x || !w || !y) return set_err(ctx, AVCER_EINVAL, "conv_gemm: null pointer");
     GemmParams p;
     p.X = (const char*)x; p.W = (const char*)w; p.scale = scale; p.bias = bias; p.R = (const char*)residual;
