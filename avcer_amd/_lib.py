@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
         ("x_coff", C.c_int32), ("n", C.c_int32),
         ("y_ld", C.c_int64), ("y_coff", C.c_int32),
         ("r_ld", C.c_int64), ("r_coff", C.c_int32),
-        ("act", C.c_int32), ("res_after_act", C.c_int32),
+        ("act", C.c_int32), ("res_after_act", C.c_int32), ("groups", C.c_int32),
     ]
 
 
@@ -38,6 +38,7 @@ SIGNATURES = {
     "avcer_load_audio": (C.c_int, [c_ctx, C.c_void_p, C.c_size_t]),
     "avcer_static_forward": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, c_stream]),
+    "avcer_set_static_batch": (C.c_int, [c_ctx, C.c_int]),
     "avcer_static_forward_nchw": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             c_stream]),
     "avcer_gather_windows": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, c_stream]),

@@ -208,7 +208,7 @@ struct Net {
             if (!wp) { err = set_err(ctx, AVCER_ESTATE, "gemm %s: bf16 weights not prepared", wname.c_str()); return; }
         }
         const long K = (long)d.kh * d.kw * d.cin;
-        if ((long)w->numel != (long)d.n * K) {
+        if ((long)w->numel != (long)d.n * K * (d.groups > 1 ? d.groups : 1)) {
             err = set_err(ctx, AVCER_EFORMAT, "gemm %s: weight has %zu elements, expected %ld x %ld", wname.c_str(),
                           w->numel, (long)d.n, K);
             return;
@@ -334,7 +334,7 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     if (bf) TRY(ensure_all_bf16(ctx, ctx->stat, st));
     if (mode == AVCER_MODE_BF16X3) TRY(ensure_all_x3(ctx, ctx->stat, st));
     const size_t es = bf ? 2 : 4;
-    const int NB = std::min(n, 256);
+    const int NB = std::min(n, ctx->static_batch);
     const size_t act_elems = (size_t)NB * 112 * 112 * 64;  // largest activation (stem output)
     const size_t pre_elems = (size_t)NB * 230 * 230 * 4;
     const size_t total = pre_elems * es + 5 * (act_elems * es + 256) + (size_t)NB * (2048 + 512) * 4 + 4096;
@@ -586,14 +586,13 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
             net.chk(k_f32_to_bf16(ctx, Hf, Xb, (size_t)r * E, st));
             pin = Xb;
         }
-        for (int g = 0; g < 16; ++g) {
+        {  // 16 groups of 64 channels in ONE launch (grid.y = group)
             avcer_conv_desc d = conv1d_desc(nb, S, 64, 128, 1, 64, 1, S, 64, 2);
             d.x_stride_b = (int64_t)S * E; d.x_stride_h = E; d.x_stride_w = E;
-            d.x_coff = g * 64;
-            d.y_ld = E; d.y_coff = g * 64; d.r_ld = E; d.r_coff = g * 64;
+            d.y_ld = E; d.r_ld = E;
             d.res_after_act = 1;
-            net.gemm(d, "pos.g" + std::to_string(g) + ".w", nullptr, net.F("pos.b") ? net.F("pos.b") + g * 64 : nullptr, pin,
-                     Hf, Of, bf, false);
+            d.groups = 16;
+            net.gemm(d, "pos.w", nullptr, net.F("pos.b"), pin, Hf, Of, bf, false);
         }
         float* h = Of;
         net.tap("posconv", h, (size_t)r * E * 4);
@@ -680,6 +679,14 @@ extern "C" int avcer_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc* d, int dty
     if (!ctx || !d) return AVCER_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return launch_conv_gemm(ctx, *d, dtype, x, w, scale, bias, residual, y, (hipStream_t)stream);
+}
+
+// Frames per internal pass of the static CNN (default 1024; layers 3/4 need >= 512 frames to fill 256 CUs twice).
+extern "C" int avcer_set_static_batch(avcer_ctx* ctx, int frames) {
+    if (!ctx) return AVCER_EINVAL;
+    if (frames < 1 || frames > 1024) return set_err(ctx, AVCER_EINVAL, "static batch %d outside [1,1024]", frames);
+    ctx->static_batch = frames;
+    return AVCER_OK;
 }
 
 extern "C" int avcer_profile_enable(avcer_ctx* ctx, int on) {

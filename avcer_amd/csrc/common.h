@@ -41,6 +41,7 @@ struct avcer_ctx {
     char err[512] = {0};
     Model stat, dyn, aud;
     int aud_classes = 0;
+    int static_batch = 1024;  // frames per internal pass of the static CNN (4 GiB buffer-descriptor limit at f32)
     // grow-only workspace arenas (activations), one per pipeline
     DevBuf ws[8];
     int64_t gemm_launches = 0;

@@ -57,6 +57,7 @@ struct GemmParams {
     int roff;
     int act, res_after;
     int ntn, nwg;
+    int groups;  // grid.y: group g shifts coff / yoff / roff by g*Cin / g*N and the weight/scale/bias rows by g*N
     int ablate;  // test-only (env AVCER_GEMM_ABLATE): 1 = skip MFMA, 2 = skip global loads, 3 = and LDS stores
 };
 
@@ -225,7 +226,9 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
     const int tile_n = bid % p.ntn;
     const int tile_m = bid / p.ntn;
     const int m_base = tile_m * BM;
-    const int n_base = tile_n * BN;
+    const int grp = blockIdx.y;
+    const int n_base = grp * p.N + tile_n * BN;  // row of W / entry of scale, bias; output channel = yoff + n_base
+    const int x_coff = p.coff + grp * p.Cin;
 
     // hardware-bounds-checked buffer descriptors: an out-of-range voffset returns zeros without a branch
     const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.X), (short)0, (int)p.x_bytes, 0x00020000);
@@ -255,7 +258,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
         const int ix = ox * p.sw - p.pw;
         a_iy[j] = ok ? iy : -(1 << 28);  // rows past M fail the bounds test below
         a_ix[j] = ix;
-        a_off[j] = (unsigned)(((long)b * p.sB + (long)iy * p.sH + (long)ix * p.sW + p.coff) * ES);
+        a_off[j] = (unsigned)(((long)b * p.sB + (long)iy * p.sH + (long)ix * p.sW + x_coff) * ES);
         a_kc[j] = (slot ^ swz_key(lrow)) * VEC;
     }
     unsigned w_off[B_ISS];
@@ -391,11 +394,11 @@ void launch_t(const GemmParams& p0, hipStream_t st) {
     if (p.N % 128 == 0) {
         p.ntn = p.N / 128;
         p.nwg = ntm * p.ntn;
-        conv_gemm_kernel<MODE, OutT, 128><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
+        conv_gemm_kernel<MODE, OutT, 128><<<dim3(p.nwg, p.groups), dim3(256), 0, st>>>(p);
     } else {
         p.ntn = p.N / 64;
         p.nwg = ntm * p.ntn;
-        conv_gemm_kernel<MODE, OutT, 64><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
+        conv_gemm_kernel<MODE, OutT, 64><<<dim3(p.nwg, p.groups), dim3(256), 0, st>>>(p);
     }
 }
 
@@ -429,14 +432,15 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
     p.sB = d.x_stride_b; p.sH = d.x_stride_h; p.sW = d.x_stride_w; p.coff = d.x_coff;
     p.ldY = d.y_ld; p.yoff = d.y_coff; p.ldR = d.r_ld; p.roff = d.r_coff;
     p.act = d.act; p.res_after = d.res_after_act;
+    const int groups = d.groups > 1 ? d.groups : 1;
     const long x_extent = ((long)(d.batch - 1) * d.x_stride_b + (long)(d.in_h - 1) * d.x_stride_h +
-                           (long)(d.in_w - 1) * d.x_stride_w + d.x_coff + d.cin) * es;
-    const long w_extent = (long)d.n * K * es;
+                           (long)(d.in_w - 1) * d.x_stride_w + d.x_coff + (long)groups * d.cin) * es;
+    const long w_extent = (long)groups * d.n * K * es;
     if (x_extent >= (long)OOB || w_extent >= (long)OOB)
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: operand larger than 4 GiB (%ld / %ld bytes): split the batch", x_extent,
                        w_extent);
     p.x_bytes = (unsigned)x_extent; p.w_bytes = (unsigned)w_extent;
-    p.ntn = 0; p.nwg = 0;
+    p.ntn = 0; p.nwg = 0; p.groups = groups;
     static const int ablate = getenv("AVCER_GEMM_ABLATE") ? atoi(getenv("AVCER_GEMM_ABLATE")) : 0;
     p.ablate = ablate;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -460,6 +464,6 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "conv_gemm launch: %s", hipGetErrorString(e));
     ctx->gemm_launches += 1;
-    ctx->gemm_flops += 2.0 * (double)M * (double)d.n * (double)K;
+    ctx->gemm_flops += 2.0 * (double)M * (double)d.n * (double)K * groups;
     return AVCER_OK;
 }

@@ -81,6 +81,9 @@ class Engine:
         self._load(self.lib.avcer_load_audio, packing.pack_audio(state_dict))
         self.audio_classes = self.lib.avcer_audio_num_classes(self.ctx)
 
+    def set_static_batch(self, frames: int):
+        self._check(self.lib.avcer_set_static_batch(self.ctx, int(frames)))
+
     # ------------------------------------------------------------------ forward passes
     def static_forward(self, frames_u8, mode: int = MODE_FP32):
         """frames u8 [N,H,W,3] RGB -> (logits [N,7], probs [N,7], feats [N,512] pre-ReLU)."""

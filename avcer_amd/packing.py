@@ -114,8 +114,7 @@ def pack_audio(sd) -> "OrderedDict[str, np.ndarray]":
     out["fp.ln.g"], out["fp.ln.b"] = _f32(sd[p + "layer_norm.weight"]), _f32(sd[p + "layer_norm.bias"])
     out["fp.w"], out["fp.b"] = _f32(sd[p + "projection.weight"]), _f32(sd[p + "projection.bias"])
     pw = pos_conv_weight(sd)  # [1024, 64, 128] (out, in/groups, k)
-    for g in range(16):
-        out[f"pos.g{g}.w"] = _conv1d_w(pw[g * 64:(g + 1) * 64])
+    out["pos.w"] = _conv1d_w(pw)  # [1024, 128*64]: rows g*64..g*64+63 are group g (one grouped launch)
     out["pos.b"] = _f32(sd[w2 + "encoder.pos_conv_embed.conv.bias"])
     for l in range(12):
         p = f"{w2}encoder.layers.{l}."

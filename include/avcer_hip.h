@@ -70,6 +70,9 @@ int avcer_load_audio(avcer_ctx* ctx, const void* blob_host, size_t nbytes);
 int avcer_static_forward(avcer_ctx* ctx, const uint8_t* frames_hwc, int n, int in_h, int in_w, int mode,
                          float* logits, float* probs, float* feats, avcer_stream_t stream);
 
+/* Frames per internal pass of the static CNN, 1..1024 (default 1024). Larger passes fill the chip on layers 3/4. */
+int avcer_set_static_batch(avcer_ctx* ctx, int frames);
+
 /* The same model on an already preprocessed tensor, i.e. the exact argument of the reference's
  * `pth_model_static(x)`:  x f32 [n,3,224,224] (BGR, mean-subtracted).   ref: get_prob_video.py:103-109 */
 int avcer_static_forward_nchw(avcer_ctx* ctx, const float* x, int n, int mode, float* logits, float* probs,
@@ -138,6 +141,9 @@ typedef struct avcer_conv_desc {
     int64_t r_ld; int32_t r_coff;    /* residual row stride / offset (if residual != NULL) */
     int32_t act;                     /* 0 none, 1 relu, 2 gelu(erf) */
     int32_t res_after_act;           /* 0: act(v + r), 1: act(v) + r */
+    int32_t groups;                  /* 0/1 = plain; G > 1 = grouped convolution in ONE launch: group g reads input
+                                        channels x_coff + g*cin, uses weight rows [g*n, (g+1)*n) of w (and scale/bias
+                                        entries g*n..), and writes / adds channels y_coff + g*n, r_coff + g*n */
 } avcer_conv_desc;
 
 int avcer_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, const void* x, const void* w,

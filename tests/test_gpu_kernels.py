@@ -13,7 +13,7 @@ def _desc(**kw):
     d = ConvDesc()
     base = dict(batch=1, in_h=1, in_w=1, out_h=1, out_w=1, cin=32, kh=1, kw=1, stride_h=1, stride_w=1, pad_h=0, pad_w=0,
                 dil_h=1, dil_w=1, x_stride_b=0, x_stride_h=0, x_stride_w=0, x_coff=0, n=64, y_ld=64, y_coff=0, r_ld=64,
-                r_coff=0, act=0, res_after_act=0)
+                r_coff=0, act=0, res_after_act=0, groups=0)
     base.update(kw)
     for k, v in base.items():
         setattr(d, k, int(v))
@@ -171,3 +171,22 @@ def test_split_bf16_is_far_more_accurate_than_bf16(engine):
         errs[dtype] = float((y.double() - ref).abs().max())
     print("max|err| f32 / bf16 / split-bf16:", errs)
     assert errs[3] < 30 * errs[0] + 1e-6 and errs[3] < errs[2] / 50
+
+
+@pytest.mark.parametrize("dtype", [0, 2, 3])
+def test_grouped_launch_matches_grouped_conv1d(engine, dtype):
+    """wav2vec2 pos-conv shape in one launch: groups of 64 channels, k taps, zero padding, gelu(conv+b) + residual."""
+    b, s, groups, cin, k = 2, 37, 4, 64, 16
+    ctot = groups * cin
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(b, s, ctot, generator=gen)
+    w = torch.randn(ctot, k, cin, generator=gen) / (k * cin) ** 0.5   # [out, k, in/groups]
+    bias = torch.randn(ctot, generator=gen)
+    res = torch.randn(b, s, ctot, generator=gen)
+    d = _desc(batch=b, in_h=s, in_w=1, out_h=s, out_w=1, cin=cin, kh=k, kw=1, pad_h=k // 2, x_stride_b=s * ctot,
+              x_stride_h=ctot, x_stride_w=ctot, n=64, y_ld=ctot, r_ld=ctot, act=2, res_after_act=1, groups=groups)
+    y, xd, wd, rd = _run(engine, d, dtype, x, w.reshape(ctot, -1), None, bias, res, torch.zeros(b, s, ctot))
+    ref = F.conv1d(xd.permute(0, 2, 1), wd.reshape(ctot, k, cin).permute(0, 2, 1), bias.double(), padding=k // 2,
+                   groups=groups)[:, :, :s]
+    ref = F.gelu(ref).permute(0, 2, 1) + rd
+    assert (y.double() - ref).abs().max() < _tol(dtype, ref)

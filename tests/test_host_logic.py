@@ -92,7 +92,7 @@ def test_pack_static_layouts(sd_static):
 def test_pack_audio_layouts(sd_audio):
     t = packing.pack_audio(sd_audio)
     w = oa.pos_conv_weight(sd_audio).numpy()  # torch._weight_norm
-    g3 = t["pos.g3.w"].reshape(64, 128, 64)
+    g3 = t["pos.w"].reshape(1024, 128, 64)[192:256]
     np.testing.assert_array_equal(g3, w[192:256].transpose(0, 2, 1))
     assert t["enc4.qkv.w"].shape == (3072, 1024) and t["tl1.qkv.w"].shape == (3072, 1024)
     np.testing.assert_array_equal(t["enc4.qkv.w"][1024:2048],

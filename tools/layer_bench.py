@@ -22,7 +22,7 @@ def desc(**kw):
     d = ConvDesc()
     base = dict(batch=1, in_h=1, in_w=1, out_h=1, out_w=1, cin=32, kh=1, kw=1, stride_h=1, stride_w=1, pad_h=0, pad_w=0,
                 dil_h=1, dil_w=1, x_stride_b=0, x_stride_h=0, x_stride_w=0, x_coff=0, n=64, y_ld=64, y_coff=0, r_ld=64,
-                r_coff=0, act=0, res_after_act=0)
+                r_coff=0, act=0, res_after_act=0, groups=0)
     base.update(kw)
     for k, v in base.items():
         setattr(d, k, int(v))
@@ -74,9 +74,9 @@ def audio_layers(nb, t):
     L = [conv1d(nb, ln[i], 512, ck[i], cs[i], 512, f"fe{i} k{ck[i]} s{cs[i]} L{ln[i]}->{ln[i+1]}") for i in range(1, 7)]
     r = nb * S
     L.append(linear(r, 512, 1024, "feature projection"))
-    pos = dict(name="pos-conv group (k128, 64->64)", count=16, res=True, in_elems=r * 64, out_elems=r * 64,
+    pos = dict(name="pos-conv 16 groups (k128, 64->64)", count=1, res=True, in_elems=r * 1024, out_elems=r * 1024, groups=16,
                d=desc(batch=nb, in_h=S, in_w=1, out_h=S, out_w=1, cin=64, kh=128, kw=1, pad_h=64, x_stride_b=S * 1024,
-                      x_stride_h=1024, x_stride_w=1024, n=64, y_ld=1024, r_ld=1024, act=2, res_after_act=1))
+                      x_stride_h=1024, x_stride_w=1024, n=64, y_ld=1024, r_ld=1024, act=2, res_after_act=1, groups=16))
     L.append(pos)
     L += [linear(r, 1024, 3072, "qkv 1024->3072", 14), linear(r, 1024, 1024, "out-proj / tl ffn 1024->1024", 18, res=True),
           linear(r, 1024, 4096, "ffn1 1024->4096", 12), linear(r, 4096, 1024, "ffn2 4096->1024", 12, res=True)]
@@ -96,13 +96,14 @@ def run(engine, layers, dtype, iters, title):
         m = d.batch * d.out_h * d.out_w
         k = d.kh * d.kw * d.cin
         x = torch.randn(max(L["in_elems"], d.x_stride_b * d.batch) + 64, device=engine.device).to(tin)
-        w = (torch.randn(d.n * k, device=engine.device) / k ** 0.5).to(tin)
+        g = L.get("groups", 1)
+        w = (torch.randn(g * d.n * k, device=engine.device) / k ** 0.5).to(tin)
         if dtype == 3:
             w = engine.split_weights(w)
         ylen = m * max(d.y_ld, d.n) + 64
         y = torch.empty(ylen, device=engine.device, dtype=tin)
         res = torch.randn(ylen, device=engine.device).to(tin) if L["res"] else None
-        sc, bi = torch.ones(d.n, device=engine.device), torch.zeros(d.n, device=engine.device)
+        sc, bi = torch.ones(g * d.n, device=engine.device), torch.zeros(g * d.n, device=engine.device)
         for _ in range(2):
             engine.conv_gemm(d, dtype, x, w, sc, bi, res, y)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -112,7 +113,7 @@ def run(engine, layers, dtype, iters, title):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
-        fl = 2.0 * m * d.n * k
+        fl = 2.0 * m * d.n * k * g
         by = (L["in_elems"] + L["out_elems"] * (2 if L["res"] else 1) + d.n * k) * es
         print(f"{L['name']:38s} x{L['count']:<2d} M={m:<7d} N={d.n:<5d} K={k:<5d} {ms*1e3:9.1f} us {fl/ms/1e9:8.1f} TF/s "
               f"{by/ms/1e6:8.1f} GB/s  blocks={((m+127)//128)*(d.n//(128 if d.n%128==0 else 64))}")
