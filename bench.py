@@ -16,6 +16,7 @@ max |dprob| (plain bf16 does not meet the 1e-4 gate and is never the headline).
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -69,6 +70,19 @@ def usable_cores() -> int:
         except (OSError, ValueError, IndexError):
             pass
     return max(1, min(n, 64))
+
+
+def pmc_traffic(mode, clips):
+    """HBM bytes per conv_gemm launch from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py): the counters
+    cannot be read from inside this process, so the figure comes from profiles/ when it matches this configuration."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{mode}.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("clips_per_gpu") == clips:
+            return d["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def parse():
@@ -223,12 +237,14 @@ def main():
         dt, kern_ms, launches = timed(pipe, frames, wav, n_total, steps, warmup, device, profile=True)
         flops_gemm = GFLOP_CLIP_GEMM * 1e9 * args.clips * steps  # algorithmic FLOPs this rank pushed through conv_gemm
         ach = flops_gemm / (kern_ms * 1e-3) / 1e12 if kern_ms else None
+        traffic, traffic_src = pmc_traffic(name, args.clips)
         res = {
             "clips_per_s": n_total * steps / dt,
             "ms_per_step": dt / steps * 1e3,
             "roofline": {
                 "bound": "mfma", "kernel": KERNEL[name], "achieved": ach, "peak": PEAK_TFLOPS[name], "unit": "TFLOP/s",
-                "frac": ach / PEAK_TFLOPS[name] if ach else None, "traffic": None,
+                "frac": ach / PEAK_TFLOPS[name] if ach else None, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                "traffic_source": traffic_src,
                 "mfma_products_per_algorithmic_product": MFMA_PASSES[name],
                 "frac_of_peak_executed": ach * MFMA_PASSES[name] / PEAK_TFLOPS[name] if ach else None,
                 "launches_per_step": launches / steps if steps else 0,

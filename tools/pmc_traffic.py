@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, MI355X_MICROARCH.md 'HBM' section) into
+HBM bytes per launch of the dominant kernel.
+
+    python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE [--out profiles/r01_traffic_x3.json]
+
+Corrections applied exactly as the guide prescribes for gfx950: counter unit = KiB; FETCH_SIZE reports 1/2 of the bytes of
+a wide (16 B/lane) coalesced stream (global_load and buffer_load...lds alike) -> doubled; WRITE_SIZE is exact for
+16-B-per-lane streaming stores.
+"""
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def per_kernel(dirname, counter):
+    f = glob.glob(f"{dirname}/**/*counter_collection.csv", recursive=True)[0]
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0].replace("void ", "")
+        a = acc.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+        a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+    return acc
+
+
+def main():
+    fetch_dir, write_dir = sys.argv[1], sys.argv[2]
+    out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
+    fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    rows = []
+    for name in fe:
+        n, kib, secs = fe[name]
+        wn, wkib, _ = wr.get(name, [0, 0.0, 0.0])
+        rd = 2.0 * kib * 1024.0          # gfx950: FETCH_SIZE counts 64 B per 128-B request
+        wb = wkib * 1024.0
+        rows.append((rd + wb, name, n, rd, wb, secs))
+    rows.sort(reverse=True)
+    print(f"{'kernel':70s} {'launches':>8s} {'read GB':>9s} {'write GB':>9s} {'B/launch':>12s} {'TB/s':>6s}")
+    for tot, name, n, rd, wb, secs in rows[:12]:
+        print(f"{name[-70:]:70s} {n:8d} {rd/1e9:9.2f} {wb/1e9:9.2f} {tot/n:12.0f} {tot/secs/1e12 if secs else 0:6.2f}")
+    gem = [r for r in rows if "conv_gemm_kernel" in r[1]]
+    tot = sum(r[0] for r in gem); n = sum(r[2] for r in gem); secs = sum(r[5] for r in gem)
+    res = {"kernel": "conv_gemm_kernel (all instantiations)", "launches": n, "hbm_bytes_per_launch": tot / n,
+           "read_bytes_per_launch": sum(r[3] for r in gem) / n, "write_bytes_per_launch": sum(r[4] for r in gem) / n,
+           "hbm_tb_per_s_during_kernel": tot / secs / 1e12,
+           "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), KiB units, WRITE_SIZE as is"}
+    print(json.dumps(res))
+    if out:
+        json.dump(res, open(out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
