@@ -186,26 +186,33 @@ struct Net {
         const Tensor* t = T(name);
         return t ? t->f32 : nullptr;
     }
-    // contraction with weights `wname`; in_bf16/out_bf16 choose the kernel instantiation
+    // contraction with weights `wname`; akind / okind = storage of the activations read / written
+    // (0 = f32, 1 = bf16, 2 = sp32 pairs), which selects the kernel instantiation (avcer_conv_gemm dtype)
     void gemm(avcer_conv_desc d, const std::string& wname, const float* scale, const float* bias, const void* x,
-              const void* res, void* y, bool in_bf16, bool out_bf16) {
+              const void* res, void* y, int akind, int okind) {
         if (err != AVCER_OK) return;
         const Tensor* w = T(wname);
         if (!w) return;
-        int dtype;
-        const void* wp;
-        if (!in_bf16) {
-            if (out_bf16) { err = set_err(ctx, AVCER_EINVAL, "gemm %s: f32 in / bf16 out unsupported", wname.c_str()); return; }
+        int dtype = -1;
+        const void* wp = nullptr;
+        if (akind == 0 && okind == 0) {
             dtype = 0;
             wp = w->f32;
             if (x3 && w->x3) {
                 dtype = 3;
                 wp = w->x3;
             }
-        } else {
-            dtype = out_bf16 ? 1 : 2;
+        } else if (akind == 1 && okind <= 1) {
+            dtype = okind == 1 ? 1 : 2;
             wp = w->bf16;
-            if (!wp) { err = set_err(ctx, AVCER_ESTATE, "gemm %s: bf16 weights not prepared", wname.c_str()); return; }
+        } else if (x3 && ((akind == 0 && okind == 2) || akind == 2) && okind != 1) {
+            dtype = akind == 0 ? 4 : (okind == 2 ? 5 : 6);
+            wp = w->x3;
+        }
+        if (dtype < 0 || !wp) {
+            err = set_err(ctx, AVCER_ESTATE, "gemm %s: storage kinds %d -> %d unsupported or weights not prepared",
+                          wname.c_str(), akind, okind);
+            return;
         }
         const long K = (long)d.kh * d.kw * d.cin;
         if ((long)w->numel != (long)d.n * K * (d.groups > 1 ? d.groups : 1)) {
@@ -331,6 +338,7 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int bf = mode == AVCER_MODE_BF16;
+    const int act = bf ? 1 : (mode == AVCER_MODE_BF16X3 ? 2 : 0);  // activation storage: f32 / bf16 / sp32 pairs
     if (bf) TRY(ensure_all_bf16(ctx, ctx->stat, st));
     if (mode == AVCER_MODE_BF16X3) TRY(ensure_all_x3(ctx, ctx->stat, st));
     const size_t es = bf ? 2 : 4;
@@ -361,11 +369,11 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
             d.stride_h = 2; d.stride_w = 2; d.dil_h = d.dil_w = 1;
             d.x_stride_b = 230L * 230 * 4; d.x_stride_h = 230 * 4; d.x_stride_w = 4;
             d.n = 64; d.y_ld = 64; d.r_ld = 64; d.act = 1;
-            net.gemm(d, "stem.w", net.F("stem.s"), net.F("stem.b"), P, nullptr, buf[0], bf, bf);
+            net.gemm(d, "stem.w", net.F("stem.s"), net.F("stem.b"), P, nullptr, buf[0], bf, act);  // P is f32 unless bf16
         }
         net.tap("pre", P, (size_t)nb * 230 * 230 * 4 * es);
         net.tap("stem_conv", buf[0], (size_t)nb * 112 * 112 * 64 * es);
-        net.chk(k_maxpool3s2(ctx, buf[0], buf[1], nb, 112, 112, 64, 55, 55, bf, st));
+        net.chk(k_maxpool3s2(ctx, buf[0], buf[1], nb, 112, 112, 64, 55, 55, act, st));
         net.tap("stem", buf[1], (size_t)nb * 55 * 55 * 64 * es);
         void* X = buf[1];
         void* T1 = buf[2];
@@ -380,17 +388,17 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
                 const std::string p = "l" + std::to_string(li + 1) + "." + std::to_string(b) + ".";
                 const int oh = (h - 1) / stride + 1;
                 net.gemm(conv2d_desc(nb, h, h, cin, 1, 1, stride, 0, planes, 1), p + "c1.w", net.F(p + "c1.s"),
-                         net.F(p + "c1.b"), X, nullptr, T1, bf, bf);
+                         net.F(p + "c1.b"), X, nullptr, T1, act, act);
                 net.gemm(conv2d_desc(nb, oh, oh, planes, 3, 3, 1, 1, planes, 1), p + "c2.w", net.F(p + "c2.s"),
-                         net.F(p + "c2.b"), T1, nullptr, T2, bf, bf);
+                         net.F(p + "c2.b"), T1, nullptr, T2, act, act);
                 const void* identity = X;
                 if (b == 0) {
                     net.gemm(conv2d_desc(nb, h, h, cin, 1, 1, stride, 0, planes * 4, 0), p + "ds.w", net.F(p + "ds.s"),
-                             net.F(p + "ds.b"), X, nullptr, ID, bf, bf);
+                             net.F(p + "ds.b"), X, nullptr, ID, act, act);
                     identity = ID;
                 }
                 net.gemm(conv2d_desc(nb, oh, oh, planes, 1, 1, 1, 0, planes * 4, 1), p + "c3.w", net.F(p + "c3.s"),
-                         net.F(p + "c3.b"), T2, identity, OUT, bf, bf);
+                         net.F(p + "c3.b"), T2, identity, OUT, act, act);
                 std::swap(X, OUT);
                 h = oh;
                 cin = planes * 4;
@@ -403,10 +411,10 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
             }
             net.tap(("layer" + std::to_string(li + 1)).c_str(), X, (size_t)nb * h * h * cin * es);
         }
-        net.chk(k_avgpool_hw(ctx, X, pooled, nb, h * h, 2048, bf, st));
+        net.chk(k_avgpool_hw(ctx, X, pooled, nb, h * h, 2048, act, st));
         net.tap("avgpool", pooled, (size_t)nb * 2048 * 4);
         float* fo = feats ? feats + (size_t)s0 * 512 : feat_ws;
-        net.gemm(linear_desc(nb, 2048, 512, 0), "fc1.w", nullptr, net.F("fc1.b"), pooled, nullptr, fo, false, false);
+        net.gemm(linear_desc(nb, 2048, 512, 0), "fc1.w", nullptr, net.F("fc1.b"), pooled, nullptr, fo, 0, 0);
         if (logits || probs)
             net.chk(k_small_linear(ctx, fo, net.F("fc2.w"), net.F("fc2.b"), logits ? logits + (size_t)s0 * 7 : nullptr,
                                    probs ? probs + (size_t)s0 * 7 : nullptr, nb, 512, 7, 1, st));
@@ -468,19 +476,19 @@ extern "C" int avcer_dynamic_forward(avcer_ctx* ctx, const float* windows, int n
     float* c2 = (float*)ar.get((size_t)n * H2 * 4);
     if (!c2) return set_err(ctx, AVCER_ENOMEM, "dynamic workspace arithmetic");
     Net net{ctx, ctx->dyn, 0, st};
-    net.gemm(linear_desc((long)n * T, I, 4 * H1, 0), "lstm1.wih.w", nullptr, net.F("lstm1.b"), windows, nullptr, xp1, false, false);
+    net.gemm(linear_desc((long)n * T, I, 4 * H1, 0), "lstm1.wih.w", nullptr, net.F("lstm1.b"), windows, nullptr, xp1, 0, 0);
     for (int t = 0; t < T; ++t) {
         if (t > 0) {
             avcer_conv_desc d = linear_desc(n, H1, 4 * H1, 0);
             d.x_stride_b = (int64_t)T * H1;  // rows of h_{t-1} inside the [n, T, H1] sequence buffer
-            net.gemm(d, "lstm1.whh.w", nullptr, nullptr, h1 + (size_t)(t - 1) * H1, nullptr, hp, false, false);
+            net.gemm(d, "lstm1.whh.w", nullptr, nullptr, h1 + (size_t)(t - 1) * H1, nullptr, hp, 0, 0);
         }
         net.chk(k_lstm_cell(ctx, xp1 + (size_t)t * 4 * H1, (int64_t)T * 4 * H1, hp, c1, h1 + (size_t)t * H1,
                             (int64_t)T * H1, n, H1, t == 0, st));
     }
-    net.gemm(linear_desc((long)n * T, H1, 4 * H2, 0), "lstm2.wih.w", nullptr, net.F("lstm2.b"), h1, nullptr, xp2, false, false);
+    net.gemm(linear_desc((long)n * T, H1, 4 * H2, 0), "lstm2.wih.w", nullptr, net.F("lstm2.b"), h1, nullptr, xp2, 0, 0);
     for (int t = 0; t < T; ++t) {
-        if (t > 0) net.gemm(linear_desc(n, H2, 4 * H2, 0), "lstm2.whh.w", nullptr, nullptr, h2, nullptr, hp, false, false);
+        if (t > 0) net.gemm(linear_desc(n, H2, 4 * H2, 0), "lstm2.whh.w", nullptr, nullptr, h2, nullptr, hp, 0, 0);
         net.chk(k_lstm_cell(ctx, xp2 + (size_t)t * 4 * H2, (int64_t)T * 4 * H2, hp, c2, h2, H2, n, H2, t == 0, st));
     }
     net.chk(k_small_linear(ctx, h2, net.F("fc.w"), net.F("fc.b"), logits, nullptr, n, H2, 7, 0, st));
@@ -490,8 +498,8 @@ extern "C" int avcer_dynamic_forward(avcer_ctx* ctx, const float* windows, int n
 // ------------------------------------------------------------------------------------------------ audio model
 // ref: architectures/audio_8_cl.py:131-190; transformers 4.36.2 Wav2Vec2Model with feat_extract_norm="layer",
 // do_stable_layer_norm=True (third party); architectures/attention_layers.py:221-267.
-// Residual streams stay f32 in both modes; in bf16 mode only MFMA operands (and the wide conv-extractor
-// activations) are bf16.
+// Residual streams stay f32 in every mode; MFMA operand tensors (LN outputs, attention context, GELU'd FFN hidden,
+// conv-extractor activations) are f32 / bf16 / sp32 pairs according to the mode.
 extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int t, int normalize, int mode,
                                    float* logits, avcer_stream_t stream) {
     if (!ctx) return AVCER_EINVAL;
@@ -514,6 +522,8 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int bf = mode == AVCER_MODE_BF16;
+    const int act = bf ? 1 : (mode == AVCER_MODE_BF16X3 ? 2 : 0);  // storage of MFMA operand tensors: f32 / bf16 / sp32
+    const int plain = bf ? 1 : 0;                                   // storage of GEMM outputs read by LN / attention
     if (bf) TRY(ensure_all_bf16(ctx, ctx->aud, st));
     if (mode == AVCER_MODE_BF16X3) TRY(ensure_all_x3(ctx, ctx->aud, st));
     const size_t es = bf ? 2 : 4;
@@ -521,7 +531,7 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
     const int NB = std::min(n, 128);
     const size_t rows = (size_t)NB * S;
     const size_t e0 = (size_t)NB * len[1] * C * es, e1 = (size_t)NB * len[2] * C * es;
-    const size_t total = (size_t)NB * t * 4 + e0 + 2 * e1 + rows * E * 4 * 4 + rows * E * 2 * 2 + rows * 3 * E * es +
+    const size_t total = (size_t)NB * t * 4 + e0 + 2 * e1 + rows * E * 4 * 4 + rows * E * es * 2 + rows * 3 * E * es +
                          rows * FF * es + rows * E * es + (size_t)NB * (L1 + L2 + L3 + 1) * E * 4 + 32 * 256;
     void* wsp = nullptr;
     TRY(ws_reserve(ctx, 2, total, &wsp));
@@ -534,8 +544,8 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
     float* Of = (float*)ar.get(rows * E * 4);
     float* Xf = (float*)ar.get(rows * E * 4);
     float* Yf = (float*)ar.get(rows * E * 4);
-    bf16_t* Xb = (bf16_t*)ar.get(rows * E * 2);
-    bf16_t* Yb = (bf16_t*)ar.get(rows * E * 2);
+    void* Xb = ar.get(rows * E * es);  // operand-typed copies (bf16 or sp32) of f32 tensors
+    void* Yb = ar.get(rows * E * es);
     void* QKV = ar.get(rows * 3 * E * es);
     void* FFB = ar.get(rows * FF * es);
     void* ATT = ar.get(rows * E * es);
@@ -547,10 +557,10 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
     const int ncls = ctx->aud_classes;
 
     Net net{ctx, ctx->aud, bf, st, mode == AVCER_MODE_BF16X3};
-    // LN output helper: activation-typed operand (f32 in parity mode, bf16 in throughput mode)
-    auto ln_act = [&](const void* x, bool x_bf16, const std::string& p, void* y, long r, int c, int act) {
-        net.chk(k_layernorm(ctx, x, nullptr, net.F(p + ".g"), net.F(p + ".b"), bf ? nullptr : y, bf ? y : nullptr, r, c,
-                            1e-5f, act, x_bf16, 0, st));
+    // LN whose output is an MFMA operand: f32 in the f32 mode, else a bf16 / sp32 tensor
+    auto ln_act = [&](const void* x, int x_kind, const std::string& p, void* y, long r, int c, int fn) {
+        net.chk(k_layernorm(ctx, x, nullptr, net.F(p + ".g"), net.F(p + ".b"), act ? nullptr : y, act ? y : nullptr, r, c,
+                            1e-5f, fn, x_kind, act, st));
     };
     for (int s0 = 0; s0 < n; s0 += NB) {
         const int nb = std::min(NB, n - s0);
@@ -562,7 +572,7 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
         }
         // ---- conv feature extractor: 7 x (Conv1d -> LN(512) -> GELU)
         net.chk(k_conv0_ln_gelu(ctx, x0, net.F("fe0.w"), net.F("fe0.cb"), net.F("fe0.ln.g"), net.F("fe0.ln.b"), EA, nb, t,
-                                len[1], bf, st));
+                                len[1], act, st));
         net.tap("norm", x0, (size_t)nb * t * 4);
         net.tap("conv0", EA, (size_t)nb * len[1] * C * es);
         void* cur = EA;
@@ -570,20 +580,23 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
         for (int i = 1; i < 7; ++i) {
             const std::string p = "fe" + std::to_string(i);
             net.gemm(conv1d_desc(nb, len[i], C, ck[i], cs[i], 0, 1, len[i + 1], C, 0), p + ".w", nullptr, net.F(p + ".cb"),
-                     cur, nullptr, TMP, bf, bf);
-            ln_act(TMP, bf, p + ".ln", nxt, (long)nb * len[i + 1], C, 2);
+                     cur, nullptr, TMP, act, plain);
+            ln_act(TMP, plain, p + ".ln", nxt, (long)nb * len[i + 1], C, 2);
             std::swap(cur, nxt);
             if (i == 1) nxt = EA;  // EA (largest) is free once layer 1 has consumed it
         }
         net.tap("extract", cur, (size_t)r * C * es);
         // ---- feature projection: LN(512) -> Linear 512 -> 1024
-        ln_act(cur, bf, "fp.ln", TMP, r, C, 0);
-        net.gemm(linear_desc(r, C, E, 0), "fp.w", nullptr, net.F("fp.b"), TMP, nullptr, Hf, bf, false);
+        ln_act(cur, act, "fp.ln", TMP, r, C, 0);
+        net.gemm(linear_desc(r, C, E, 0), "fp.w", nullptr, net.F("fp.b"), TMP, nullptr, Hf, act, 0);
         net.tap("proj", Hf, (size_t)r * E * 4);
         // ---- positional conv embedding (k=128, groups=16, pad 64, drop last, GELU) added to the stream
         const void* pin = Hf;
-        if (bf) {
-            net.chk(k_f32_to_bf16(ctx, Hf, Xb, (size_t)r * E, st));
+        if (act == 1) {
+            net.chk(k_f32_to_bf16(ctx, Hf, (bf16_t*)Xb, (size_t)r * E, st));
+            pin = Xb;
+        } else if (act == 2) {
+            net.chk(k_split_weights(ctx, Hf, (bf16_t*)Xb, (size_t)r * E, st));  // same sp32 layout as split weights
             pin = Xb;
         }
         {  // 16 groups of 64 channels in ONE launch (grid.y = group)
@@ -592,20 +605,20 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
             d.y_ld = E; d.r_ld = E;
             d.res_after_act = 1;
             d.groups = 16;
-            net.gemm(d, "pos.w", nullptr, net.F("pos.b"), pin, Hf, Of, bf, false);
+            net.gemm(d, "pos.w", nullptr, net.F("pos.b"), pin, Hf, Of, act, 0);
         }
         float* h = Of;
         net.tap("posconv", h, (size_t)r * E * 4);
         // ---- 12 pre-LN encoder layers
         for (int l = 0; l < 12; ++l) {
             const std::string p = "enc" + std::to_string(l);
-            ln_act(h, false, p + ".ln1", TMP, r, E, 0);
-            net.gemm(linear_desc(r, E, 3 * E, 0), p + ".qkv.w", nullptr, net.F(p + ".qkv.b"), TMP, nullptr, QKV, bf, bf);
-            net.chk(k_attention(ctx, QKV, ATT, nb, S, 16, 64, 0.125f, bf, st));
-            net.gemm(linear_desc(r, E, E, 0), p + ".o.w", nullptr, net.F(p + ".o.b"), ATT, h, h, bf, false);
-            ln_act(h, false, p + ".ln2", TMP, r, E, 0);
-            net.gemm(linear_desc(r, E, FF, 2), p + ".ff1.w", nullptr, net.F(p + ".ff1.b"), TMP, nullptr, FFB, bf, bf);
-            net.gemm(linear_desc(r, FF, E, 0), p + ".ff2.w", nullptr, net.F(p + ".ff2.b"), FFB, h, h, bf, false);
+            ln_act(h, 0, p + ".ln1", TMP, r, E, 0);
+            net.gemm(linear_desc(r, E, 3 * E, 0), p + ".qkv.w", nullptr, net.F(p + ".qkv.b"), TMP, nullptr, QKV, act, plain);
+            net.chk(k_attention(ctx, QKV, ATT, nb, S, 16, 64, 0.125f, plain, act, st));
+            net.gemm(linear_desc(r, E, E, 0), p + ".o.w", nullptr, net.F(p + ".o.b"), ATT, h, h, act, 0);
+            ln_act(h, 0, p + ".ln2", TMP, r, E, 0);
+            net.gemm(linear_desc(r, E, FF, 2), p + ".ff1.w", nullptr, net.F(p + ".ff1.b"), TMP, nullptr, FFB, act, act);
+            net.gemm(linear_desc(r, FF, E, 0), p + ".ff2.w", nullptr, net.F(p + ".ff2.b"), FFB, h, h, act, 0);
             net.tap(("layer" + std::to_string(l)).c_str(), h, (size_t)r * E * 4);
         }
         net.chk(k_layernorm(ctx, h, nullptr, net.F("enc.ln.g"), net.F("enc.ln.b"), Xf, nullptr, r, E, 1e-5f, 0, 0, 0, st));
@@ -615,26 +628,27 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
         for (int l = 1; l <= 2; ++l) {
             const std::string p = "tl" + std::to_string(l);
             const int heads = l == 1 ? 32 : 16, dh = E / heads;
-            net.chk(k_add_pe(ctx, xin, net.F("pe"), Yf, bf ? Yb : nullptr, nb, S, E, st));  // x + PE: operand and residual
-            net.gemm(linear_desc(r, E, 3 * E, 0), p + ".qkv.w", nullptr, nullptr, bf ? (void*)Yb : (void*)Yf, nullptr, QKV, bf, bf);
-            net.chk(k_attention(ctx, QKV, ATT, nb, S, heads, dh, 1.0f / sqrtf((float)dh), bf, st));
-            net.gemm(linear_desc(r, E, E, 0), p + ".o.w", nullptr, nullptr, ATT, Yf, Hf, bf, false);
-            net.chk(k_layernorm(ctx, Hf, nullptr, net.F(p + ".ln1.g"), net.F(p + ".ln1.b"), Yf, bf ? Yb : nullptr, r, E, 1e-5f,
-                                0, 0, 0, st));
-            net.gemm(linear_desc(r, E, E, 1), p + ".ff1.w", nullptr, net.F(p + ".ff1.b"), bf ? (void*)Yb : (void*)Yf, nullptr,
-                     FFB, bf, bf);
-            net.gemm(linear_desc(r, E, E, 0), p + ".ff2.w", nullptr, net.F(p + ".ff2.b"), FFB, Yf, Hf, bf, false);
-            net.chk(k_layernorm(ctx, Hf, nullptr, net.F(p + ".ln2.g"), net.F(p + ".ln2.b"), Xf, bf ? Xb : nullptr, r, E, 1e-5f,
-                                0, 0, 0, st));
+            // x + PE is both the projections' operand (typed copy) and the residual (f32)
+            net.chk(k_add_pe(ctx, xin, net.F("pe"), Yf, act ? Yb : nullptr, nb, S, E, act, st));
+            net.gemm(linear_desc(r, E, 3 * E, 0), p + ".qkv.w", nullptr, nullptr, act ? Yb : (void*)Yf, nullptr, QKV, act, plain);
+            net.chk(k_attention(ctx, QKV, ATT, nb, S, heads, dh, 1.0f / sqrtf((float)dh), plain, act, st));
+            net.gemm(linear_desc(r, E, E, 0), p + ".o.w", nullptr, nullptr, ATT, Yf, Hf, act, 0);
+            net.chk(k_layernorm(ctx, Hf, nullptr, net.F(p + ".ln1.g"), net.F(p + ".ln1.b"), Yf, act ? Yb : nullptr, r, E, 1e-5f,
+                                0, 0, act, st));
+            net.gemm(linear_desc(r, E, E, 1), p + ".ff1.w", nullptr, net.F(p + ".ff1.b"), act ? Yb : (void*)Yf, nullptr, FFB,
+                     act, act);
+            net.gemm(linear_desc(r, E, E, 0), p + ".ff2.w", nullptr, net.F(p + ".ff2.b"), FFB, Yf, Hf, act, 0);
+            net.chk(k_layernorm(ctx, Hf, nullptr, net.F(p + ".ln2.g"), net.F(p + ".ln2.b"), Xf, act ? Xb : nullptr, r, E, 1e-5f,
+                                0, 0, act, st));
             xin = Xf;
             net.tap(p.c_str(), Xf, (size_t)r * E * 4);
         }
         // ---- head: Conv1d k5 s3 dil2 + BN -> MaxPool(5) -> ReLU -> Conv1d k3 + BN -> mean -> ReLU -> Linear
         net.gemm(conv1d_desc(nb, S, E, 5, 3, 0, 2, L1, E, 0), "td0.w", net.F("td0.s"), net.F("td0.b"),
-                 bf ? (void*)Xb : (void*)Xf, nullptr, c1o, bf, false);
+                 act ? Xb : (void*)Xf, nullptr, c1o, act, 0);
         net.chk(k_maxpool1d_relu(ctx, c1o, mp, nb, L1, L2, E, 5, st));
         net.gemm(conv1d_desc(nb, L2, E, 3, 1, 0, 1, L3, E, 0), "td4.w", net.F("td4.s"), net.F("td4.b"), mp, nullptr, c2o,
-                 false, false);
+                 0, 0);
         net.tap("td0", c1o, (size_t)nb * L1 * E * 4);
         net.tap("mp", mp, (size_t)nb * L2 * E * 4);
         net.tap("td4", c2o, (size_t)nb * L3 * E * 4);

@@ -93,10 +93,10 @@ int k_wav_normalize(avcer_ctx*, const float* x, float* y, int n, int t, hipStrea
 int k_conv0_ln_gelu(avcer_ctx*, const float* x, const float* w, const float* b, const float* g, const float* beta,
                     void* y, int n, int t_in, int t_out, int bf16, hipStream_t);
 int k_layernorm(avcer_ctx*, const void* x, const void* res, const float* g, const float* b, void* yf, void* yb,
-                int64_t rows, int c, float eps, int act, int in_bf16, int unused, hipStream_t);
-int k_add_pe(avcer_ctx*, const float* x, const float* pe, float* yf, bf16_t* yb, int n, int s, int c, hipStream_t);
-int k_attention(avcer_ctx*, const void* qkv, void* out, int n, int s, int heads, int d, float scale, int bf16,
-                hipStream_t);
+                int64_t rows, int c, float eps, int act, int in_kind, int yb_kind, hipStream_t);
+int k_add_pe(avcer_ctx*, const float* x, const float* pe, float* yf, void* yb, int n, int s, int c, int yb_kind, hipStream_t);
+int k_attention(avcer_ctx*, const void* qkv, void* out, int n, int s, int heads, int d, float scale, int in_kind,
+                int out_kind, hipStream_t);
 int k_maxpool1d_relu(avcer_ctx*, const float* x, float* y, int n, int t_in, int t_out, int c, int k, hipStream_t);
 int k_mean_time_relu(avcer_ctx*, const float* x, float* y, int n, int t, int c, hipStream_t);
 int k_f32_to_bf16(avcer_ctx*, const float* x, bf16_t* y, size_t n, hipStream_t);

@@ -89,21 +89,37 @@ __device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(floa
 // accumulators in an f32 [128][BN] image (16-byte chunks XOR-swizzled with row&7 against write conflicts), then the
 // 256 threads walk the image row-major, 8 consecutive channels per thread: residual add, activation, one 16-byte
 // (bf16) or two 16-byte (f32) stores.  ACT: 0 none, 1 relu, 2 gelu (compile-time: erff only in the GELU variant).
-template <typename OutT, int ACT>
+// OUT: 0 = f32, 1 = bf16, 2 = split-bf16 pairs ("sp32": per aligned group of 32 channels, 32 hi bf16 then 32 lo bf16,
+// value = hi + lo; 4 bytes per element like f32, directly consumable as MODE 3 A operand).  The residual has the
+// same storage type as the output.
+__device__ __forceinline__ long sp32_byte(long e) { return ((e & ~31L) << 2) + ((e & 31L) << 1); }
+
+template <int OUT, int ACT>
 __device__ __forceinline__ void finish8(const GemmParams& p, long m, int n0, const float4 a, const float4 b) {
     float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (p.R) {
-        const char* rp = p.R + (m * p.ldR + p.roff + n0) * (long)sizeof(OutT);
-        if constexpr (sizeof(OutT) == 4) {
+        const long e = m * p.ldR + p.roff + n0;
+        if constexpr (OUT == 0) {
+            const char* rp = p.R + e * 4;
             const float4 t0 = *reinterpret_cast<const float4*>(rp);
             const float4 t1 = *reinterpret_cast<const float4*>(rp + 16);
             r[0] = t0.x; r[1] = t0.y; r[2] = t0.z; r[3] = t0.w; r[4] = t1.x; r[5] = t1.y; r[6] = t1.z; r[7] = t1.w;
-        } else {
-            const uint4 t = *reinterpret_cast<const uint4*>(rp);
+        } else if constexpr (OUT == 1) {
+            const uint4 t = *reinterpret_cast<const uint4*>(p.R + e * 2);
             const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) { r[2 * j] = bf2f((bf16_t)(w[j] & 0xffff)); r[2 * j + 1] = bf2f((bf16_t)(w[j] >> 16)); }
+        } else {
+            const char* rp = p.R + sp32_byte(e);
+            const uint4 th = *reinterpret_cast<const uint4*>(rp);
+            const uint4 tl = *reinterpret_cast<const uint4*>(rp + 64);
+            const uint32_t wh[4] = {th.x, th.y, th.z, th.w}, wl[4] = {tl.x, tl.y, tl.z, tl.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r[2 * j] = bf2f((bf16_t)(wh[j] & 0xffff)) + bf2f((bf16_t)(wl[j] & 0xffff));
+                r[2 * j + 1] = bf2f((bf16_t)(wh[j] >> 16)) + bf2f((bf16_t)(wl[j] >> 16));
+            }
         }
     }
 #pragma unroll
@@ -113,17 +129,29 @@ __device__ __forceinline__ void finish8(const GemmParams& p, long m, int n0, con
         if constexpr (ACT == 2) x = gelu_erf(x);
         v[j] = p.res_after ? x + r[j] : x;
     }
-    char* yp = p.Y + (m * p.ldY + p.yoff + n0) * (long)sizeof(OutT);
-    if constexpr (sizeof(OutT) == 4) {
+    const long e = m * p.ldY + p.yoff + n0;
+    if constexpr (OUT == 0) {
+        char* yp = p.Y + e * 4;
         *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(yp + 16) = make_float4(v[4], v[5], v[6], v[7]);
-    } else {
+    } else if constexpr (OUT == 1) {
         uint4 t;
         t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
         t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
         t.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
         t.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-        *reinterpret_cast<uint4*>(yp) = t;
+        *reinterpret_cast<uint4*>(p.Y + e * 2) = t;
+    } else {
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16_t h0 = f2bf(v[2 * j]), h1 = f2bf(v[2 * j + 1]);
+            h[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            l[j] = (uint32_t)f2bf(v[2 * j] - bf2f(h0)) | ((uint32_t)f2bf(v[2 * j + 1] - bf2f(h1)) << 16);
+        }
+        char* yp = p.Y + sp32_byte(e);
+        *reinterpret_cast<uint4*>(yp) = make_uint4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<uint4*>(yp + 64) = make_uint4(l[0], l[1], l[2], l[3]);
     }
 }
 
@@ -169,7 +197,7 @@ __device__ __forceinline__ void stage_acc(const GemmParams& p, char* smem, AccT 
     }
 }
 
-template <typename OutT, int BN, int ACT>
+template <int OUT, int BN, int ACT>
 __device__ __forceinline__ void drain_stage(const GemmParams& p, const char* smem, int m_base, int n_base, int tid) {
     constexpr int TPR = BN / 8;          // threads per row (8 channels each)
     constexpr int RPP = 256 / TPR;       // rows per pass
@@ -181,7 +209,7 @@ __device__ __forceinline__ void drain_stage(const GemmParams& p, const char* sme
         if (m < p.M) {
             const float4 a = *reinterpret_cast<const float4*>(smem + stage_off<BN>(row, 2 * c8));
             const float4 b = *reinterpret_cast<const float4*>(smem + stage_off<BN>(row, 2 * c8 + 1));
-            finish8<OutT, ACT>(p, m, n_base + c8 * 8, a, b);
+            finish8<OUT, ACT>(p, m, n_base + c8 * 8, a, b);
         }
     }
 }
@@ -201,7 +229,9 @@ __device__ __forceinline__ void split8(const float4 x, const float4 y, bf16x8_t&
 // MODE 2 ("bf16x3"): f32 activations split on the fly into bf16 hi+lo, weights pre-split (per 32-element K group:
 // 32 hi then 32 lo bf16), a.w ~= ah.wh + ah.wl + al.wh on the bf16 MFMA with f32 accumulation -- f32-grade
 // results (relative error ~2^-17 per product) at a third of the bf16 MFMA rate instead of a sixteenth.
-template <int MODE, typename OutT, int BN>
+// MODE 3: as MODE 2 but the activations are ALREADY stored as sp32 pairs (written by a producer's epilogue), so the
+// A fragments are read like the weights and the main loop has no conversion arithmetic at all.
+template <int MODE, int OUT, int BN>
 __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
     constexpr bool IS_F32 = MODE == 0;
     constexpr int ES = MODE == 1 ? 2 : 4;
@@ -295,7 +325,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
 
     constexpr int NFN = IS_F32 ? WN / 32 : WN / 16;
     constexpr int NFM = IS_F32 ? 2 : 4;
-    static_assert(MODE != 2 || sizeof(OutT) == 4, "split-bf16 mode writes f32");
+    static_assert(MODE < 2 || OUT != 1, "split-bf16 modes write f32 or sp32");
     using acc_t = typename std::conditional<IS_F32, f32x16_t, f32x4_t>::type;
     acc_t acc[NFN][NFM];
 #pragma unroll
@@ -334,12 +364,17 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
                         acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[fn].w, af[fm].w, acc[fn][fm], 0, 0, 0);
                     }
             }
-        } else if constexpr (MODE == 2) {
+        } else if constexpr (MODE == 2 || MODE == 3) {
             const int g = lane >> 4;
             bf16x8_t ahi[NFM], alo[NFM];
 #pragma unroll
             for (int fm = 0; fm < NFM; ++fm) {
                 const int row = wm * 64 + fm * 16 + (lane & 15);
+                if constexpr (MODE == 3) {
+                    ahi[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, g));
+                    alo[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, 4 + g));
+                    continue;
+                }
                 const float4 x = *reinterpret_cast<const float4*>(sa + swz(row, 2 * g));
                 const float4 y = *reinterpret_cast<const float4*>(sa + swz(row, 2 * g + 1));
                 if (p.ablate == 4) {  // timing only: reinterpret instead of splitting
@@ -387,23 +422,23 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
     // epilogue through LDS (the tile buffers are free: the loop ended on a barrier)
     stage_acc<MODE, BN>(p, smem, acc, n_base, wm, wn, lane);
     __syncthreads();
-    if (p.act == 2) drain_stage<OutT, BN, 2>(p, smem, m_base, n_base, tid);
-    else if (p.act == 1) drain_stage<OutT, BN, 1>(p, smem, m_base, n_base, tid);
-    else drain_stage<OutT, BN, 0>(p, smem, m_base, n_base, tid);
+    if (p.act == 2) drain_stage<OUT, BN, 2>(p, smem, m_base, n_base, tid);
+    else if (p.act == 1) drain_stage<OUT, BN, 1>(p, smem, m_base, n_base, tid);
+    else drain_stage<OUT, BN, 0>(p, smem, m_base, n_base, tid);
 }
 
-template <int MODE, typename OutT>
+template <int MODE, int OUT>
 void launch_t(const GemmParams& p0, hipStream_t st) {
     GemmParams p = p0;
     const int ntm = (p.M + BM - 1) / BM;
     if (p.N % 128 == 0) {
         p.ntn = p.N / 128;
         p.nwg = ntm * p.ntn;
-        conv_gemm_kernel<MODE, OutT, 128><<<dim3(p.nwg, p.groups), dim3(256), 0, st>>>(p);
+        conv_gemm_kernel<MODE, OUT, 128><<<dim3(p.nwg, p.groups), dim3(256), 0, st>>>(p);
     } else {
         p.ntn = p.N / 64;
         p.nwg = ntm * p.ntn;
-        conv_gemm_kernel<MODE, OutT, 64><<<dim3(p.nwg, p.groups), dim3(256), 0, st>>>(p);
+        conv_gemm_kernel<MODE, OUT, 64><<<dim3(p.nwg, p.groups), dim3(256), 0, st>>>(p);
     }
 }
 
@@ -411,8 +446,9 @@ void launch_t(const GemmParams& p0, hipStream_t st) {
 
 int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const void* x, const void* w,
                      const float* scale, const float* bias, const void* residual, void* y, hipStream_t st) {
-    if (dtype < 0 || dtype > 3) return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d", dtype);
-    const int es = (dtype == 0 || dtype == 3) ? 4 : 2;
+    if (dtype < 0 || dtype > 6) return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d", dtype);
+    const int es = (dtype == 1 || dtype == 2) ? 2 : 4;
+    const bool a_split = dtype == 5 || dtype == 6, o_split = dtype == 4 || dtype == 5;
     const int vec = 16 / es;
     const int bk = ROWB / es;  // 32 elements (f32, split-bf16) or 64 (bf16) per K-step
     const long M = (long)d.batch * d.out_h * d.out_w;
@@ -424,9 +460,11 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: cin/coff/strides must be multiples of %d", vec);
     if (d.x_stride_w % vec && !(d.kw == 1 && d.pad_w == 0 && (d.stride_w * d.x_stride_w) % vec == 0))
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: x_stride_w=%ld breaks 16-byte alignment", (long)d.x_stride_w);
-    const int ovec = 16 / ((dtype == 1) ? 2 : 4);  // 16-byte output / residual vectors
+    const int ovec = o_split ? 32 : 16 / ((dtype == 1) ? 2 : 4);  // 16-byte vectors / whole sp32 groups
     if (d.y_ld % ovec || d.y_coff % ovec || (residual && (d.r_ld % ovec || d.r_coff % ovec)))
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: output/residual leading dims and offsets must be multiples of %d", ovec);
+    if (a_split && (d.cin % 32 || d.x_coff % 32 || d.x_stride_b % 32 || d.x_stride_h % 32 || d.x_stride_w % 32))
+        return set_err(ctx, AVCER_EINVAL, "conv_gemm: sp32 activations need cin/coff/strides in whole groups of 32");
     if (!x || !w || !y) return set_err(ctx, AVCER_EINVAL, "conv_gemm: null pointer");
     GemmParams p;
     p.X = (const char*)x; p.W = (const char*)w; p.scale = scale; p.bias = bias; p.R = (const char*)residual;
@@ -461,10 +499,15 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
         ev1 = ctx->prof_ev[ctx->prof_used++];
         (void)hipEventRecord(ev0, st);
     }
-    if (dtype == 0) launch_t<0, float>(p, st);
-    else if (dtype == 1) launch_t<1, bf16_t>(p, st);
-    else if (dtype == 2) launch_t<1, float>(p, st);
-    else launch_t<2, float>(p, st);
+    switch (dtype) {
+        case 0: launch_t<0, 0>(p, st); break;  // f32
+        case 1: launch_t<1, 1>(p, st); break;  // bf16 -> bf16
+        case 2: launch_t<1, 0>(p, st); break;  // bf16 -> f32
+        case 3: launch_t<2, 0>(p, st); break;  // f32 (split on the fly) -> f32
+        case 4: launch_t<2, 2>(p, st); break;  // f32 (split on the fly) -> sp32
+        case 5: launch_t<3, 2>(p, st); break;  // sp32 -> sp32
+        default: launch_t<3, 0>(p, st); break; // sp32 -> f32
+    }
     if (ev1) (void)hipEventRecord(ev1, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "conv_gemm launch: %s", hipGetErrorString(e));

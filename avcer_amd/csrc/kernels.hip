@@ -50,6 +50,43 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, long i, const
     *reinterpret_cast<uint2*>(p + i) = t;
 }
 
+// sp32 storage (AVCER_MODE_BF16X3 activations): per aligned group of 32 channels, 32 bf16 hi then 32 bf16 lo,
+// x = hi + lo.  4 bytes per element; element index e lives at byte ((e & ~31) << 2) + ((e & 31) << 1) (+64 for lo).
+struct sp32_t { uint32_t raw; };
+__device__ __forceinline__ long sp32_byte(long e) { return ((e & ~31L) << 2) + ((e & 31L) << 1); }
+template <> __device__ __forceinline__ float ldf<sp32_t>(const sp32_t* p, long i) {
+    const char* b = reinterpret_cast<const char*>(p) + sp32_byte(i);
+    return bf2f(*reinterpret_cast<const bf16_t*>(b)) + bf2f(*reinterpret_cast<const bf16_t*>(b + 64));
+}
+template <> __device__ __forceinline__ void stf<sp32_t>(sp32_t* p, long i, float v) {
+    char* b = reinterpret_cast<char*>(p) + sp32_byte(i);
+    const bf16_t h = f2bf(v);
+    *reinterpret_cast<bf16_t*>(b) = h;
+    *reinterpret_cast<bf16_t*>(b + 64) = f2bf(v - bf2f(h));
+}
+template <> __device__ __forceinline__ void ld4<sp32_t>(const sp32_t* p, long i, float* v) {
+    const char* b = reinterpret_cast<const char*>(p) + sp32_byte(i);
+    const uint2 h = *reinterpret_cast<const uint2*>(b);
+    const uint2 l = *reinterpret_cast<const uint2*>(b + 64);
+    v[0] = bf2f((bf16_t)(h.x & 0xffff)) + bf2f((bf16_t)(l.x & 0xffff));
+    v[1] = bf2f((bf16_t)(h.x >> 16)) + bf2f((bf16_t)(l.x >> 16));
+    v[2] = bf2f((bf16_t)(h.y & 0xffff)) + bf2f((bf16_t)(l.y & 0xffff));
+    v[3] = bf2f((bf16_t)(h.y >> 16)) + bf2f((bf16_t)(l.y >> 16));
+}
+template <> __device__ __forceinline__ void st4<sp32_t>(sp32_t* p, long i, const float* v) {
+    char* b = reinterpret_cast<char*>(p) + sp32_byte(i);
+    bf16_t h[4];
+    uint2 hh, ll;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = f2bf(v[j]);
+    hh.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+    hh.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+    ll.x = (uint32_t)f2bf(v[0] - bf2f(h[0])) | ((uint32_t)f2bf(v[1] - bf2f(h[1])) << 16);
+    ll.y = (uint32_t)f2bf(v[2] - bf2f(h[2])) | ((uint32_t)f2bf(v[3] - bf2f(h[3])) << 16);
+    *reinterpret_cast<uint2*>(b) = hh;
+    *reinterpret_cast<uint2*>(b + 64) = ll;
+}
+
 // ------------------------------------------------------------------------------------------------ preprocess
 // data/utils.py:19-39.  u8 [n,in_h,in_w,3] RGB -> zero-bordered [n,230,230,4] (BGR - mean, 4th channel 0).
 // The border materialises Conv2dSame's asymmetric padding (video.py:68-80: 2 before, 3 after) plus one extra
@@ -324,10 +361,10 @@ __global__ void __launch_bounds__(256) conv0_ln_gelu_kernel(const float* __restr
 
 // LayerNorm over the last dimension (c in {512, 1024}), optional residual add in front, optional GELU behind,
 // dual output (f32 residual-stream copy and/or bf16 GEMM-operand copy).  One wave per row.
-template <typename TI, int C>
+template <typename TI, typename OB, int C>
 __global__ void __launch_bounds__(256) layernorm_kernel(const TI* __restrict__ x, const TI* __restrict__ res,
                                                       const float* __restrict__ g, const float* __restrict__ b,
-                                                      float* __restrict__ yf, bf16_t* __restrict__ yb, long rows,
+                                                      float* __restrict__ yf, OB* __restrict__ yb, long rows,
                                                       float eps, int act) {
     constexpr int PER = C / 64;  // 8 or 16 consecutive elements per lane
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -368,13 +405,14 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const TI* __restrict__ x
 #pragma unroll
     for (int i = 0; i < PER; i += 4) {
         if (yf) st4<float>(yf, base + i, v + i);
-        if (yb) st4<bf16_t>(yb, base + i, v + i);
+        if (yb) st4<OB>(yb, base + i, v + i);
     }
 }
 
 // attention_layers.py:206-211,249-254: x + pe[:, :S]; writes f32 (residual) and/or bf16 (GEMM operand).
+template <typename OB>
 __global__ void add_pe_kernel(const float* __restrict__ x, const float* __restrict__ pe, float* __restrict__ yf,
-                              bf16_t* __restrict__ yb, long total4, int s, int c) {
+                              OB* __restrict__ yb, long total4, int s, int c) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total4) return;
     const long e = idx * 4;
@@ -386,15 +424,15 @@ __global__ void add_pe_kernel(const float* __restrict__ x, const float* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] += p[j];
     if (yf) st4<float>(yf, e, v);
-    if (yb) st4<bf16_t>(yb, e, v);
+    if (yb) st4<OB>(yb, e, v);
 }
 
 // ------------------------------------------------------------------------------------------------ attention
 // softmax(q k^T * scale) v for one (batch, head) per workgroup; S <= 256, d in {32, 64}.
 // wav2vec2 encoder self-attention (16 x 64) and attention_layers.py:10-38 (32 x 32, 16 x 64).
 // K (rows padded by 4 floats: conflict-free b128 row reads) and V live in LDS as f32; each wave owns query rows.
-template <typename T, int D>
-__global__ void __launch_bounds__(256) attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int s, int heads,
+template <typename T, typename TO, int D>
+__global__ void __launch_bounds__(256) attention_kernel(const T* __restrict__ qkv, TO* __restrict__ out, int s, int heads,
                                                       float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int KP = D + 4;
@@ -458,7 +496,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const T* __restrict__ qk
             for (int j = half; j < s; j += 2) o += pw[j] * vs[j * D + c];
             o += __shfl_xor(o, 32, 64);
         }
-        if (lane < D) stf<T>(out, ((long)b * s + qi) * e + h * D + lane, o / den);
+        if (lane < D) stf<TO>(out, ((long)b * s + qi) * e + h * D + lane, o / den);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -637,18 +675,23 @@ int k_preprocess(avcer_ctx* ctx, const uint8_t* frames, int n, int in_h, int in_
     return AVCER_OK;
 }
 
-int k_maxpool3s2(avcer_ctx* ctx, const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int bf16, hipStream_t st) {
+// `kind` of activation storage: 0 = f32, 1 = bf16, 2 = sp32
+int k_maxpool3s2(avcer_ctx* ctx, const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int kind, hipStream_t st) {
     const long total = (long)n * oh * ow * (c / 4);
-    if (bf16) maxpool3s2_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, n, h, w, c, oh, ow);
-    else maxpool3s2_kernel<float><<<cdiv(total, 256), 256, 0, st>>>((const float*)x, (float*)y, n, h, w, c, oh, ow);
+    const int grid = cdiv(total, 256);
+    if (kind == 1) maxpool3s2_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, n, h, w, c, oh, ow);
+    else if (kind == 2) maxpool3s2_kernel<sp32_t><<<grid, 256, 0, st>>>((const sp32_t*)x, (sp32_t*)y, n, h, w, c, oh, ow);
+    else maxpool3s2_kernel<float><<<grid, 256, 0, st>>>((const float*)x, (float*)y, n, h, w, c, oh, ow);
     CHECK_LAUNCH(ctx, "maxpool3s2");
     return AVCER_OK;
 }
 
-int k_avgpool_hw(avcer_ctx* ctx, const void* x, float* y, int n, int hw, int c, int bf16, hipStream_t st) {
+int k_avgpool_hw(avcer_ctx* ctx, const void* x, float* y, int n, int hw, int c, int kind, hipStream_t st) {
     const long total = (long)n * c;
-    if (bf16) avgpool_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>((const bf16_t*)x, y, n, hw, c);
-    else avgpool_kernel<float><<<cdiv(total, 256), 256, 0, st>>>((const float*)x, y, n, hw, c);
+    const int grid = cdiv(total, 256);
+    if (kind == 1) avgpool_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, y, n, hw, c);
+    else if (kind == 2) avgpool_kernel<sp32_t><<<grid, 256, 0, st>>>((const sp32_t*)x, y, n, hw, c);
+    else avgpool_kernel<float><<<grid, 256, 0, st>>>((const float*)x, y, n, hw, c);
     CHECK_LAUNCH(ctx, "avgpool");
     return AVCER_OK;
 }
@@ -675,57 +718,80 @@ int k_wav_normalize(avcer_ctx* ctx, const float* x, float* y, int n, int t, hipS
 }
 
 int k_conv0_ln_gelu(avcer_ctx* ctx, const float* x, const float* w, const float* b, const float* g, const float* beta,
-                    void* y, int n, int t_in, int t_out, int bf16, hipStream_t st) {
+                    void* y, int n, int t_in, int t_out, int kind, hipStream_t st) {
     const int spb = 64;
     dim3 grid(cdiv(t_out, spb), n);
-    if (bf16) conv0_ln_gelu_kernel<bf16_t><<<grid, 256, 0, st>>>(x, w, b, g, beta, (bf16_t*)y, t_in, t_out, spb);
+    if (kind == 1) conv0_ln_gelu_kernel<bf16_t><<<grid, 256, 0, st>>>(x, w, b, g, beta, (bf16_t*)y, t_in, t_out, spb);
+    else if (kind == 2) conv0_ln_gelu_kernel<sp32_t><<<grid, 256, 0, st>>>(x, w, b, g, beta, (sp32_t*)y, t_in, t_out, spb);
     else conv0_ln_gelu_kernel<float><<<grid, 256, 0, st>>>(x, w, b, g, beta, (float*)y, t_in, t_out, spb);
     CHECK_LAUNCH(ctx, "conv0_ln_gelu");
     return AVCER_OK;
 }
 
-int k_layernorm(avcer_ctx* ctx, const void* x, const void* res, const float* g, const float* b, void* yf, void* yb,
-                int64_t rows, int c, float eps, int act, int in_bf16, int /*unused*/, hipStream_t st) {
+namespace {
+template <typename TI, typename OB>
+int ln_launch(avcer_ctx* ctx, const void* x, const void* res, const float* g, const float* b, void* yf, void* yb, int64_t rows,
+              int c, float eps, int act, hipStream_t st) {
     const int grid = cdiv(rows, 4);
-    if (c == 512 && !in_bf16)
-        layernorm_kernel<float, 512><<<grid, 256, 0, st>>>((const float*)x, (const float*)res, g, b, (float*)yf, (bf16_t*)yb, rows, eps, act);
-    else if (c == 512)
-        layernorm_kernel<bf16_t, 512><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)res, g, b, (float*)yf, (bf16_t*)yb, rows, eps, act);
-    else if (c == 1024 && !in_bf16)
-        layernorm_kernel<float, 1024><<<grid, 256, 0, st>>>((const float*)x, (const float*)res, g, b, (float*)yf, (bf16_t*)yb, rows, eps, act);
+    if (c == 512)
+        layernorm_kernel<TI, OB, 512><<<grid, 256, 0, st>>>((const TI*)x, (const TI*)res, g, b, (float*)yf, (OB*)yb, rows, eps, act);
     else if (c == 1024)
-        layernorm_kernel<bf16_t, 1024><<<grid, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)res, g, b, (float*)yf, (bf16_t*)yb, rows, eps, act);
+        layernorm_kernel<TI, OB, 1024><<<grid, 256, 0, st>>>((const TI*)x, (const TI*)res, g, b, (float*)yf, (OB*)yb, rows, eps, act);
     else
         return set_err(ctx, AVCER_EINVAL, "layernorm: c=%d unsupported", c);
+    return AVCER_OK;
+}
+}  // namespace
+
+// in_kind: storage of x / res (0 f32, 1 bf16, 2 sp32); yb_kind: storage of the operand copy yb (1 bf16, 2 sp32)
+int k_layernorm(avcer_ctx* ctx, const void* x, const void* res, const float* g, const float* b, void* yf, void* yb,
+                int64_t rows, int c, float eps, int act, int in_kind, int yb_kind, hipStream_t st) {
+    int r;
+    if (yb_kind == 2) {
+        if (in_kind == 2) r = ln_launch<sp32_t, sp32_t>(ctx, x, res, g, b, yf, yb, rows, c, eps, act, st);
+        else if (in_kind == 1) r = ln_launch<bf16_t, sp32_t>(ctx, x, res, g, b, yf, yb, rows, c, eps, act, st);
+        else r = ln_launch<float, sp32_t>(ctx, x, res, g, b, yf, yb, rows, c, eps, act, st);
+    } else {
+        if (in_kind == 2) r = ln_launch<sp32_t, bf16_t>(ctx, x, res, g, b, yf, yb, rows, c, eps, act, st);
+        else if (in_kind == 1) r = ln_launch<bf16_t, bf16_t>(ctx, x, res, g, b, yf, yb, rows, c, eps, act, st);
+        else r = ln_launch<float, bf16_t>(ctx, x, res, g, b, yf, yb, rows, c, eps, act, st);
+    }
+    if (r != AVCER_OK) return r;
     CHECK_LAUNCH(ctx, "layernorm");
     return AVCER_OK;
 }
 
-int k_add_pe(avcer_ctx* ctx, const float* x, const float* pe, float* yf, bf16_t* yb, int n, int s, int c, hipStream_t st) {
+int k_add_pe(avcer_ctx* ctx, const float* x, const float* pe, float* yf, void* yb, int n, int s, int c, int yb_kind,
+             hipStream_t st) {
     const long total4 = (long)n * s * c / 4;
-    add_pe_kernel<<<cdiv(total4, 256), 256, 0, st>>>(x, pe, yf, yb, total4, s, c);
+    if (yb_kind == 2) add_pe_kernel<sp32_t><<<cdiv(total4, 256), 256, 0, st>>>(x, pe, yf, (sp32_t*)yb, total4, s, c);
+    else add_pe_kernel<bf16_t><<<cdiv(total4, 256), 256, 0, st>>>(x, pe, yf, (bf16_t*)yb, total4, s, c);
     CHECK_LAUNCH(ctx, "add_pe");
     return AVCER_OK;
 }
 
-int k_attention(avcer_ctx* ctx, const void* qkv, void* out, int n, int s, int heads, int d, float scale, int bf16,
-                hipStream_t st) {
+// in_kind: storage of qkv (0 f32, 1 bf16); out_kind: storage of the context vectors (0 f32, 1 bf16, 2 sp32)
+int k_attention(avcer_ctx* ctx, const void* qkv, void* out, int n, int s, int heads, int d, float scale, int in_kind,
+                int out_kind, hipStream_t st) {
     if (s > 256 || s < 1) return set_err(ctx, AVCER_EINVAL, "attention: S=%d outside [1,256]", s);
     if (d != 32 && d != 64) return set_err(ctx, AVCER_EINVAL, "attention: head dim %d", d);
+    if (in_kind == 2 || (in_kind == 1) != (out_kind == 1))
+        return set_err(ctx, AVCER_EINVAL, "attention: unsupported storage combination %d -> %d", in_kind, out_kind);
     const size_t lds = ((size_t)s * (d + 4) + (size_t)s * d + 4 * 256 + 4 * d) * sizeof(float);
     const int grid = n * heads;
-#define ATT(T, D)                                                                                                    \
+#define ATT(T, TO, D)                                                                                                \
     do {                                                                                                             \
         static bool attr_set = false;                                                                                \
         if (!attr_set) {                                                                                             \
-            HIP_TRY(ctx, hipFuncSetAttribute((const void*)attention_kernel<T, D>,                                    \
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)attention_kernel<T, TO, D>,                                \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
             attr_set = true;                                                                                         \
         }                                                                                                            \
-        attention_kernel<T, D><<<grid, 256, lds, st>>>((const T*)qkv, (T*)out, s, heads, scale);                     \
+        attention_kernel<T, TO, D><<<grid, 256, lds, st>>>((const T*)qkv, (TO*)out, s, heads, scale);                \
     } while (0)
-    if (bf16) { if (d == 64) ATT(bf16_t, 64); else ATT(bf16_t, 32); }
-    else { if (d == 64) ATT(float, 64); else ATT(float, 32); }
+    if (in_kind == 1) { if (d == 64) ATT(bf16_t, bf16_t, 64); else ATT(bf16_t, bf16_t, 32); }
+    else if (out_kind == 2) { if (d == 64) ATT(float, sp32_t, 64); else ATT(float, sp32_t, 32); }
+    else { if (d == 64) ATT(float, float, 64); else ATT(float, float, 32); }
 #undef ATT
     CHECK_LAUNCH(ctx, "attention");
     return AVCER_OK;

@@ -106,12 +106,18 @@ class Engine:
                                                        _ptr(feats), self._stream()))
         return logits, probs, feats
 
-    def gather_windows(self, feats, idx):
+    def gather_windows(self, feats, idx, validated: bool = False):
+        """`validated=True`: the caller built idx on the host and already checked its range (no device sync here)."""
         feats = self._dev(feats, torch.float32)
+        if not validated and not (isinstance(idx, torch.Tensor) and idx.is_cuda):
+            a = np.asarray(idx)
+            if a.size and (a.min() < 0 or a.max() >= feats.shape[0]):
+                raise ValueError("gather_windows: index out of range")
+            validated = True
         idx = self._dev(idx, torch.int32)
         if idx.dim() != 2 or idx.shape[1] != 10 or feats.dim() != 2 or feats.shape[1] != 512:
             raise ValueError("gather_windows: feats [*,512], idx [nwin,10]")
-        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= feats.shape[0]):
+        if not validated and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= feats.shape[0]):
             raise ValueError("gather_windows: index out of range")
         out = self._new(idx.shape[0], 10, 512)
         self._check(self.lib.avcer_gather_windows(self.ctx, _ptr(feats), _ptr(idx), int(idx.shape[0]), _ptr(out),

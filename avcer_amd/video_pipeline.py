@@ -62,6 +62,44 @@ def plan_clip(present, fps: float, feat_base: int = 0, win_base: int = 0) -> Cli
     return plan
 
 
+class _DevicePlan:
+    """Index tensors of one (present mask, fps) combination, resident on the device.  Building them costs Python loops
+    and host->device copies that serialise behind in-flight GPU work, so they are cached per mask."""
+
+    def __init__(self, engine: Engine, present: np.ndarray, fps: float):
+        n, t = present.shape
+        plans, fb, wb = [], 0, 0
+        for c in range(n):
+            p = plan_clip(present[c], fps, fb, wb)
+            fb += int(present[c].sum())
+            wb += len(p.windows)
+            plans.append(p)
+        dev = engine.device
+        self.n_feat, self.n_win = fb, wb
+        self.sel = None if fb == n * t else torch.from_numpy(np.nonzero(present.reshape(-1))[0]).to(dev)
+        s_src = np.array([i if i >= 0 else fb for p in plans for i in p.static_src], dtype=np.int64)
+        d_src = np.array([i if i >= 0 else wb for p in plans for i in p.dyn_src], dtype=np.int64)
+        win = np.array([w for p in plans for w in p.windows], dtype=np.int32).reshape(-1, 10)
+        assert win.size == 0 or (win.min() >= 0 and win.max() < max(fb, 1))
+        self.s_src = torch.from_numpy(s_src).to(dev)
+        self.d_src = torch.from_numpy(d_src).to(dev)
+        self.win = torch.from_numpy(win).to(dev)
+        self.zero_row = torch.zeros(1, 7, device=dev)
+
+
+_PLAN_CACHE: dict = {}
+
+
+def _device_plan(engine: Engine, present: np.ndarray, fps: float) -> _DevicePlan:
+    key = (id(engine), present.shape, present.tobytes(), float(fps))
+    plan = _PLAN_CACHE.get(key)
+    if plan is None:
+        if len(_PLAN_CACHE) > 64:
+            _PLAN_CACHE.clear()
+        plan = _PLAN_CACHE[key] = _DevicePlan(engine, present, fps)
+    return plan
+
+
 def visual_forward(engine: Engine, frames_u8: torch.Tensor, present, fps: float, mode: int = MODE_FP32):
     """frames_u8 [N,T,H,W,3] (or [T,H,W,3]) RGB tiles, present [N,T] bool.
     Returns (static_probs [N,T,7], dynamic_logits [N,T,7]) float32 in VIDEO column order (DICT_EMO_VIDEO).
@@ -69,29 +107,22 @@ def visual_forward(engine: Engine, frames_u8: torch.Tensor, present, fps: float,
     single = frames_u8.dim() == 4
     if single:
         frames_u8 = frames_u8[None]
-    present = np.asarray(present, dtype=bool).reshape(frames_u8.shape[0], frames_u8.shape[1])
+    present = np.ascontiguousarray(np.asarray(present, dtype=bool).reshape(frames_u8.shape[0], frames_u8.shape[1]))
     n, t = present.shape
-    plans, fb, wb = [], 0, 0
-    for c in range(n):
-        p = plan_clip(present[c], fps, fb, wb)
-        fb += int(present[c].sum())
-        wb += len(p.windows)
-        plans.append(p)
+    plan = _device_plan(engine, present, fps)
     dev = engine.device
     flat = frames_u8.reshape(n * t, *frames_u8.shape[2:])
-    stat = torch.zeros(n * t, 7, device=dev)
-    dyn = torch.zeros(n * t, 7, device=dev)
-    if fb:
-        sel = torch.from_numpy(np.nonzero(present.reshape(-1))[0]).to(dev)
-        frames_sel = flat.to(dev) if fb == n * t else flat.to(dev).index_select(0, sel)
+    if plan.n_feat:
+        frames_sel = flat.to(dev) if plan.sel is None else flat.to(dev).index_select(0, plan.sel)
         _, probs, feats = engine.static_forward(frames_sel, mode)
-        zero_row = torch.zeros(1, 7, device=dev)
-        s_src = torch.tensor([i if i >= 0 else fb for p in plans for i in p.static_src], device=dev)
-        stat = torch.cat([probs, zero_row]).index_select(0, s_src)
-        if wb:
-            idx = torch.tensor([w for p in plans for w in p.windows], dtype=torch.int32, device=dev)
-            dl = engine.dynamic_forward(engine.gather_windows(feats, idx))
-            d_src = torch.tensor([i if i >= 0 else wb for p in plans for i in p.dyn_src], device=dev)
-            dyn = torch.cat([dl, zero_row]).index_select(0, d_src)
+        stat = torch.cat([probs, plan.zero_row]).index_select(0, plan.s_src)
+        if plan.n_win:
+            dl = engine.dynamic_forward(engine.gather_windows(feats, plan.win, validated=True))
+            dyn = torch.cat([dl, plan.zero_row]).index_select(0, plan.d_src)
+        else:
+            dyn = torch.zeros(n * t, 7, device=dev)
+    else:
+        stat = torch.zeros(n * t, 7, device=dev)
+        dyn = torch.zeros(n * t, 7, device=dev)
     stat, dyn = stat.view(n, t, 7), dyn.view(n, t, 7)
     return (stat[0], dyn[0]) if single else (stat, dyn)

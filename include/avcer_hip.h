@@ -127,7 +127,10 @@ int avcer_fuse(avcer_ctx* ctx, const float* stat, const float* dyn_logits, const
 /* The contraction kernel itself (implicit-GEMM convolution with fused epilogue), exported for kernel-level
  * parity tests and micro-benchmarks:  Y[m, n] = act(scale[n] * sum_k A[m,k] * W[n,k] + bias[n] (+ R[m,n]))
  * where A is gathered from an NHWC tensor.  See avcer_conv_desc. dtype: 0 = f32 in/out, 1 = bf16 in/out,
- * 2 = bf16 in / f32 out, 3 = split-bf16: f32 in/out with w pre-split by avcer_split_weights. */
+ * 2 = bf16 in / f32 out; split-bf16 arithmetic with w pre-split by avcer_split_weights: 3 = f32 in / f32 out,
+ * 4 = f32 in / sp32 out, 5 = sp32 in / sp32 out (+ sp32 residual), 6 = sp32 in / f32 out (+ f32 residual).
+ * "sp32" storage = per aligned group of 32 channels, 32 bf16 hi values then 32 bf16 lo values (x = hi + lo), i.e. the
+ * layout avcer_split_weights produces; 4 bytes per element. */
 typedef struct avcer_conv_desc {
     int32_t batch, in_h, in_w;       /* input extents used for bounds (zero padding outside) */
     int32_t out_h, out_w;            /* M = batch*out_h*out_w */

@@ -24,30 +24,63 @@ def _act(v, act):
     return F.relu(v) if act == 1 else (F.gelu(v) if act == 2 else v)
 
 
+def to_sp32(x):
+    """f32 [..., C] -> sp32 storage as int16 [..., 2C]: per group of 32 channels, 32 bf16 hi then 32 bf16 lo."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    c = x.shape[-1]
+    h = hi.contiguous().view(torch.int16).reshape(*x.shape[:-1], c // 32, 32)
+    l = lo.contiguous().view(torch.int16).reshape(*x.shape[:-1], c // 32, 32)
+    return torch.cat([h, l], dim=-1).reshape(*x.shape[:-1], 2 * c).contiguous()
+
+
+def from_sp32(s):
+    g = s.contiguous().reshape(*s.shape[:-1], s.shape[-1] // 64, 64)
+    hi = g[..., :32].contiguous().view(torch.bfloat16).float()
+    lo = g[..., 32:].contiguous().view(torch.bfloat16).float()
+    return (hi + lo).reshape(*s.shape[:-1], s.shape[-1] // 2)
+
+
+A_KIND = {0: "f32", 1: "bf16", 2: "bf16", 3: "f32", 4: "f32", 5: "sp32", 6: "sp32"}
+O_KIND = {0: "f32", 1: "bf16", 2: "f32", 3: "f32", 4: "sp32", 5: "sp32", 6: "f32"}
+
+
+def _enc(t, kind, dev):
+    if kind == "f32":
+        return t.to(dev, torch.float32).contiguous()
+    if kind == "bf16":
+        return t.to(dev, torch.bfloat16).contiguous()
+    return to_sp32(t.float()).to(dev)
+
+
+def _dec(t, kind):
+    return from_sp32(t.cpu()) if kind == "sp32" else t.float().cpu()
+
+
 def _run(engine, d, dtype, x, w, scale, bias, res, y):
-    tin = torch.float32 if dtype in (0, 3) else torch.bfloat16
-    tout = torch.float32 if dtype in (0, 2, 3) else torch.bfloat16
     dev = engine.device
-    xd, wd = x.to(dev, tin).contiguous(), w.to(dev, tin).contiguous()
-    w_arg = engine.split_weights(wd) if dtype == 3 else wd  # dtype 3: bf16 hi/lo split of the f32 weights
+    ak, ok = A_KIND[dtype], O_KIND[dtype]
+    xd = _enc(x, ak, dev)
+    wd = w.to(dev, torch.bfloat16 if ak == "bf16" else torch.float32).contiguous()
+    w_arg = engine.split_weights(wd) if dtype >= 3 else wd  # split-bf16 arithmetic: bf16 hi/lo split of the f32 weights
     sd_ = None if scale is None else scale.to(dev, torch.float32)
     bd = None if bias is None else bias.to(dev, torch.float32)
-    rd = None if res is None else res.to(dev, tout).contiguous()
-    yd = y.to(dev, tout).contiguous()
+    rd = None if res is None else _enc(res, ok, dev)
+    yd = _enc(y, ok, dev)
     engine.conv_gemm(d, dtype, xd, w_arg, sd_, bd, rd, yd)
     torch.cuda.synchronize()
-    return yd.float().cpu(), xd.double().cpu(), wd.double().cpu(), (None if rd is None else rd.double().cpu())
+    return _dec(yd, ok), _dec(xd, ak).double(), wd.double().cpu(), (None if rd is None else _dec(rd, ok).double())
 
 
 def _tol(dtype, ref):
     scale = float(ref.abs().max()) + 1e-6
-    return {0: 2e-5, 1: 1.2e-2, 2: 2e-4, 3: 6e-5}[dtype] * scale
+    return {0: 2e-5, 1: 1.2e-2, 2: 2e-4, 3: 6e-5, 4: 8e-5, 5: 8e-5, 6: 6e-5}[dtype] * scale
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3, 4, 5, 6])
 def test_identity_times_asymmetric_weight(engine, dtype):
     """A = I with an ASYMMETRIC W catches a row/col swap of the accumulator layout (exact small integers)."""
-    k = 32 if dtype in (0, 3) else 64
+    k = 64 if dtype in (1, 2) else 32
     m, n = 128, 128
     x = torch.zeros(m, k)
     x[torch.arange(k), torch.arange(k)] = 1.0
@@ -59,7 +92,7 @@ def test_identity_times_asymmetric_weight(engine, dtype):
     assert torch.equal(y, ref), (y - ref).abs().max()
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("m,k,n", [(300, 128, 192), (129, 64, 256), (1, 256, 64), (1000, 2048, 128)])
 def test_linear(engine, dtype, m, k, n):
     g = torch.Generator().manual_seed(m + k + n)
@@ -83,7 +116,7 @@ CONVS = [
 ]
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("cfg", CONVS)
 def test_conv(engine, dtype, cfg):
     b, h, w_, c, kh, kw, s, p, dil, n, act = cfg
@@ -105,7 +138,7 @@ def test_conv(engine, dtype, cfg):
     assert (y.double() - ref).abs().max() < _tol(dtype, ref)
 
 
-@pytest.mark.parametrize("dtype", [0, 2, 3])
+@pytest.mark.parametrize("dtype", [0, 2, 3, 5, 6])
 def test_grouped_slices_and_residual_after_act(engine, dtype):
     """pos-conv shape: one group of a [B,S,C] tensor, zero padding in time, output/residual written into a channel
     slice, y = gelu(conv + bias) + residual."""
@@ -127,7 +160,7 @@ def test_grouped_slices_and_residual_after_act(engine, dtype):
     assert torch.equal(y[:, :, :128], y0[:, :, :128]) and torch.equal(y[:, :, 192:], y0[:, :, 192:])
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 3])
+@pytest.mark.parametrize("dtype", [0, 1, 3, 4])
 def test_stem_layout(engine, dtype):
     """7x7/2 stem as 8 tap rows x (8 pixels x 4 channels) over a zero-bordered 230x230x4 image."""
     from avcer_amd import packing, synth
@@ -173,7 +206,7 @@ def test_split_bf16_is_far_more_accurate_than_bf16(engine):
     assert errs[3] < 30 * errs[0] + 1e-6 and errs[3] < errs[2] / 50
 
 
-@pytest.mark.parametrize("dtype", [0, 2, 3])
+@pytest.mark.parametrize("dtype", [0, 2, 3, 6])
 def test_grouped_launch_matches_grouped_conv1d(engine, dtype):
     """wav2vec2 pos-conv shape in one launch: groups of 64 channels, k taps, zero padding, gelu(conv+b) + residual."""
     b, s, groups, cin, k = 2, 37, 4, 64, 16
