@@ -7,7 +7,7 @@ clips of 16 x 224x224 frames + 2 s @ 16 kHz (BASELINE.json metric), one process 
         bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path over one batch of `--clips` clips per GPU (weak scaling; 128 clips/GPU = BASELINE
-config 5 at 8 GPUs, static CNN in sub-batches of 256 frames = config 2's batch).  Inputs are resident in HBM before
+config 5 at 8 GPUs; the static CNN runs in passes of up to 1024 frames).  Inputs are resident in HBM before
 the timed region.  Rank 0 prints ONE JSON line.  The headline `value` is measured in a parity-green arithmetic mode
 (--mode x3, default: bf16 MFMA on hi/lo-split operands with f32 accumulation, probabilities within 1e-4 of the CPU
 oracle; --mode fp32: exact f32 MFMA); the other modes are measured next to it under "modes", each with ITS measured
@@ -46,7 +46,8 @@ GFLOP_CLIP_GEMM = GFLOP_CLIP - GFLOP_AUDIO_NOT_GEMM - 2 * 512 * 7 * T_FRAMES * 1
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "x3": 2500.0}  # MI355X_MICROARCH.md dense MFMA peaks (f32-in; bf16)
 MFMA_PASSES = {"fp32": 1, "bf16": 1, "x3": 3}  # MFMA products issued per algorithmic product
 DTYPE = {"fp32": "f32", "bf16": "bf16", "x3": "bf16x3 (bf16 MFMA on hi/lo-split f32 operands, f32 accumulate)"}
-KERNEL = {"fp32": "conv_gemm_kernel<0,float,*>", "bf16": "conv_gemm_kernel<1,*,*>", "x3": "conv_gemm_kernel<2,float,*>"}
+KERNEL = {"fp32": "conv_gemm_kernel<0,0,*>", "bf16": "conv_gemm_kernel<1,*,*>",
+          "x3": "conv_gemm_kernel<3,*,*> (sp32 activations; <2,*,*> where the input is still f32)"}
 
 
 def log(msg):
@@ -110,7 +111,11 @@ def one_step(pipe, frames, wav, n_total):
     """shard-local records -> one all-gather -> replicated fusion (avcer_amd/dist.py)."""
     stat, dyn, aud = pipe.clip_records(frames, wav, FPS)
     if dist.is_initialized() and dist.get_world_size() > 1:
-        rec = adist.all_gather_records(adist.pack_records(stat, dyn, aud), n_total)
+        rec = adist.pack_records(stat, dyn, aud)
+        if dist.get_backend() == "gloo":  # rehearsal only: the CPU backend cannot take device tensors
+            rec = adist.all_gather_records(rec.cpu(), n_total).to(stat.device)
+        else:
+            rec = adist.all_gather_records(rec, n_total)
         stat, dyn, aud = adist.unpack_records(rec, T_FRAMES, aud.shape[1])
     return pipe.fuse_records(stat.contiguous(), dyn.contiguous(), aud.contiguous())
 
@@ -136,7 +141,7 @@ def timed(pipe, frames, wav, n_total, steps, warmup, device, profile):
     kern_ms, launches = pipe.engine.profile_read() if profile else (0.0, 0)
     pipe.engine.profile_enable(False)
     if dist.is_initialized():
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if dist.get_backend() == "gloo" else device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt, kern_ms, launches
@@ -209,11 +214,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # rehearsal on a 1-GPU box: AVCER_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo (CPU) for the collective
+    rehearse = os.environ.get("AVCER_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     device = torch.device("cuda", local_rank)
@@ -272,7 +284,7 @@ def main():
                                    "samples per clip, synthetic weights (ResNet-50 + LSTM + wav2vec2-large-robust-12 "
                                    "ExprModelV3)", "clips_per_gpu": args.clips, "global_clips": n_total,
                        "frames_per_clip": T_FRAMES, "audio_samples_per_clip": T_AUDIO, "fps": FPS,
-                       "static_sub_batch": 256, "parallelism": f"clip-sharded x{world} + 1 all-gather of per-clip records"},
+                       "static_sub_batch": 1024, "parallelism": f"clip-sharded x{world} + 1 all-gather of per-clip records"},
             "max_dprob_vs_cpu_oracle": dprob, "argmax_identical": same, "parity_gate": 1e-4,
             "gflop_per_clip": GFLOP_CLIP, "roofline": head["roofline"],
         }
