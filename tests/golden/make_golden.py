@@ -80,6 +80,7 @@ def install_stubs():
     vis = types.ModuleType("visualization.visualize")
     vis.show_cam_on_image = None
     vis.plot_compound_expression_prediction = None
+    vis.plot_conf_matrix = None
     pkg = types.ModuleType("visualization")
     pkg.visualize = vis
     sys.modules["visualization"] = pkg
@@ -284,6 +285,92 @@ def gen_audio():
     print("chunker cases", len(out6) // 2)
 
 
+# ----------------------------------------------------------------------------- F9: 7-class ExprModelV2 (row f3)
+def gen_audio7():
+    from transformers import Wav2Vec2FeatureExtractor
+    from transformers.models.wav2vec2.modeling_wav2vec2 import Wav2Vec2PreTrainedModel
+
+    Wav2Vec2PreTrainedModel.init_weights = lambda self: None
+    from architectures.audio_7_cl import ExprModelV2
+
+    proc = Wav2Vec2FeatureExtractor(feature_size=1, sampling_rate=16000, padding_value=0.0, do_normalize=True,
+                                    return_attention_mask=True)
+    sd = synth.to_torch(synth.audio_state_dict(43, num_classes=7))
+    model = ExprModelV2(w2v_config())
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    wav = synth.waveforms(777, 2, 32000)
+    x = np.stack([np.asarray(proc(torch.from_numpy(r[None]), sampling_rate=16000)["input_values"][0])[0] for r in wav])
+    with torch.no_grad():
+        lg = model(torch.from_numpy(x))
+    np.savez_compressed(os.path.join(HERE, "audio_model7.npz"), logits=lg.numpy())
+    print("7-class logits", lg.numpy()[0])
+
+
+# ----------------------------------------------------------------------------- F10: CSV wire formats + dataset fusion (row f2)
+def gen_dataset_fusion():
+    import shutil
+    import tempfile
+
+    import pandas as pd
+
+    import data.utils as du
+    import get_pred_av as gpa
+
+    vid_cols = ["Neutral", "Happiness", "Sadness", "Surprise", "Fear", "Disgust", "Anger"]
+    aud_cols = ["Neutral", "Anger", "Disgust", "Fear", "Happiness", "Sadness", "Surprise", "Other"]
+    tmp = tempfile.mkdtemp()
+    cwd = os.getcwd()
+    out = {}
+    try:
+        os.chdir(tmp)
+        root = os.path.join(tmp, "preds")
+        os.makedirs(os.path.join(root, "video"))
+        os.makedirs(os.path.join(root, "audio", "modelA"))
+        videos = {"vidA": (20, 20), "vidB": (33, 27)}  # (video frames, frames covered by audio windows)
+        fmt_rows = []
+        for vi, (name, (n, cover)) in enumerate(videos.items()):
+            stat = du.softmax(synth.centered(500 + vi, "stat", (n, 7), 1.5)).astype(np.float32)
+            dyn = synth.centered(600 + vi, "dyn", (n, 7), 2.0).astype(np.float32)
+            pd.DataFrame(stat, columns=vid_cols).to_csv(os.path.join(root, "video", f"static__{name}.csv"), index=False)
+            pd.DataFrame(dyn, columns=vid_cols).to_csv(os.path.join(root, "video", f"dynamic__{name}.csv"), index=False)
+            rows, frames = [], []
+            for w, lo in enumerate(range(0, cover, 6)):
+                lg = synth.centered(700 + vi, f"aud{w}", (8,), 2.0).astype(np.float32)
+                for f in range(lo, min(lo + 13, cover)):
+                    rows.append(lg)
+                    frames.append(f"{f:06d}.jpg")
+            rows.append(np.full(8, np.nan, np.float32))  # the empty-tail window of the reference's chunker
+            frames.append(f"{cover:06d}.jpg")
+            df = pd.DataFrame(np.array(rows), columns=aud_cols)
+            df["frames"] = frames
+            df.to_csv(os.path.join(root, "audio", "modelA", f"{name}.csv"), index=False)
+            # the challenge's prediction file lists a SUBSET of the frames (1-based, 5 digits)
+            fmt_rows += [f"{name}/{f + 1:05d}.jpg" for f in range(n) if f % 7 != 3]
+            out[f"{name}_stat"], out[f"{name}_dyn"] = stat, dyn
+            out[f"{name}_aud_rows"] = np.array(rows)
+            out[f"{name}_aud_frames"] = np.array([int(f[:6]) for f in frames])
+        fmt = os.path.join(tmp, "prediction_file_format.csv")
+        pd.DataFrame({"image_location": fmt_rows}).to_csv(fmt, index=False)
+        w1 = np.array(ast.literal_eval(str([list(r) for r in __import__("oracle.fusion", fromlist=["x"]).WEIGHTS_AV_1])))
+        gpa.get_c_expr_db_pred(fmt, root, ["video", "audio", "modelA"], list(videos), w1, np.array([1, 1, 1]), "av", "w",
+                               False, True)
+        txt = open(os.path.join(tmp, "src/pred_results/DF_C_EXPR_DB/C_EXPR_DB_av_sd_w_False_True.txt")).read()
+        out["submission_txt"] = np.frombuffer(txt.encode(), dtype=np.uint8)
+        out["format_rows"] = np.array(fmt_rows)
+        for name in videos:  # the CSV text itself is the wire format: keep it as fixture data
+            for kind in ("static", "dynamic"):
+                out[f"{name}_{kind}_csv"] = np.frombuffer(
+                    open(os.path.join(root, "video", f"{kind}__{name}.csv"), "rb").read(), dtype=np.uint8)
+            out[f"{name}_audio_csv"] = np.frombuffer(
+                open(os.path.join(root, "audio", "modelA", f"{name}.csv"), "rb").read(), dtype=np.uint8)
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+    np.savez_compressed(os.path.join(HERE, "dataset_fusion.npz"), **out)
+    print("dataset fusion: submission lines", len(txt.splitlines()))
+
+
 # ----------------------------------------------------------------------------- F7/F8 fusion
 def gen_fusion():
     import pandas as pd
@@ -365,10 +452,14 @@ if __name__ == "__main__":
     from transformers.models.wav2vec2 import modeling_wav2vec2  # noqa: F401
 
     install_stubs()
-    which = sys.argv[1:] or ["visual", "audio", "fusion"]
+    which = sys.argv[1:] or ["visual", "audio", "fusion", "audio7", "dataset"]
     if "visual" in which:
         gen_visual()
     if "audio" in which:
         gen_audio()
     if "fusion" in which:
         gen_fusion()
+    if "audio7" in which:
+        gen_audio7()
+    if "dataset" in which:
+        gen_dataset_fusion()

@@ -120,3 +120,21 @@ def test_audio_batch_invariance_128(engine_audio):
     small = engine_audio.audio_forward(wav[126:130], True, MODE_BF16).cpu()
     assert torch.equal(big[126:130], small)
     assert torch.isfinite(big).all()
+
+
+def test_seven_class_variant(engine, golden):
+    """Row f3: the 7-class ExprModelV2 weights load through the same packer/kernels (n_classes comes from the blob)."""
+    from avcer_amd.engine import Engine
+
+    eng = Engine(0)
+    eng.load_audio(synth.audio_state_dict(43, num_classes=7))
+    assert eng.audio_classes == 7
+    wav = torch.from_numpy(synth.waveforms(777, 2, 32000))
+    ref = golden("audio_model7")["logits"]
+    for mode, tol in ((MODE_FP32, 2e-3), (MODE_BF16X3, 2e-3)):
+        out = eng.audio_forward(wav, normalize=True, mode=mode).cpu().numpy()
+        assert out.shape == (2, 7)
+        p_got = torch.softmax(torch.from_numpy(out), 1).numpy()
+        p_ref = torch.softmax(torch.from_numpy(ref), 1).numpy()
+        assert np.abs(out - ref).max() < tol and np.abs(p_got - p_ref).max() < 1e-4
+    eng.close()

@@ -1,0 +1,62 @@
+"""Row f2: CSV wire formats and the dataset-level fusion driver, pinned by files/outputs of the reference
+(tests/golden/make_golden.py gen_dataset_fusion runs get_pred_av.get_c_expr_db_pred on them)."""
+import os
+
+import numpy as np
+import pytest
+
+from avcer_amd import io_formats as iof
+
+VIDEOS = ("vidA", "vidB")
+
+
+def _materialise(g, tmp_path):
+    root = tmp_path / "preds"
+    (root / "video").mkdir(parents=True)
+    (root / "audio" / "modelA").mkdir(parents=True)
+    for v in VIDEOS:
+        for kind in ("static", "dynamic"):
+            (root / "video" / f"{kind}__{v}.csv").write_bytes(g[f"{v}_{kind}_csv"].tobytes())
+        (root / "audio" / "modelA" / f"{v}.csv").write_bytes(g[f"{v}_audio_csv"].tobytes())
+    fmt = tmp_path / "prediction_file_format.csv"
+    fmt.write_text("image_location\n" + "\n".join(g["format_rows"].tolist()) + "\n")
+    return str(root), str(fmt)
+
+
+def test_writers_are_byte_compatible_with_the_reference(golden, tmp_path):
+    g = golden("dataset_fusion")
+    for v in VIDEOS:
+        dyn_path, stat_path = iof.write_visual_csvs(g[f"{v}_stat"], g[f"{v}_dyn"], str(tmp_path / "w"), v)
+        assert open(stat_path, "rb").read() == g[f"{v}_static_csv"].tobytes()
+        assert open(dyn_path, "rb").read() == g[f"{v}_dynamic_csv"].tobytes()
+        p = iof.write_audio_csv(g[f"{v}_aud_rows"], g[f"{v}_aud_frames"], str(tmp_path / "w"), "modelA", v)
+        assert open(p, "rb").read() == g[f"{v}_audio_csv"].tobytes()
+    assert iof.write_audio_csv(np.zeros((1, 8), np.float32), [0], str(tmp_path / "w"), "m", "6-30-1920x1080").endswith(
+        "6-30-1920x1080_right.csv")
+
+
+def test_readers_and_alignment(golden, tmp_path):
+    g = golden("dataset_fusion")
+    root, fmt = _materialise(g, tmp_path)
+    rows, frames = iof.read_audio_csv(os.path.join(root, "audio", "modelA", "vidB.csv"))
+    assert not np.isnan(rows).any() and len(rows) == len(g["vidB_aud_rows"]) - 1  # the NaN tail row is dropped
+    np.testing.assert_allclose(iof.read_visual_csv(os.path.join(root, "video", "static__vidB.csv")), g["vidB_stat"], rtol=1e-6)
+    listed = [r for r in g["format_rows"].tolist() if r.startswith("vidB/")]
+    sel, aud_sel, aud_pos = iof.align_video(33, frames, listed, "vidB")
+    assert [f"vidB/{f + 1:05d}.jpg" for f in sel] == listed
+    assert aud_sel.max() == 26 and len(aud_pos) == len(sel) and aud_pos.max() == len(aud_sel) - 1
+    assert (np.diff(aud_pos) >= 0).all() and aud_pos[-1] == aud_pos[-2]  # tail repeats the last audio row
+
+
+@pytest.mark.gpu
+def test_dataset_fusion_reproduces_the_reference_submission(engine, golden, tmp_path):
+    g = golden("dataset_fusion")
+    root, fmt = _materialise(g, tmp_path)
+    locs, pred, txt = iof.dataset_fusion(engine, fmt, root, ["video", "audio", "modelA"], list(VIDEOS),
+                                         save_path=str(tmp_path / "out"))
+    ref = g["submission_txt"].tobytes().decode()
+    got = open(txt).read()
+    assert os.path.basename(txt) == "C_EXPR_DB_av_sd_w_False_True.txt"
+    assert got.splitlines()[0] == ref.splitlines()[0]
+    assert [l.split(",")[0] for l in got.splitlines()] == [l.split(",")[0] for l in ref.splitlines()]
+    assert got == ref

@@ -75,3 +75,13 @@ def test_param_count(golden, sd_audio):
     n = sum(v.numel() for k, v in sd_audio.items()
             if k.startswith("wav2vec2.") and "running" not in k and "num_batches" not in k)
     assert n == int(golden("audio_model")["n_params"][0]) == 164284032
+
+
+def test_seven_class_variant_matches_reference(golden):
+    """Row f3: ExprModelV2 of architectures/audio_7_cl.py (same graph, 7-wide last Linear)."""
+    sd = synth.to_torch(synth.audio_state_dict(43, num_classes=7))
+    x = oa.normalize(synth.waveforms(777, 2, 32000))
+    with torch.no_grad():
+        lg = oa.expr_model_v3_forward(sd, torch.from_numpy(x))
+    assert tuple(lg.shape) == (2, 7)
+    assert np.abs(lg.numpy() - golden("audio_model7")["logits"]).max() < 2e-5
