@@ -24,6 +24,8 @@ class ConvDesc(C.Structure):
         ("y_ld", C.c_int64), ("y_coff", C.c_int32),
         ("r_ld", C.c_int64), ("r_coff", C.c_int32),
         ("act", C.c_int32), ("res_after_act", C.c_int32), ("groups", C.c_int32),
+        ("x2_cin", C.c_int32), ("x2_coff", C.c_int32), ("x2_stride", C.c_int32),
+        ("x2_stride_b", C.c_int64), ("x2_stride_h", C.c_int64), ("x2_stride_w", C.c_int64),
     ]
 
 
@@ -54,6 +56,8 @@ SIGNATURES = {
     "avcer_conv_gemm": (C.c_int, [c_ctx, C.POINTER(ConvDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, c_stream]),
     "avcer_split_weights": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_size_t, c_stream]),
+    "avcer_conv_gemm_dual": (C.c_int, [c_ctx, C.POINTER(ConvDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
     "avcer_gemm_stats": (C.c_int, [c_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
     "avcer_profile_enable": (C.c_int, [c_ctx, C.c_int]),
     "avcer_profile_read": (C.c_int, [c_ctx, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -189,7 +189,7 @@ struct Net {
     // contraction with weights `wname`; akind / okind = storage of the activations read / written
     // (0 = f32, 1 = bf16, 2 = sp32 pairs), which selects the kernel instantiation (avcer_conv_gemm dtype)
     void gemm(avcer_conv_desc d, const std::string& wname, const float* scale, const float* bias, const void* x,
-              const void* res, void* y, int akind, int okind) {
+              const void* res, void* y, int akind, int okind, const void* x2 = nullptr) {
         if (err != AVCER_OK) return;
         const Tensor* w = T(wname);
         if (!w) return;
@@ -214,13 +214,13 @@ struct Net {
                           wname.c_str(), akind, okind);
             return;
         }
-        const long K = (long)d.kh * d.kw * d.cin;
+        const long K = (long)d.kh * d.kw * d.cin + (x2 ? d.x2_cin : 0);
         if ((long)w->numel != (long)d.n * K * (d.groups > 1 ? d.groups : 1)) {
             err = set_err(ctx, AVCER_EFORMAT, "gemm %s: weight has %zu elements, expected %ld x %ld", wname.c_str(),
                           w->numel, (long)d.n, K);
             return;
         }
-        err = launch_conv_gemm(ctx, d, dtype, x, wp, scale, bias, res, y, st);
+        err = launch_conv_gemm(ctx, d, dtype, x, wp, scale, bias, res, y, st, x2);
     }
     void chk(int r) { if (err == AVCER_OK && r != AVCER_OK) err = r; }
     // debug tap: raw copy of min(requested, available) bytes of an intermediate tensor
@@ -345,12 +345,12 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     const int NB = std::min(n, ctx->static_batch);
     const size_t act_elems = (size_t)NB * 112 * 112 * 64;  // largest activation (stem output)
     const size_t pre_elems = (size_t)NB * 230 * 230 * 4;
-    const size_t total = pre_elems * es + 5 * (act_elems * es + 256) + (size_t)NB * (2048 + 512) * 4 + 4096;
+    const size_t total = pre_elems * es + 4 * (act_elems * es + 256) + (size_t)NB * (2048 + 512) * 4 + 4096;
     void* wsp = nullptr;
     TRY(ws_reserve(ctx, 0, total, &wsp));
     Arena ar(wsp, ctx->ws[0].cap);
     void* P = ar.get(pre_elems * es);
-    void* buf[5];
+    void* buf[4];
     for (auto& b : buf) b = ar.get(act_elems * es);
     float* pooled = (float*)ar.get((size_t)NB * 2048 * 4);
     float* feat_ws = (float*)ar.get((size_t)NB * 512 * 4);
@@ -378,7 +378,6 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
         void* X = buf[1];
         void* T1 = buf[2];
         void* T2 = buf[3];
-        void* ID = buf[4];
         void* OUT = buf[0];
         int h = 55, cin = 64;
         for (int li = 0; li < 4; ++li) {
@@ -391,21 +390,22 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
                          net.F(p + "c1.b"), X, nullptr, T1, act, act);
                 net.gemm(conv2d_desc(nb, oh, oh, planes, 3, 3, 1, 1, planes, 1), p + "c2.w", net.F(p + "c2.s"),
                          net.F(p + "c2.b"), T1, nullptr, T2, act, act);
-                const void* identity = X;
                 if (b == 0) {
-                    net.gemm(conv2d_desc(nb, h, h, cin, 1, 1, stride, 0, planes * 4, 0), p + "ds.w", net.F(p + "ds.s"),
-                             net.F(p + "ds.b"), X, nullptr, ID, act, act);
-                    identity = ID;
+                    // conv3 + downsample fused: K = [T2 (planes) | X at stride (cin)], BN scales folded into the weights
+                    avcer_conv_desc d = conv2d_desc(nb, oh, oh, planes, 1, 1, 1, 0, planes * 4, 1);
+                    d.x2_cin = cin; d.x2_stride = stride;
+                    d.x2_stride_b = (int64_t)h * h * cin; d.x2_stride_h = (int64_t)h * cin; d.x2_stride_w = cin;
+                    net.gemm(d, p + "c3d.w", nullptr, net.F(p + "c3d.b"), T2, nullptr, OUT, act, act, X);
+                } else {
+                    net.gemm(conv2d_desc(nb, oh, oh, planes, 1, 1, 1, 0, planes * 4, 1), p + "c3.w", net.F(p + "c3.s"),
+                             net.F(p + "c3.b"), T2, X, OUT, act, act);
                 }
-                net.gemm(conv2d_desc(nb, oh, oh, planes, 1, 1, 1, 0, planes * 4, 1), p + "c3.w", net.F(p + "c3.s"),
-                         net.F(p + "c3.b"), T2, identity, OUT, act, act);
                 std::swap(X, OUT);
                 h = oh;
                 cin = planes * 4;
                 if (li == 0 && b == 0) {
                     net.tap("l1b0_c1", T1, (size_t)nb * h * h * planes * es);
                     net.tap("l1b0_c2", T2, (size_t)nb * h * h * planes * es);
-                    net.tap("l1b0_ds", ID, (size_t)nb * h * h * cin * es);
                     net.tap("l1b0", X, (size_t)nb * h * h * cin * es);
                 }
             }
@@ -737,6 +737,14 @@ extern "C" int avcer_debug_tap(avcer_ctx* ctx, const char* name, void* dst_dev, 
 }
 
 extern "C" int64_t avcer_debug_tap_copied(const avcer_ctx* ctx) { return ctx ? ctx->tap_copied : -1; }
+
+extern "C" int avcer_conv_gemm_dual(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, const void* x, const void* x2,
+                                    const void* w, const float* scale, const float* bias, const void* residual, void* y,
+                                    avcer_stream_t stream) {
+    if (!ctx || !d || !x2) return AVCER_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_conv_gemm(ctx, *d, dtype, x, w, scale, bias, residual, y, (hipStream_t)stream, x2);
+}
 
 extern "C" int avcer_split_weights(avcer_ctx* ctx, const float* w, void* out, size_t numel, avcer_stream_t stream) {
     if (!ctx) return AVCER_EINVAL;

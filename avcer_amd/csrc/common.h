@@ -79,7 +79,8 @@ int ensure_bf16(avcer_ctx* ctx, Model& m, const char* name);
 
 // ---- gemm.hip
 int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const void* x, const void* w,
-                     const float* scale, const float* bias, const void* residual, void* y, hipStream_t st);
+                     const float* scale, const float* bias, const void* residual, void* y, hipStream_t st,
+                     const void* x2 = nullptr);
 
 // ---- kernels.hip (element-wise / reduction kernels; T selects f32 (0) or bf16 (1) activations)
 int k_preprocess(avcer_ctx*, const uint8_t* frames, int n, int in_h, int in_w, void* out, int bf16, hipStream_t);

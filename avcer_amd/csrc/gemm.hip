@@ -46,6 +46,12 @@ struct GemmParams {
     const char* R;
     char* Y;
     unsigned x_bytes, w_bytes;  // buffer extents for the hardware bounds check (reads past them return 0)
+    // optional second A source (fused 1x1 convolutions: K elements [K1, K) come from X2, a 1x1 conv with its own stride)
+    const char* X2;
+    unsigned x2_bytes;
+    int K1;
+    long sB2, sH2, sW2;
+    int coff2, st2;
     int M, N, K;
     int OH, OW, H, Wd, Cin, KW;
     int sh, sw, ph, pw, dh, dw;
@@ -263,6 +269,8 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
     // hardware-bounds-checked buffer descriptors: an out-of-range voffset returns zeros without a branch
     const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.X), (short)0, (int)p.x_bytes, 0x00020000);
     const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W), (short)0, (int)p.w_bytes, 0x00020000);
+    const auto x2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.X2 ? p.X2 : p.X), (short)0,
+                                                        (int)(p.X2 ? p.x2_bytes : p.x_bytes), 0x00020000);
 
     // Global -> LDS by DMA (buffer_load_dwordx4 ... lds): one wave-instruction fills 1 KiB = 8 tile rows x 128 B,
     // lane i landing at (row i>>3, 16-byte slot i&7).  The XOR swizzle of the LDS image is therefore applied to the
@@ -273,6 +281,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
     const int lrow8 = lane >> 3;
     const int slot = lane & 7;
     unsigned a_off[A_ISS];  // byte offset of (b, iy0, ix0, coff) of this lane's row in issue j
+    unsigned a_off2[A_ISS]; // same row in the second source (OOB when the row is past M)
     int a_iy[A_ISS], a_ix[A_ISS], a_kc[A_ISS];
 #pragma unroll
     for (int j = 0; j < A_ISS; ++j) {
@@ -290,6 +299,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
         a_ix[j] = ix;
         a_off[j] = (unsigned)(((long)b * p.sB + (long)iy * p.sH + (long)ix * p.sW + x_coff) * ES);
         a_kc[j] = (slot ^ swz_key(lrow)) * VEC;
+        a_off2[j] = ok ? (unsigned)(((long)b * p.sB2 + (long)oy * p.st2 * p.sH2 + (long)ox * p.st2 * p.sW2 + p.coff2) * ES) : OOB;
     }
     unsigned w_off[B_ISS];
 #pragma unroll
@@ -298,20 +308,29 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
         w_off[j] = (unsigned)(((long)(n_base + lrow) * p.K + (slot ^ swz_key(lrow)) * VEC) * ES);
     }
     int kc = 0, kx = 0, ky = 0;  // (channel, tap) of the first element of the current K-step
+    int kdone = 0;               // K elements issued so far (selects the second A source once >= K1)
 
 #define AVCER_ISSUE_TILES(buf)                                                                                      \
     do {                                                                                                            \
         char* sa_ = smem + (buf) * TILE_BYTES + wave * (A_ISS * 1024);                                              \
         char* sb_ = smem + (buf) * TILE_BYTES + BM * ROWB + wave * (B_ISS * 1024);                                  \
-        _Pragma("unroll") for (int j = 0; j < A_ISS; ++j) {                                                         \
-            int kk = kc + a_kc[j], kxx = kx, kyy = ky;                                                              \
-            if (kk >= p.Cin) { kk -= p.Cin; if (++kxx == p.KW) { kxx = 0; ++kyy; } }                                \
-            const int dy = kyy * p.dh, dx = kxx * p.dw;                                                             \
-            const int iy = a_iy[j] + dy, ix = a_ix[j] + dx;                                                         \
-            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd && p.ablate < 2;          \
-            const unsigned vo = a_off[j] + (unsigned)(((long)dy * p.sH + (long)dx * p.sW + kk) * ES);               \
-            dma16(xrs, sa_ + j * 1024, ok ? vo : OOB);                                                             \
+        if (kdone >= p.K1) {                                                                                        \
+            _Pragma("unroll") for (int j = 0; j < A_ISS; ++j) {                                                     \
+                const unsigned vo = a_off2[j] + (unsigned)((kdone - p.K1 + a_kc[j]) * ES);                          \
+                dma16(x2rs, sa_ + j * 1024, (a_off2[j] != OOB && p.ablate < 2) ? vo : OOB);                         \
+            }                                                                                                       \
+        } else {                                                                                                    \
+            _Pragma("unroll") for (int j = 0; j < A_ISS; ++j) {                                                     \
+                int kk = kc + a_kc[j], kxx = kx, kyy = ky;                                                          \
+                if (kk >= p.Cin) { kk -= p.Cin; if (++kxx == p.KW) { kxx = 0; ++kyy; } }                            \
+                const int dy = kyy * p.dh, dx = kxx * p.dw;                                                         \
+                const int iy = a_iy[j] + dy, ix = a_ix[j] + dx;                                                     \
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd && p.ablate < 2;      \
+                const unsigned vo = a_off[j] + (unsigned)(((long)dy * p.sH + (long)dx * p.sW + kk) * ES);           \
+                dma16(xrs, sa_ + j * 1024, ok ? vo : OOB);                                                          \
+            }                                                                                                       \
         }                                                                                                           \
+        kdone += BK;                                                                                                \
         _Pragma("unroll") for (int j = 0; j < B_ISS; ++j) {                                                         \
             dma16(wrs, sb_ + j * 1024, p.ablate < 2 ? w_off[j] : OOB);                                             \
             w_off[j] += ROWB;                                                                                       \
@@ -431,7 +450,9 @@ template <int MODE, int OUT>
 void launch_t(const GemmParams& p0, hipStream_t st) {
     GemmParams p = p0;
     const int ntm = (p.M + BM - 1) / BM;
-    if (p.N % 128 == 0) {
+    // K <= bn64_max_k: bandwidth-bound 1x1 convolutions; the 48 KiB BN=64 tile lets three blocks share a CU
+    static const int bn64_max_k = getenv("AVCER_GEMM_BN64_MAXK") ? atoi(getenv("AVCER_GEMM_BN64_MAXK")) : 128;
+    if (p.N % 128 == 0 && p.K > bn64_max_k) {
         p.ntn = p.N / 128;
         p.nwg = ntm * p.ntn;
         conv_gemm_kernel<MODE, OUT, 128><<<dim3(p.nwg, p.groups), dim3(256), 0, st>>>(p);
@@ -445,14 +466,19 @@ void launch_t(const GemmParams& p0, hipStream_t st) {
 }  // namespace
 
 int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const void* x, const void* w,
-                     const float* scale, const float* bias, const void* residual, void* y, hipStream_t st) {
+                     const float* scale, const float* bias, const void* residual, void* y, hipStream_t st,
+                     const void* x2) {
     if (dtype < 0 || dtype > 6) return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d", dtype);
     const int es = (dtype == 1 || dtype == 2) ? 2 : 4;
     const bool a_split = dtype == 5 || dtype == 6, o_split = dtype == 4 || dtype == 5;
     const int vec = 16 / es;
     const int bk = ROWB / es;  // 32 elements (f32, split-bf16) or 64 (bf16) per K-step
     const long M = (long)d.batch * d.out_h * d.out_w;
-    const long K = (long)d.kh * d.kw * d.cin;
+    const long K1 = (long)d.kh * d.kw * d.cin;
+    const long K = K1 + (x2 ? d.x2_cin : 0);
+    if (x2 && (d.kh != 1 || d.kw != 1 || d.pad_h || d.pad_w || d.groups > 1 || d.x2_cin <= 0 || K1 % bk || d.x2_cin % bk ||
+               d.x2_stride < 1 || d.x2_coff % vec || d.x2_stride_b % vec || d.x2_stride_h % vec || d.x2_stride_w % vec))
+        return set_err(ctx, AVCER_EINVAL, "conv_gemm: a second A source needs two 1x1 convolutions with K multiples of %d", bk);
     if (M <= 0 || M > 0x7fffff00L) return set_err(ctx, AVCER_EINVAL, "conv_gemm: M=%ld out of range", M);
     if (d.n <= 0 || d.n % 64) return set_err(ctx, AVCER_EINVAL, "conv_gemm: N=%d must be a multiple of 64", d.n);
     if (K % bk) return set_err(ctx, AVCER_EINVAL, "conv_gemm: K=%ld must be a multiple of %d", K, bk);
@@ -463,6 +489,8 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
     const int ovec = o_split ? 32 : 16 / ((dtype == 1) ? 2 : 4);  // 16-byte vectors / whole sp32 groups
     if (d.y_ld % ovec || d.y_coff % ovec || (residual && (d.r_ld % ovec || d.r_coff % ovec)))
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: output/residual leading dims and offsets must be multiples of %d", ovec);
+    if (a_split && x2 && (d.x2_cin % 32 || d.x2_coff % 32 || d.x2_stride_b % 32 || d.x2_stride_h % 32 || d.x2_stride_w % 32))
+        return set_err(ctx, AVCER_EINVAL, "conv_gemm: sp32 second source needs cin/coff/strides in whole groups of 32");
     if (a_split && (d.cin % 32 || d.x_coff % 32 || d.x_stride_b % 32 || d.x_stride_h % 32 || d.x_stride_w % 32))
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: sp32 activations need cin/coff/strides in whole groups of 32");
     if (!x || !w || !y) return set_err(ctx, AVCER_EINVAL, "conv_gemm: null pointer");
@@ -483,6 +511,14 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: operand larger than 4 GiB (%ld / %ld bytes): split the batch", x_extent,
                        w_extent);
     p.x_bytes = (unsigned)x_extent; p.w_bytes = (unsigned)w_extent;
+    p.X2 = (const char*)x2; p.x2_bytes = 0; p.K1 = (int)K; p.sB2 = p.sH2 = p.sW2 = 0; p.coff2 = 0; p.st2 = 1;
+    if (x2) {
+        const long x2_extent = ((long)(d.batch - 1) * d.x2_stride_b + (long)(d.out_h - 1) * d.x2_stride * d.x2_stride_h +
+                                (long)(d.out_w - 1) * d.x2_stride * d.x2_stride_w + d.x2_coff + d.x2_cin) * es;
+        if (x2_extent >= (long)OOB) return set_err(ctx, AVCER_EINVAL, "conv_gemm: second source larger than 4 GiB");
+        p.x2_bytes = (unsigned)x2_extent; p.K1 = (int)K1;
+        p.sB2 = d.x2_stride_b; p.sH2 = d.x2_stride_h; p.sW2 = d.x2_stride_w; p.coff2 = d.x2_coff; p.st2 = d.x2_stride;
+    }
     p.ntn = 0; p.nwg = 0; p.groups = groups;
     static const int ablate = getenv("AVCER_GEMM_ABLATE") ? atoi(getenv("AVCER_GEMM_ABLATE")) : 0;
     p.ablate = ablate;

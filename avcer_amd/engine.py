@@ -216,6 +216,10 @@ class Engine:
         self._check(self.lib.avcer_split_weights(self.ctx, _ptr(w), _ptr(out), w.numel(), self._stream()))
         return out
 
+    def conv_gemm_dual(self, desc: ConvDesc, dtype: int, x, x2, w, scale, bias, residual, y):
+        self._check(self.lib.avcer_conv_gemm_dual(self.ctx, C.byref(desc), dtype, _ptr(x), _ptr(x2), _ptr(w), _ptr(scale),
+                                                  _ptr(bias), _ptr(residual), _ptr(y), self._stream()))
+
     def gemm_stats(self, reset: bool = True):
         n, f = C.c_int64(0), C.c_double(0.0)
         self._check(self.lib.avcer_gemm_stats(self.ctx, C.byref(n), C.byref(f), int(reset)))

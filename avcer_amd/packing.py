@@ -6,6 +6,7 @@ same way as the synthetic ones.  Layout transforms done here (all in float32 num
   * conv weights OIHW -> [O][kh][kw][I] (K contiguous, matches the NHWC gather order of the kernel);
   * inference BatchNorm folded into per-channel (scale, bias) applied in the GEMM epilogue;
   * the 7x7 stem packed as 8 tap rows x (8 pixels x 4 channels) with zero taps (see kernels.hip preprocess);
+  * conv3 and the downsample conv of the first block of every ResNet stage concatenated along K (one dual-source GEMM);
   * LSTM bias_ih + bias_hh summed; q/k/v projection matrices concatenated into one [3E, E] GEMM;
   * wav2vec2 positional-conv weight-norm materialised (w = g * v / ||v||, norm over dims 0,1) and split per group.
 
@@ -68,8 +69,13 @@ def pack_static(sd) -> "OrderedDict[str, np.ndarray]":
                 out[f"{dst}.c{i}.w"] = _conv_w(sd[f"{src}.conv{i}.weight"])
                 out[f"{dst}.c{i}.s"], out[f"{dst}.c{i}.b"] = _bn_fold(sd, f"{src}.batch_norm{i}", STATIC_BN_EPS)
             if b == 0:
-                out[f"{dst}.ds.w"] = _conv_w(sd[f"{src}.i_downsample.0.weight"])
-                out[f"{dst}.ds.s"], out[f"{dst}.ds.b"] = _bn_fold(sd, f"{src}.i_downsample.1", STATIC_BN_EPS)
+                # relu(bn3(conv3(t2)) + bn_d(conv_d(x))) as ONE contraction over K = [t2 | x strided]: the two BN scales
+                # are folded into the weight rows (scale 1 in the epilogue), the two BN shifts are summed
+                wd = _conv_w(sd[f"{src}.i_downsample.0.weight"])
+                s_d, b_d = _bn_fold(sd, f"{src}.i_downsample.1", STATIC_BN_EPS)
+                w3, s3, b3 = out.pop(f"{dst}.c3.w"), out.pop(f"{dst}.c3.s"), out.pop(f"{dst}.c3.b")
+                out[f"{dst}.c3d.w"] = np.ascontiguousarray(np.concatenate([w3 * s3[:, None], wd * s_d[:, None]], axis=1))
+                out[f"{dst}.c3d.b"] = (b3 + b_d).astype(np.float32)
     out["fc1.w"], out["fc1.b"] = _f32(sd["fc1.weight"]), _f32(sd["fc1.bias"])
     out["fc2.w"], out["fc2.b"] = _f32(sd["fc2.weight"]), _f32(sd["fc2.bias"])
     return out

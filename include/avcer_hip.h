@@ -147,10 +147,19 @@ typedef struct avcer_conv_desc {
     int32_t groups;                  /* 0/1 = plain; G > 1 = grouped convolution in ONE launch: group g reads input
                                         channels x_coff + g*cin, uses weight rows [g*n, (g+1)*n) of w (and scale/bias
                                         entries g*n..), and writes / adds channels y_coff + g*n, r_coff + g*n */
+    /* Optional second A source for avcer_conv_gemm_dual (two fused 1x1 convolutions, e.g. ResNet conv3 + downsample):
+     * K elements [kh*kw*cin, kh*kw*cin + x2_cin) of every row come from x2 at position (oy*x2_stride, ox*x2_stride). */
+    int32_t x2_cin, x2_coff, x2_stride;
+    int64_t x2_stride_b, x2_stride_h, x2_stride_w;
 } avcer_conv_desc;
 
 int avcer_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, const void* x, const void* w,
                     const float* scale, const float* bias, const void* residual, void* y, avcer_stream_t stream);
+
+/* Same contraction with a second activation tensor supplying the tail of K (see avcer_conv_desc.x2_*); w is
+ * [n][kh*kw*cin + x2_cin].  Both sources must be 1x1 / unpadded. */
+int avcer_conv_gemm_dual(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, const void* x, const void* x2, const void* w,
+                         const float* scale, const float* bias, const void* residual, void* y, avcer_stream_t stream);
 
 /* Weight layout of dtype 3: for every group of 32 K-elements, 32 bf16 "hi" values then 32 bf16 "lo" values with
  * w = hi + lo (+ O(2^-17 |w|)).  w f32 [n*k] (k a multiple of 32) -> out, same size in bytes. Both device pointers. */
@@ -168,7 +177,7 @@ int avcer_profile_read(avcer_ctx* ctx, double* total_ms, int64_t* launches);
 
 /* Debug aid for parity tests: arm a one-shot tap; the next forward pass copies up to `bytes` raw bytes of the
  * named intermediate activation (first sub-batch) into dst_dev.  Names: static "pre", "stem_conv", "stem",
- * "l1b0_c1", "l1b0_c2", "l1b0_ds", "l1b0", "layer1".."layer4", "avgpool"; audio "norm", "conv0", "extract", "proj",
+ * "l1b0_c1", "l1b0_c2", "l1b0", "layer1".."layer4", "avgpool"; audio "norm", "conv0", "extract", "proj",
  * "posconv", "layer0".."layer11", "w2v", "tl1", "tl2", "td0", "mp", "td4", "pooled".  Activations are NHWC / time-major,
  * f32 in AVCER_MODE_FP32 and bf16 in AVCER_MODE_BF16 (residual streams "proj".."tl2" and the head are always f32).
  * avcer_debug_tap_copied returns the number of bytes copied (-1 if the tap did not fire). */

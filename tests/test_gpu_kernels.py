@@ -13,7 +13,8 @@ def _desc(**kw):
     d = ConvDesc()
     base = dict(batch=1, in_h=1, in_w=1, out_h=1, out_w=1, cin=32, kh=1, kw=1, stride_h=1, stride_w=1, pad_h=0, pad_w=0,
                 dil_h=1, dil_w=1, x_stride_b=0, x_stride_h=0, x_stride_w=0, x_coff=0, n=64, y_ld=64, y_coff=0, r_ld=64,
-                r_coff=0, act=0, res_after_act=0, groups=0)
+                r_coff=0, act=0, res_after_act=0, groups=0, x2_cin=0, x2_coff=0, x2_stride=0, x2_stride_b=0, x2_stride_h=0,
+                x2_stride_w=0)
     base.update(kw)
     for k, v in base.items():
         setattr(d, k, int(v))
@@ -223,3 +224,31 @@ def test_grouped_launch_matches_grouped_conv1d(engine, dtype):
                    groups=groups)[:, :, :s]
     ref = F.gelu(ref).permute(0, 2, 1) + rd
     assert (y.double() - ref).abs().max() < _tol(dtype, ref)
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 3, 5])
+def test_dual_source_fused_1x1(engine, dtype):
+    """ResNet block 0: relu(conv3(T2) + downsample(X, stride 2)) as ONE contraction over K = [T2 | X strided]."""
+    b, h, p_, cin, n, st = 2, 14, 64, 128, 256, 2
+    oh = (h - 1) // st + 1
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(b, h, h, cin, generator=g)            # block input (downsample source)
+    t2 = torch.randn(b, oh, oh, p_, generator=g)          # conv2 output (conv3 source)
+    w3 = torch.randn(n, p_, generator=g) / p_ ** 0.5
+    wd = torch.randn(n, cin, generator=g) / cin ** 0.5
+    bias = torch.randn(n, generator=g)
+    w = torch.cat([w3, wd], dim=1)
+    d = _desc(batch=b, in_h=oh, in_w=oh, out_h=oh, out_w=oh, cin=p_, x_stride_b=oh * oh * p_, x_stride_h=oh * p_, x_stride_w=p_,
+              n=n, y_ld=n, r_ld=n, act=1, x2_cin=cin, x2_stride=st, x2_stride_b=h * h * cin, x2_stride_h=h * cin, x2_stride_w=cin)
+    dev = engine.device
+    ak, ok = A_KIND[dtype], O_KIND[dtype]
+    xd, td = _enc(x, ak, dev), _enc(t2, ak, dev)
+    wdv = w.to(dev, torch.bfloat16 if ak == "bf16" else torch.float32).contiguous()
+    w_arg = engine.split_weights(wdv) if dtype >= 3 else wdv
+    yd = _enc(torch.zeros(b, oh, oh, n), ok, dev)
+    engine.conv_gemm_dual(d, dtype, td, xd, w_arg, None, bias.to(dev), None, yd)
+    torch.cuda.synchronize()
+    xs = _dec(xd, ak).double()[:, ::st, ::st, :]
+    ref = F.relu(_dec(td, ak).double() @ wdv.double().cpu()[:, :p_].t() + xs @ wdv.double().cpu()[:, p_:].t() + bias.double())
+    got = _dec(yd, ok).double()
+    assert (got - ref).abs().max() < _tol(dtype, ref)

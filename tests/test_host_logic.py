@@ -81,12 +81,15 @@ def test_pack_static_layouts(sd_static):
     np.testing.assert_array_equal(c2, sd_static["layer2.1.conv2.weight"].numpy().transpose(0, 2, 3, 1))
     # BN fold: scale * x + bias == batch_norm(x)
     x = torch.randn(4, 256, 3, 3)
-    p = "layer1.0.batch_norm3"
+    p = "layer1.1.batch_norm3"
     ref = torch.nn.functional.batch_norm(x, sd_static[p + ".running_mean"], sd_static[p + ".running_var"],
                                          sd_static[p + ".weight"], sd_static[p + ".bias"], False, 0.0, 1e-3)
-    got = x * torch.from_numpy(t["l1.0.c3.s"])[None, :, None, None] + torch.from_numpy(t["l1.0.c3.b"])[None, :, None, None]
+    got = x * torch.from_numpy(t["l1.1.c3.s"])[None, :, None, None] + torch.from_numpy(t["l1.1.c3.b"])[None, :, None, None]
     assert (ref - got).abs().max() < 1e-5
-    assert len(t) == 1 * 3 + 16 * 9 + 4 * 3 + 4
+    assert len(t) == 1 * 3 + 16 * 9 - 4 * 3 + 4 * 2 + 4  # block 0 of each stage: c3 + downsample fused into c3d.{w,b}
+    w3 = sd_static["layer2.0.conv3.weight"].numpy()[:, :, 0, 0]
+    assert t["l2.0.c3d.w"].shape == (512, 128 + 256)
+    np.testing.assert_allclose(t["l2.0.c3d.w"][:, :128] / w3, np.broadcast_to((t["l2.0.c3d.w"][:, :1] / w3[:, :1]), w3.shape), rtol=1e-5)
 
 
 def test_pack_audio_layouts(sd_audio):
