@@ -74,8 +74,6 @@ int set_err(avcer_ctx* ctx, int code, const char* fmt, ...);
     } while (0)
 
 int ws_reserve(avcer_ctx* ctx, int slot, size_t bytes, void** out);
-const Tensor* find_tensor(avcer_ctx* ctx, const Model& m, const char* name);
-int ensure_bf16(avcer_ctx* ctx, Model& m, const char* name);
 
 // ---- gemm.hip
 int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const void* x, const void* w,

@@ -62,7 +62,8 @@ struct GemmParams {
     long ldR;
     int roff;
     int act, res_after;
-    int ntn, nwg;
+    int ntn, ntm, nwg;
+    int gm;  // m-tiles per group of the grouped block order (0 = plain n-fastest order)
     int groups;  // grid.y: group g shifts coff / yoff / roff by g*Cin / g*N and the weight/scale/bias rows by g*N
     int ablate;  // test-only (env AVCER_GEMM_ABLATE): 1 = skip MFMA, 2 = skip DMA loads, 4 = skip the x3 operand split
 };
@@ -259,8 +260,20 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
         const int xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_n = bid % p.ntn;
-    const int tile_m = bid / p.ntn;
+    // Grouped order: gm m-tiles x all n-tiles form a group that is swept n-major, so the ~64 blocks an XCD runs at
+    // a time share BOTH their activation slabs (across n) and their weight slabs (across m) in its 4 MiB L2.
+    int tile_n, tile_m;
+    if (p.gm > 1) {
+        const int per_group = p.gm * p.ntn;
+        const int group = bid / per_group, within = bid - group * per_group;
+        const int first_m = group * p.gm;
+        const int gsize = min(p.gm, p.ntm - first_m);
+        tile_m = first_m + within % gsize;
+        tile_n = within / gsize;
+    } else {
+        tile_n = bid % p.ntn;
+        tile_m = bid / p.ntn;
+    }
     const int m_base = tile_m * BM;
     const int grp = blockIdx.y;
     const int n_base = grp * p.N + tile_n * BN;  // row of W / entry of scale, bias; output channel = yoff + n_base
@@ -452,6 +465,9 @@ void launch_t(const GemmParams& p0, hipStream_t st) {
     const int ntm = (p.M + BM - 1) / BM;
     // K <= bn64_max_k: bandwidth-bound 1x1 convolutions; the 48 KiB BN=64 tile lets three blocks share a CU
     static const int bn64_max_k = getenv("AVCER_GEMM_BN64_MAXK") ? atoi(getenv("AVCER_GEMM_BN64_MAXK")) : 128;
+    static const int gm_env = getenv("AVCER_GEMM_GM") ? atoi(getenv("AVCER_GEMM_GM")) : 8;
+    p.ntm = ntm;
+    p.gm = gm_env;
     if (p.N % 128 == 0 && p.K > bn64_max_k) {
         p.ntn = p.N / 128;
         p.nwg = ntm * p.ntn;

@@ -86,3 +86,40 @@ def test_full_av_clips_match_oracle(engine, sd_static, sd_dynamic, sd_audio):
             top = np.take_along_axis(prob, am[..., None], 2)[..., 0]
             alt = np.take_along_axis(prob, got_am[..., None].astype(np.int64), 2)[..., 0]
             assert np.abs(top - alt)[bad].max() < 1e-4
+
+
+def test_full_size_batch_properties_x3(engine, sd_static, sd_dynamic, sd_audio):
+    """BASELINE config 4/5 per-GPU size (128 clips = 2048 frames + 128 windows) in the headline arithmetic mode:
+    determinism, independence of batch composition (a clip's record does not depend on its neighbours or position),
+    probabilities normalised, and agreement of a sample of clips with the oracle within the 1e-4 gate."""
+    from avcer_amd.engine import MODE_BF16X3
+    from avcer_amd.pipeline import AVPipeline
+
+    pipe = AVPipeline.__new__(AVPipeline)
+    pipe.engine, pipe.mode = engine, MODE_BF16X3
+    engine.load_static(sd_static); engine.load_dynamic(sd_dynamic); engine.load_audio(sd_audio)
+    n, t = 128, 16
+    frames = torch.from_numpy(synth.face_frames(31337, n * t).reshape(n, t, 224, 224, 3)).to(engine.device)
+    wav = torch.from_numpy(synth.waveforms(31338, n, 32000)).to(engine.device)
+    a = pipe.run_clips(frames, wav, 25)
+    b = pipe.run_clips(frames, wav, 25)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(1)).to(engine.device)
+    c = pipe.run_clips(frames[perm], wav[perm], 25)
+    assert torch.equal(c["static_probs"], a["static_probs"][perm])
+    assert torch.equal(c["dynamic_logits"], a["dynamic_logits"][perm])
+    assert torch.equal(c["audio_logits"], a["audio_logits"][perm])
+    assert torch.equal(c["compound_argmax"], a["compound_argmax"][:, perm])
+    sub = pipe.run_clips(frames[40:43], wav[40:43], 25)
+    assert torch.equal(sub["static_probs"], a["static_probs"][40:43])
+    assert torch.equal(sub["audio_logits"], a["audio_logits"][40:43])
+    p = a["static_probs"]
+    assert torch.isfinite(p).all() and (p.sum(-1) - 1).abs().max() < 1e-5
+    for c_ in (0, 77, 127):
+        st, dy = ov.visual_forward(sd_static, sd_dynamic, frames[c_].cpu().numpy(), np.ones(t, bool), 25, batched=True)
+        assert np.abs(a["static_probs"][c_].cpu().numpy() - st).max() < 1e-4
+        with torch.no_grad():
+            lg = oa.expr_model_v3_forward(sd_audio, torch.from_numpy(oa.normalize(wav[c_:c_ + 1].cpu().numpy()))).numpy().reshape(1, 8)
+        d = np.abs(of.softmax(a["audio_logits"][c_:c_ + 1, :7].cpu().numpy()) - of.softmax(lg[:, :7])).max()
+        assert d < 1e-4
