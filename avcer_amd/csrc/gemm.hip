@@ -238,8 +238,94 @@ __device__ __forceinline__ void split8(const float4 x, const float4 y, bf16x8_t&
 // results (relative error ~2^-17 per product) at a third of the bf16 MFMA rate instead of a sixteenth.
 // MODE 3: as MODE 2 but the activations are ALREADY stored as sp32 pairs (written by a producer's epilogue), so the
 // A fragments are read like the weights and the main loop has no conversion arithmetic at all.
-template <int MODE, int OUT, int BN>
-__global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
+template <int MODE, int BN, int TILE_BYTES, typename AccT, int NFN, int NFM>
+__device__ __forceinline__ void mfma_step(const GemmParams& p, const char* smem, int cur, AccT (&acc)[NFN][NFM], int wm, int wn,
+                                      int lane) {
+    constexpr bool IS_F32 = MODE == 0;
+    constexpr int WN = BN / 2;
+    const char* sa = smem + cur * TILE_BYTES;
+    const char* sb = sa + BM * ROWB;
+    if (p.ablate == 1) {
+        // ablation: no fragment reads / MFMA
+    } else if constexpr (IS_F32) {
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            const int ch = kq * 2 + (lane >> 5);
+            float4 af[NFM], wf[NFN];
+#pragma unroll
+            for (int fm = 0; fm < NFM; ++fm)
+                af[fm] = *reinterpret_cast<const float4*>(sa + swz(wm * 64 + fm * 32 + (lane & 31), ch));
+#pragma unroll
+            for (int fn = 0; fn < NFN; ++fn)
+                wf[fn] = *reinterpret_cast<const float4*>(sb + swz(wn * WN + fn * 32 + (lane & 31), ch));
+#pragma unroll
+            for (int fn = 0; fn < NFN; ++fn)
+#pragma unroll
+                for (int fm = 0; fm < NFM; ++fm) {
+                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[fn].x, af[fm].x, acc[fn][fm], 0, 0, 0);
+                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[fn].y, af[fm].y, acc[fn][fm], 0, 0, 0);
+                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[fn].z, af[fm].z, acc[fn][fm], 0, 0, 0);
+                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[fn].w, af[fm].w, acc[fn][fm], 0, 0, 0);
+                }
+        }
+    } else if constexpr (MODE == 2 || MODE == 3) {
+        const int g = lane >> 4;
+        bf16x8_t ahi[NFM], alo[NFM];
+#pragma unroll
+        for (int fm = 0; fm < NFM; ++fm) {
+            const int row = wm * 64 + fm * 16 + (lane & 15);
+            if constexpr (MODE == 3) {
+                ahi[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, g));
+                alo[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, 4 + g));
+                continue;
+            }
+            const float4 x = *reinterpret_cast<const float4*>(sa + swz(row, 2 * g));
+            const float4 y = *reinterpret_cast<const float4*>(sa + swz(row, 2 * g + 1));
+            if (p.ablate == 4) {  // timing only: reinterpret instead of splitting
+                ahi[fm] = __builtin_bit_cast(bf16x8_t, x);
+                alo[fm] = __builtin_bit_cast(bf16x8_t, y);
+            } else {
+                split8(x, y, ahi[fm], alo[fm]);
+            }
+        }
+#pragma unroll
+        for (int fn = 0; fn < NFN; ++fn) {
+            const int row = wn * WN + fn * 16 + (lane & 15);
+            const bf16x8_t whi = *reinterpret_cast<const bf16x8_t*>(sb + swz(row, g));
+            const bf16x8_t wlo = *reinterpret_cast<const bf16x8_t*>(sb + swz(row, 4 + g));
+#pragma unroll
+            for (int fm = 0; fm < NFM; ++fm) {
+                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, ahi[fm], acc[fn][fm], 0, 0, 0);
+                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, alo[fm], acc[fn][fm], 0, 0, 0);
+                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, ahi[fm], acc[fn][fm], 0, 0, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ks * 4 + (lane >> 4);
+            bf16x8_t af[NFM], wf[NFN];
+#pragma unroll
+            for (int fm = 0; fm < NFM; ++fm)
+                af[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(wm * 64 + fm * 16 + (lane & 15), ch));
+#pragma unroll
+            for (int fn = 0; fn < NFN; ++fn)
+                wf[fn] = *reinterpret_cast<const bf16x8_t*>(sb + swz(wn * WN + fn * 16 + (lane & 15), ch));
+#pragma unroll
+            for (int fn = 0; fn < NFN; ++fn)
+#pragma unroll
+                for (int fm = 0; fm < NFM; ++fm)
+                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], af[fm], acc[fn][fm], 0, 0, 0);
+        }
+    }
+}
+
+// LW = number of dedicated loader waves (0, or 4 as an opt-in experiment).  With LW = 4 the block has 8 waves: waves 0-3
+// only read fragments and issue MFMAs, waves 4-7 only issue the LDS-DMA of the next K-step (an LDS-DMA instruction costs its issuing wave
+// ~100 cycles inside a busy phase -- MI355X_MICROARCH.md, 'LDS-DMA piece issue cost' -- and eight of them per K-step
+// rival the MFMA time of a 64x64 wave tile).
+template <int MODE, int OUT, int BN, int LW>
+__global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kernel(const GemmParams p) {
     constexpr bool IS_F32 = MODE == 0;
     constexpr int ES = MODE == 1 ? 2 : 4;
     constexpr int VEC = 16 / ES;
@@ -250,8 +336,11 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
+    constexpr int NDW = LW ? LW : 4;                  // waves that issue DMA
+    const bool is_loader = LW > 0 && wave >= 4;       // wave-uniform
+    const int dw = LW ? (wave - 4) & (NDW - 1) : wave;  // index among the DMA-issuing waves
 
     // XCD-aware bijective remap: blocks b and b+8 share an XCD (speed only, never correctness)
     int bid = blockIdx.x;
@@ -289,44 +378,43 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
     // lane i landing at (row i>>3, 16-byte slot i&7).  The XOR swizzle of the LDS image is therefore applied to the
     // SOURCE: lane i fetches data chunk c = slot ^ ((row>>1)&7) of its row.  Padding taps / rows past M use an
     // out-of-range offset, for which the buffer load writes zeros.
-    constexpr int A_ISS = BM / 32;  // DMA instructions per wave per K-step for the A tile
-    constexpr int B_ISS = BN / 32;
+    constexpr int A_ISS = BM / 8 / NDW;  // DMA instructions per issuing wave per K-step for the A tile
+    constexpr int B_ISS = BN / 8 / NDW;
     const int lrow8 = lane >> 3;
     const int slot = lane & 7;
-    unsigned a_off[A_ISS];  // byte offset of (b, iy0, ix0, coff) of this lane's row in issue j
-    unsigned a_off2[A_ISS]; // same row in the second source (OOB when the row is past M)
-    int a_iy[A_ISS], a_ix[A_ISS], a_kc[A_ISS];
-#pragma unroll
-    for (int j = 0; j < A_ISS; ++j) {
-        const int lrow = wave * (A_ISS * 8) + j * 8 + lrow8;
-        const int m = m_base + lrow;
-        const bool ok = m < p.M;
-        const int mm = ok ? m : 0;
-        const int ox = mm % p.OW;
-        const int t = mm / p.OW;
-        const int oy = t % p.OH;
-        const int b = t / p.OH;
-        const int iy = oy * p.sh - p.ph;
-        const int ix = ox * p.sw - p.pw;
-        a_iy[j] = ok ? iy : -(1 << 28);  // rows past M fail the bounds test below
-        a_ix[j] = ix;
-        a_off[j] = (unsigned)(((long)b * p.sB + (long)iy * p.sH + (long)ix * p.sW + x_coff) * ES);
-        a_kc[j] = (slot ^ swz_key(lrow)) * VEC;
-        a_off2[j] = ok ? (unsigned)(((long)b * p.sB2 + (long)oy * p.st2 * p.sH2 + (long)ox * p.st2 * p.sW2 + p.coff2) * ES) : OOB;
-    }
-    unsigned w_off[B_ISS];
-#pragma unroll
-    for (int j = 0; j < B_ISS; ++j) {
-        const int lrow = wave * (B_ISS * 8) + j * 8 + lrow8;
-        w_off[j] = (unsigned)(((long)(n_base + lrow) * p.K + (slot ^ swz_key(lrow)) * VEC) * ES);
-    }
-    int kc = 0, kx = 0, ky = 0;  // (channel, tap) of the first element of the current K-step
-    int kdone = 0;               // K elements issued so far (selects the second A source once >= K1)
+#define AVCER_DMA_SETUP()                                                                                           \
+    unsigned a_off[A_ISS];                                                                                          \
+    unsigned a_off2[A_ISS];                                                                                         \
+    int a_iy[A_ISS], a_ix[A_ISS], a_kc[A_ISS];                                                                      \
+    _Pragma("unroll") for (int j = 0; j < A_ISS; ++j) {                                                             \
+        const int lrow = dw * (A_ISS * 8) + j * 8 + lrow8;                                                          \
+        const int m = m_base + lrow;                                                                                \
+        const bool ok = m < p.M;                                                                                    \
+        const int mm = ok ? m : 0;                                                                                  \
+        const int ox = mm % p.OW;                                                                                   \
+        const int t = mm / p.OW;                                                                                    \
+        const int oy = t % p.OH;                                                                                    \
+        const int b = t / p.OH;                                                                                     \
+        const int iy = oy * p.sh - p.ph;                                                                            \
+        const int ix = ox * p.sw - p.pw;                                                                            \
+        a_iy[j] = ok ? iy : -(1 << 28);                                                                             \
+        a_ix[j] = ix;                                                                                               \
+        a_off[j] = (unsigned)(((long)b * p.sB + (long)iy * p.sH + (long)ix * p.sW + x_coff) * ES);                  \
+        a_kc[j] = (slot ^ swz_key(lrow)) * VEC;                                                                     \
+        a_off2[j] = ok ? (unsigned)(((long)b * p.sB2 + (long)oy * p.st2 * p.sH2 + (long)ox * p.st2 * p.sW2 + p.coff2) * ES) : OOB;\
+    }                                                                                                               \
+    unsigned w_off[B_ISS];                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < B_ISS; ++j) {                                                             \
+        const int lrow = dw * (B_ISS * 8) + j * 8 + lrow8;                                                          \
+        w_off[j] = (unsigned)(((long)(n_base + lrow) * p.K + (slot ^ swz_key(lrow)) * VEC) * ES);                   \
+    }                                                                                                               \
+    int kc = 0, kx = 0, ky = 0;                                                                                     \
+    int kdone = 0;
 
 #define AVCER_ISSUE_TILES(buf)                                                                                      \
     do {                                                                                                            \
-        char* sa_ = smem + (buf) * TILE_BYTES + wave * (A_ISS * 1024);                                              \
-        char* sb_ = smem + (buf) * TILE_BYTES + BM * ROWB + wave * (B_ISS * 1024);                                  \
+        char* sa_ = smem + (buf) * TILE_BYTES + dw * (A_ISS * 1024);                                                \
+        char* sb_ = smem + (buf) * TILE_BYTES + BM * ROWB + dw * (B_ISS * 1024);                                    \
         if (kdone >= p.K1) {                                                                                        \
             _Pragma("unroll") for (int j = 0; j < A_ISS; ++j) {                                                     \
                 const unsigned vo = a_off2[j] + (unsigned)((kdone - p.K1 + a_kc[j]) * ES);                          \
@@ -355,6 +443,33 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
         }                                                                                                           \
     } while (0)
 
+// A raw workgroup barrier that the compiler may not move LDS accesses across
+#define AVCER_MEET()                                                                                                \
+    do {                                                                                                            \
+        asm volatile("" ::: "memory");                                                                              \
+        __builtin_amdgcn_s_barrier();                                                                               \
+        asm volatile("" ::: "memory");                                                                              \
+    } while (0)
+
+    const int nk = p.K / BK;
+    int cur = 0;
+    if constexpr (LW > 0) {
+        if (is_loader) {
+            // loader role: nothing but DMA issue; one barrier per K-step, exactly like the MFMA waves below
+            AVCER_DMA_SETUP();
+            AVCER_ISSUE_TILES(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            AVCER_MEET();
+            for (int step = 0; step < nk; ++step) {
+                if (step + 1 < nk) AVCER_ISSUE_TILES(cur ^ 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                AVCER_MEET();
+                cur ^= 1;
+            }
+            return;  // the epilogue belongs to the four MFMA waves (barriers only count live waves)
+        }
+    }
+
     constexpr int NFN = IS_F32 ? WN / 32 : WN / 16;
     constexpr int NFM = IS_F32 ? 2 : 4;
     static_assert(MODE < 2 || OUT != 1, "split-bf16 modes write f32 or sp32");
@@ -365,91 +480,27 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int b = 0; b < NFM; ++b) acc[a][b] = acc_t{0};
 
-    const int nk = p.K / BK;
-    AVCER_ISSUE_TILES(0);
-    __syncthreads();  // hipcc puts the s_waitcnt vmcnt(0) of the in-flight DMA in front of the barrier
-    int cur = 0;
-    for (int step = 0; step < nk; ++step) {
-        if (step + 1 < nk) AVCER_ISSUE_TILES(cur ^ 1);  // next K-step lands while this one is multiplied
-        const char* sa = smem + cur * TILE_BYTES;
-        const char* sb = sa + BM * ROWB;
-        if (p.ablate == 1) {
-            // ablation: no fragment reads / MFMA
-        } else if constexpr (IS_F32) {
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) {
-                const int ch = kq * 2 + (lane >> 5);
-                float4 af[NFM], wf[NFN];
-#pragma unroll
-                for (int fm = 0; fm < NFM; ++fm)
-                    af[fm] = *reinterpret_cast<const float4*>(sa + swz(wm * 64 + fm * 32 + (lane & 31), ch));
-#pragma unroll
-                for (int fn = 0; fn < NFN; ++fn)
-                    wf[fn] = *reinterpret_cast<const float4*>(sb + swz(wn * WN + fn * 32 + (lane & 31), ch));
-#pragma unroll
-                for (int fn = 0; fn < NFN; ++fn)
-#pragma unroll
-                    for (int fm = 0; fm < NFM; ++fm) {
-                        acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[fn].x, af[fm].x, acc[fn][fm], 0, 0, 0);
-                        acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[fn].y, af[fm].y, acc[fn][fm], 0, 0, 0);
-                        acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[fn].z, af[fm].z, acc[fn][fm], 0, 0, 0);
-                        acc[fn][fm] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[fn].w, af[fm].w, acc[fn][fm], 0, 0, 0);
-                    }
-            }
-        } else if constexpr (MODE == 2 || MODE == 3) {
-            const int g = lane >> 4;
-            bf16x8_t ahi[NFM], alo[NFM];
-#pragma unroll
-            for (int fm = 0; fm < NFM; ++fm) {
-                const int row = wm * 64 + fm * 16 + (lane & 15);
-                if constexpr (MODE == 3) {
-                    ahi[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, g));
-                    alo[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, 4 + g));
-                    continue;
-                }
-                const float4 x = *reinterpret_cast<const float4*>(sa + swz(row, 2 * g));
-                const float4 y = *reinterpret_cast<const float4*>(sa + swz(row, 2 * g + 1));
-                if (p.ablate == 4) {  // timing only: reinterpret instead of splitting
-                    ahi[fm] = __builtin_bit_cast(bf16x8_t, x);
-                    alo[fm] = __builtin_bit_cast(bf16x8_t, y);
-                } else {
-                    split8(x, y, ahi[fm], alo[fm]);
-                }
-            }
-#pragma unroll
-            for (int fn = 0; fn < NFN; ++fn) {
-                const int row = wn * WN + fn * 16 + (lane & 15);
-                const bf16x8_t whi = *reinterpret_cast<const bf16x8_t*>(sb + swz(row, g));
-                const bf16x8_t wlo = *reinterpret_cast<const bf16x8_t*>(sb + swz(row, 4 + g));
-#pragma unroll
-                for (int fm = 0; fm < NFM; ++fm) {
-                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, ahi[fm], acc[fn][fm], 0, 0, 0);
-                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, alo[fm], acc[fn][fm], 0, 0, 0);
-                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, ahi[fm], acc[fn][fm], 0, 0, 0);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int ch = ks * 4 + (lane >> 4);
-                bf16x8_t af[NFM], wf[NFN];
-#pragma unroll
-                for (int fm = 0; fm < NFM; ++fm)
-                    af[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(wm * 64 + fm * 16 + (lane & 15), ch));
-#pragma unroll
-                for (int fn = 0; fn < NFN; ++fn)
-                    wf[fn] = *reinterpret_cast<const bf16x8_t*>(sb + swz(wn * WN + fn * 16 + (lane & 15), ch));
-#pragma unroll
-                for (int fn = 0; fn < NFN; ++fn)
-#pragma unroll
-                    for (int fm = 0; fm < NFM; ++fm)
-                        acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], af[fm], acc[fn][fm], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-        cur ^= 1;
+#define AVCER_MFMA_LOOP(ISSUE_NEXT, STEP_SYNC)                                                                      \
+    for (int step = 0; step < nk; ++step) {                                                                         \
+        ISSUE_NEXT;                                                                                                 \
+        mfma_step<MODE, BN, TILE_BYTES>(p, smem, cur, acc, wm, wn, lane);                                           \
+        STEP_SYNC;                                                                                                  \
+        cur ^= 1;                                                                                                   \
     }
+
+    if constexpr (LW > 0) {
+        AVCER_MEET();  // K-step 0 has landed
+        AVCER_MFMA_LOOP((void)0, AVCER_MEET())
+    } else {
+        AVCER_DMA_SETUP();
+        AVCER_ISSUE_TILES(0);
+        __syncthreads();  // hipcc puts the s_waitcnt vmcnt(0) of the in-flight DMA in front of the barrier
+        AVCER_MFMA_LOOP(if (step + 1 < nk) AVCER_ISSUE_TILES(cur ^ 1), __syncthreads())
+    }
+#undef AVCER_MFMA_LOOP
 #undef AVCER_ISSUE_TILES
+#undef AVCER_DMA_SETUP
+#undef AVCER_MEET
 
     // epilogue through LDS (the tile buffers are free: the loop ended on a barrier)
     stage_acc<MODE, BN>(p, smem, acc, n_base, wm, wn, lane);
@@ -459,6 +510,13 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
     else drain_stage<OUT, BN, 0>(p, smem, m_base, n_base, tid);
 }
 
+template <int MODE, int OUT, int LW>
+void launch_lw(GemmParams& p, hipStream_t st, bool bn128) {
+    constexpr int threads = 256 + 64 * LW;
+    if (bn128) conv_gemm_kernel<MODE, OUT, 128, LW><<<dim3(p.nwg, p.groups), dim3(threads), 0, st>>>(p);
+    else conv_gemm_kernel<MODE, OUT, 64, LW><<<dim3(p.nwg, p.groups), dim3(threads), 0, st>>>(p);
+}
+
 template <int MODE, int OUT>
 void launch_t(const GemmParams& p0, hipStream_t st) {
     GemmParams p = p0;
@@ -466,17 +524,17 @@ void launch_t(const GemmParams& p0, hipStream_t st) {
     // K <= bn64_max_k: bandwidth-bound 1x1 convolutions; the 48 KiB BN=64 tile lets three blocks share a CU
     static const int bn64_max_k = getenv("AVCER_GEMM_BN64_MAXK") ? atoi(getenv("AVCER_GEMM_BN64_MAXK")) : 128;
     static const int gm_env = getenv("AVCER_GEMM_GM") ? atoi(getenv("AVCER_GEMM_GM")) : 8;
+    // AVCER_GEMM_LW=4 (experiment, off by default): four dedicated loader waves per block.  Measured +3..9 % on
+    // MFMA-bound bf16 / sp32 layers, nothing for f32, and -1.4 % on the whole x3 pipeline (profiles/experiments).
+    static const int lw_env = getenv("AVCER_GEMM_LW") ? atoi(getenv("AVCER_GEMM_LW")) : 0;
+    const int lw = (lw_env == 4 && MODE != 2) ? 4 : 0;
     p.ntm = ntm;
     p.gm = gm_env;
-    if (p.N % 128 == 0 && p.K > bn64_max_k) {
-        p.ntn = p.N / 128;
-        p.nwg = ntm * p.ntn;
-        conv_gemm_kernel<MODE, OUT, 128><<<dim3(p.nwg, p.groups), dim3(256), 0, st>>>(p);
-    } else {
-        p.ntn = p.N / 64;
-        p.nwg = ntm * p.ntn;
-        conv_gemm_kernel<MODE, OUT, 64><<<dim3(p.nwg, p.groups), dim3(256), 0, st>>>(p);
-    }
+    const bool bn128 = p.N % 128 == 0 && p.K > bn64_max_k;
+    p.ntn = p.N / (bn128 ? 128 : 64);
+    p.nwg = ntm * p.ntn;
+    if (lw == 4) launch_lw<MODE, OUT, 4>(p, st, bn128);
+    else launch_lw<MODE, OUT, 0>(p, st, bn128);
 }
 
 }  // namespace
