@@ -22,6 +22,10 @@ class AVPipeline:
         self.static = StaticModel(self.engine, sds[0], mode)
         self.dynamic = DynamicModel(self.engine, sds[1])
         self.audio = AudioModel(self.engine, sds[2], mode) if sds[2] is not None else None
+        # The audio branch runs on its own HIP stream: its kernels are MFMA-bound while about half of the static CNN's
+        # are HBM-bound, so blocks of the two branches share CUs productively (each needs 64 KiB of the 160 KiB LDS).
+        self.overlap_branches = True
+        self._audio_stream = None
 
     def clip_records(self, frames_u8: torch.Tensor, wav: torch.Tensor, fps: float = 25, present=None):
         """frames_u8 [N,T,224,224,3], wav [N,L] (one window per clip).  Returns the per-clip record that is
@@ -29,8 +33,21 @@ class AVPipeline:
         n, t = int(frames_u8.shape[0]), int(frames_u8.shape[1])
         if present is None:
             present = np.ones((n, t), dtype=bool)
+        if not getattr(self, "overlap_branches", False):
+            stat, dyn = visual_forward(self.engine, frames_u8, present, fps, self.mode)
+            aud = self.engine.audio_forward(wav, normalize=True, mode=self.mode)
+            return stat, dyn, aud
+        dev = self.engine.device
+        main = torch.cuda.current_stream(dev)
+        if getattr(self, "_audio_stream", None) is None:
+            self._audio_stream = torch.cuda.Stream(dev)
+        side = self._audio_stream
+        side.wait_stream(main)  # the inputs were produced on the caller's stream
+        with torch.cuda.stream(side):
+            aud = self.engine.audio_forward(wav, normalize=True, mode=self.mode)
         stat, dyn = visual_forward(self.engine, frames_u8, present, fps, self.mode)
-        aud = self.engine.audio_forward(wav, normalize=True, mode=self.mode)
+        main.wait_stream(side)
+        aud.record_stream(main)
         return stat, dyn, aud
 
     def fuse_records(self, stat, dyn, aud, weights_1=WEIGHTS_AV_1, weights_2=(1, 1, 1), ce_weights_type=False,
