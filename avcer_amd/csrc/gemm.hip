@@ -101,32 +101,46 @@ __device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(floa
 // same storage type as the output.
 __device__ __forceinline__ long sp32_byte(long e) { return ((e & ~31L) << 2) + ((e & 31L) << 1); }
 
+// Raw 16-byte words of the residual belonging to 8 consecutive channels of one position: {f32 x4, f32 x4},
+// {bf16 x8, -} or {sp32 hi x8, sp32 lo x8}.  They are fetched at kernel start (res_prefetch) so that the read overlaps
+// the DMA / MFMA phase instead of sitting in the epilogue.
+template <int OUT>
+__device__ __forceinline__ void res_load(const GemmParams& p, long m, int n0, uint4& r0, uint4& r1) {
+    const long e = m * p.ldR + p.roff + n0;
+    if constexpr (OUT == 0) {
+        const char* rp = p.R + e * 4;
+        r0 = *reinterpret_cast<const uint4*>(rp);
+        r1 = *reinterpret_cast<const uint4*>(rp + 16);
+    } else if constexpr (OUT == 1) {
+        r0 = *reinterpret_cast<const uint4*>(p.R + e * 2);
+        r1 = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        const char* rp = p.R + sp32_byte(e);
+        r0 = *reinterpret_cast<const uint4*>(rp);
+        r1 = *reinterpret_cast<const uint4*>(rp + 64);
+    }
+}
+
 template <int OUT, int ACT>
-__device__ __forceinline__ void finish8(const GemmParams& p, long m, int n0, const float4 a, const float4 b) {
+__device__ __forceinline__ void finish8(const GemmParams& p, long m, int n0, const float4 a, const float4 b, const uint4 r0,
+                                        const uint4 r1) {
     float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (p.R) {
-        const long e = m * p.ldR + p.roff + n0;
-        if constexpr (OUT == 0) {
-            const char* rp = p.R + e * 4;
-            const float4 t0 = *reinterpret_cast<const float4*>(rp);
-            const float4 t1 = *reinterpret_cast<const float4*>(rp + 16);
-            r[0] = t0.x; r[1] = t0.y; r[2] = t0.z; r[3] = t0.w; r[4] = t1.x; r[5] = t1.y; r[6] = t1.z; r[7] = t1.w;
-        } else if constexpr (OUT == 1) {
-            const uint4 t = *reinterpret_cast<const uint4*>(p.R + e * 2);
-            const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+    float r[8];
+    if constexpr (OUT == 0) {
+        r[0] = __builtin_bit_cast(float, r0.x); r[1] = __builtin_bit_cast(float, r0.y);
+        r[2] = __builtin_bit_cast(float, r0.z); r[3] = __builtin_bit_cast(float, r0.w);
+        r[4] = __builtin_bit_cast(float, r1.x); r[5] = __builtin_bit_cast(float, r1.y);
+        r[6] = __builtin_bit_cast(float, r1.z); r[7] = __builtin_bit_cast(float, r1.w);
+    } else if constexpr (OUT == 1) {
+        const uint32_t w[4] = {r0.x, r0.y, r0.z, r0.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { r[2 * j] = bf2f((bf16_t)(w[j] & 0xffff)); r[2 * j + 1] = bf2f((bf16_t)(w[j] >> 16)); }
-        } else {
-            const char* rp = p.R + sp32_byte(e);
-            const uint4 th = *reinterpret_cast<const uint4*>(rp);
-            const uint4 tl = *reinterpret_cast<const uint4*>(rp + 64);
-            const uint32_t wh[4] = {th.x, th.y, th.z, th.w}, wl[4] = {tl.x, tl.y, tl.z, tl.w};
+        for (int j = 0; j < 4; ++j) { r[2 * j] = bf2f((bf16_t)(w[j] & 0xffff)); r[2 * j + 1] = bf2f((bf16_t)(w[j] >> 16)); }
+    } else {
+        const uint32_t wh[4] = {r0.x, r0.y, r0.z, r0.w}, wl[4] = {r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                r[2 * j] = bf2f((bf16_t)(wh[j] & 0xffff)) + bf2f((bf16_t)(wl[j] & 0xffff));
-                r[2 * j + 1] = bf2f((bf16_t)(wh[j] >> 16)) + bf2f((bf16_t)(wl[j] >> 16));
-            }
+        for (int j = 0; j < 4; ++j) {
+            r[2 * j] = bf2f((bf16_t)(wh[j] & 0xffff)) + bf2f((bf16_t)(wl[j] & 0xffff));
+            r[2 * j + 1] = bf2f((bf16_t)(wh[j] >> 16)) + bf2f((bf16_t)(wl[j] >> 16));
         }
     }
 #pragma unroll
@@ -204,19 +218,39 @@ __device__ __forceinline__ void stage_acc(const GemmParams& p, char* smem, AccT 
     }
 }
 
+template <int BN> struct DrainMap {
+    static constexpr int TPR = BN / 8;     // threads per row (8 channels each)
+    static constexpr int RPP = 256 / TPR;  // rows per pass
+    static constexpr int NP = BM / RPP;    // passes
+};
+
+template <int OUT, int BN>
+__device__ __forceinline__ void res_prefetch(const GemmParams& p, int m_base, int n_base, int tid,
+                                             uint4 (&rr)[DrainMap<BN>::NP][2]) {
+    using D = DrainMap<BN>;
+    const int c8 = tid % D::TPR, r0 = tid / D::TPR;
+#pragma unroll
+    for (int pass = 0; pass < D::NP; ++pass) {
+        const long m = (long)m_base + pass * D::RPP + r0;
+        rr[pass][0] = make_uint4(0u, 0u, 0u, 0u);  // all-zero bits decode to 0.0 in every storage type
+        rr[pass][1] = make_uint4(0u, 0u, 0u, 0u);
+        if (p.R && m < p.M) res_load<OUT>(p, m, n_base + c8 * 8, rr[pass][0], rr[pass][1]);
+    }
+}
+
 template <int OUT, int BN, int ACT>
-__device__ __forceinline__ void drain_stage(const GemmParams& p, const char* smem, int m_base, int n_base, int tid) {
-    constexpr int TPR = BN / 8;          // threads per row (8 channels each)
-    constexpr int RPP = 256 / TPR;       // rows per pass
-    const int c8 = tid % TPR, r0 = tid / TPR;
-#pragma unroll 4
-    for (int pass = 0; pass < BM / RPP; ++pass) {
-        const int row = pass * RPP + r0;
+__device__ __forceinline__ void drain_stage(const GemmParams& p, const char* smem, int m_base, int n_base, int tid,
+                                            const uint4 (&rr)[DrainMap<BN>::NP][2]) {
+    using D = DrainMap<BN>;
+    const int c8 = tid % D::TPR, r0 = tid / D::TPR;
+#pragma unroll
+    for (int pass = 0; pass < D::NP; ++pass) {
+        const int row = pass * D::RPP + r0;
         const long m = (long)m_base + row;
         if (m < p.M) {
             const float4 a = *reinterpret_cast<const float4*>(smem + stage_off<BN>(row, 2 * c8));
             const float4 b = *reinterpret_cast<const float4*>(smem + stage_off<BN>(row, 2 * c8 + 1));
-            finish8<OUT, ACT>(p, m, n_base + c8 * 8, a, b);
+            finish8<OUT, ACT>(p, m, n_base + c8 * 8, a, b, rr[pass][0], rr[pass][1]);
         }
     }
 }
@@ -470,6 +504,10 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
         }
     }
 
+    // residual tile of this thread's epilogue rows: requested now, consumed after the last MFMA
+    uint4 rres[DrainMap<BN>::NP][2];
+    res_prefetch<OUT, BN>(p, m_base, n_base, tid, rres);
+
     constexpr int NFN = IS_F32 ? WN / 32 : WN / 16;
     constexpr int NFM = IS_F32 ? 2 : 4;
     static_assert(MODE < 2 || OUT != 1, "split-bf16 modes write f32 or sp32");
@@ -505,9 +543,9 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
     // epilogue through LDS (the tile buffers are free: the loop ended on a barrier)
     stage_acc<MODE, BN>(p, smem, acc, n_base, wm, wn, lane);
     __syncthreads();
-    if (p.act == 2) drain_stage<OUT, BN, 2>(p, smem, m_base, n_base, tid);
-    else if (p.act == 1) drain_stage<OUT, BN, 1>(p, smem, m_base, n_base, tid);
-    else drain_stage<OUT, BN, 0>(p, smem, m_base, n_base, tid);
+    if (p.act == 2) drain_stage<OUT, BN, 2>(p, smem, m_base, n_base, tid, rres);
+    else if (p.act == 1) drain_stage<OUT, BN, 1>(p, smem, m_base, n_base, tid, rres);
+    else drain_stage<OUT, BN, 0>(p, smem, m_base, n_base, tid, rres);
 }
 
 template <int MODE, int OUT, int LW>
