@@ -431,21 +431,24 @@ __global__ void add_pe_kernel(const float* __restrict__ x, const float* __restri
 // softmax(q k^T * scale) v for one (batch, head) per workgroup; S <= 256, d in {32, 64}.
 // wav2vec2 encoder self-attention (16 x 64) and attention_layers.py:10-38 (32 x 32, 16 x 64).
 // K (rows padded by 4 floats: conflict-free b128 row reads) and V live in LDS as f32; each wave owns query rows.
+// 8 waves share one head's K/V image (~105 KiB f32 at S=199): two waves per SIMD hide the LDS latency of the score loop
+constexpr int ATT_WAVES = 8;
+constexpr int ATT_THREADS = ATT_WAVES * 64;
 template <typename T, typename TO, int D>
-__global__ void __launch_bounds__(256) attention_kernel(const T* __restrict__ qkv, TO* __restrict__ out, int s, int heads,
+__global__ void __launch_bounds__(ATT_THREADS) attention_kernel(const T* __restrict__ qkv, TO* __restrict__ out, int s, int heads,
                                                       float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int KP = D + 4;
     float* ks = reinterpret_cast<float*>(smem_raw);           // [s][KP]
     float* vs = ks + (long)s * KP;                            // [s][D]
-    float* ps = vs + (long)s * D;                             // [4][256]
-    float* qs = ps + 4 * 256;                                 // [4][D]
+    float* ps = vs + (long)s * D;                             // [ATT_WAVES][256]
+    float* qs = ps + ATT_WAVES * 256;                         // [ATT_WAVES][D]
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
     const int e = heads * D;
     const long rowstride = 3L * e;
     const T* base = qkv + (long)b * s * rowstride + h * D;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int i = tid; i < s * (D / 4); i += 256) {
+    for (int i = tid; i < s * (D / 4); i += ATT_THREADS) {
         const int r = i / (D / 4), c4 = (i % (D / 4)) * 4;
         float kv[4], vv[4];
         ld4<T>(base, (long)r * rowstride + e + c4, kv);
@@ -456,7 +459,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const T* __restrict__ qk
     __syncthreads();
     float* pw = ps + wv * 256;
     float* qw = qs + wv * D;
-    for (int qi = wv; qi < s; qi += 4) {
+    for (int qi = wv; qi < s; qi += ATT_WAVES) {
         if (lane < D) qw[lane] = ldf<T>(base, (long)qi * rowstride + lane) * scale;
         __builtin_amdgcn_wave_barrier();
         float sc[4];
@@ -777,7 +780,7 @@ int k_attention(avcer_ctx* ctx, const void* qkv, void* out, int n, int s, int he
     if (d != 32 && d != 64) return set_err(ctx, AVCER_EINVAL, "attention: head dim %d", d);
     if (in_kind == 2 || (in_kind == 1) != (out_kind == 1))
         return set_err(ctx, AVCER_EINVAL, "attention: unsupported storage combination %d -> %d", in_kind, out_kind);
-    const size_t lds = ((size_t)s * (d + 4) + (size_t)s * d + 4 * 256 + 4 * d) * sizeof(float);
+    const size_t lds = ((size_t)s * (d + 4) + (size_t)s * d + ATT_WAVES * 256 + ATT_WAVES * d) * sizeof(float);
     const int grid = n * heads;
 #define ATT(T, TO, D)                                                                                                \
     do {                                                                                                             \
@@ -787,7 +790,7 @@ int k_attention(avcer_ctx* ctx, const void* qkv, void* out, int n, int s, int he
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
             attr_set = true;                                                                                         \
         }                                                                                                            \
-        attention_kernel<T, TO, D><<<grid, 256, lds, st>>>((const T*)qkv, (TO*)out, s, heads, scale);                \
+        attention_kernel<T, TO, D><<<grid, ATT_THREADS, lds, st>>>((const T*)qkv, (TO*)out, s, heads, scale);        \
     } while (0)
     if (in_kind == 1) { if (d == 64) ATT(bf16_t, bf16_t, 64); else ATT(bf16_t, bf16_t, 32); }
     else if (out_kind == 2) { if (d == 64) ATT(float, sp32_t, 64); else ATT(float, sp32_t, 32); }
