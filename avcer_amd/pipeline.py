@@ -22,9 +22,10 @@ class AVPipeline:
         self.static = StaticModel(self.engine, sds[0], mode)
         self.dynamic = DynamicModel(self.engine, sds[1])
         self.audio = AudioModel(self.engine, sds[2], mode) if sds[2] is not None else None
-        # The audio branch runs on its own HIP stream: its kernels are MFMA-bound while about half of the static CNN's
-        # are HBM-bound, so blocks of the two branches share CUs productively (each needs 64 KiB of the 160 KiB LDS).
-        self.overlap_branches = True
+        # Optional: run the audio branch on its own HIP stream.  Measured +4 % clips/s in the fp32 and bf16 modes and
+        # nothing in the x3 mode (every kernel already fills the chip, only grid tails overlap); off by default because
+        # concurrent kernels make per-kernel HIP-event durations meaningless for the roofline figure.
+        self.overlap_branches = False
         self._audio_stream = None
 
     def clip_records(self, frames_u8: torch.Tensor, wav: torch.Tensor, fps: float = 25, present=None):
