@@ -11,19 +11,21 @@
 //   LSTM input / recurrent projections           architectures/video.py:169-185
 //
 // Design (CDNA4):
-//   * 256 threads = 4 waves (2x2); block tile 128(m) x BN(n), BN in {128, 64}; one K-step = 128 bytes per row
-//     (32 f32 or 64 bf16), so the global->LDS staging pattern is identical for both element types.
+//   * 256 threads = 4 waves (2x2, wave tile 64 x BN/2); block tile 128(m) x BN(n), BN in {128, 64}; one K-step =
+//     128 bytes per row for every element type (32 f32 / sp32 or 64 bf16), so the DMA pattern is type-independent.
+//     64 KiB (BN=128) / 48 KiB (BN=64) of LDS per block: two / three blocks per CU cover each other's barrier stalls.
 //   * A and W tiles go global -> LDS by DMA (buffer_load_dwordx4 ... lds, no VGPR staging, no ds_write); the
 //     hardware bounds check of the buffer descriptor supplies the zeros of image borders and of rows past M.
-//     The double-buffered LDS image has 128-byte rows whose 16-byte chunks are XOR-swizzled with (row>>1)&7
-//     (applied on the source address, since the DMA destination is lane-linear): conflict-free for the
-//     ds_read_b128 fragment reads of both MFMA shapes (MI355X LDS: 64 banks x 4 B, b128 reads in 16-lane groups).
+//     The double-buffered LDS image has 128-byte rows whose 16-byte chunks are XOR-swizzled with a searched key of
+//     (row>>1)&7, applied on the SOURCE address (the DMA destination is lane-linear): conflict-free ds_read_b128
+//     fragment reads for every MFMA shape used (MI355X LDS: 64 banks x 4 B, b128 reads served in 16-lane groups).
 //   * MFMA operands are swapped (weights = A operand, activations = B operand) so that each lane's accumulator
-//     registers hold 4 CONSECUTIVE output channels of one position: NHWC stores and the per-channel
-//     scale/bias loads become 16-byte (f32) / 8-byte (bf16) vector accesses.
-//   * f32 mode uses v_mfma_f32_32x32x2_f32 (exact f32 FMA chain, parity mode); bf16 mode uses
-//     v_mfma_f32_16x16x32_bf16 with f32 accumulation.
-//   * blockIdx is remapped so that the 8 XCDs (private L2 each) get contiguous runs of tiles.
+//     registers hold 4 CONSECUTIVE output channels of one position.
+//   * Arithmetic: MODE 0 f32 (v_mfma_f32_32x32x2_f32, exact FMA chain); MODE 1 bf16 (v_mfma_f32_16x16x32_bf16);
+//     MODE 2/3 split-bf16 "x3": hi/lo bf16 pairs, 3 MFMAs per product, f32-grade results (see conv_gemm_kernel).
+//   * Epilogue through LDS: scale/bias, residual (prefetched into registers at kernel start), activation, whole-line
+//     16-byte stores in f32, bf16 or sp32.  Optional second A source (two fused 1x1 convolutions), grouped
+//     convolution via grid.y, bijective XCD-aware block remap + grouped tile order.
 #include "common.h"
 
 #include <cstdlib>
