@@ -3,6 +3,8 @@
 // f32 statistics regardless of the activation storage type.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
@@ -504,6 +506,172 @@ __global__ void __launch_bounds__(ATT_THREADS) attention_kernel(const T* __restr
     }
 }
 
+// ---- MFMA attention for 64-wide heads (wav2vec2 encoder layers, TransformerLayer 2) ---------------------------------
+// One workgroup (4 waves) per (window, head).  K is kept in LDS as bf16 rows (GEMM swizzle), V transposed and key-
+// permuted, both as hi (+ lo in the split mode) planes.  Each wave takes 16-query tiles:
+//   S^T tile = K . Q^T   (swapped operands: a lane then holds, for ONE query lane&15, the keys 16t + 4(lane>>4) + r)
+//   softmax over keys     in-lane over its registers + 2 shuffles across the four lane groups
+//   O^T tile = V^T . P^T  the exponentiated accumulators of key tiles (2b, 2b+1) ARE the B operand of the PV MFMA for
+//                         key block b once V^T is stored with k-index 8g+e <-> key 32b + 16(e>>2) + 4g + (e&3)
+// X3 = 1: every product as hi.hi + hi.lo + lo.hi of bf16 pairs (f32-grade, as conv_gemm MODE 2/3); X3 = 0: bf16 operands.
+typedef __attribute__((ext_vector_type(8))) __bf16 att_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float att_f32x4_t;
+
+__device__ __forceinline__ int att_swz(int row, int chunk) {
+    return row * 128 + ((chunk ^ (int)((0x32765410u >> (((row >> 1) & 7) * 4)) & 7u)) << 4);
+}
+
+template <typename T, typename TO, int NKT, int X3>
+__global__ void __launch_bounds__(256) attention_mfma_kernel(const T* __restrict__ qkv, TO* __restrict__ out, int s, int heads,
+                                                           float scale) {
+    constexpr int D = 64;
+    constexpr int SP = NKT * 16;             // padded key count
+    constexpr int VROW = SP * 2 + 16;        // bytes per V^T row (16-byte pad against bank conflicts)
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* khi = smem_raw;                    // [SP][128 B]
+    char* klo = khi + SP * 128;
+    char* vhi = klo + (X3 ? SP * 128 : 0);   // [D][VROW]
+    char* vlo = vhi + D * VROW;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int e = heads * D;
+    const long rowstride = 3L * e;
+    const T* base = qkv + (long)b * s * rowstride + h * D;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = lane >> 4, q16 = lane & 15;
+
+    // ---- stage K (row-major) and V (transposed + permuted) as bf16 planes
+    for (int it = tid; it < SP * 8; it += 256) {
+        const int r = it >> 3, c = it & 7;   // key row, chunk of 8 head-dim elements
+        float kv[8], vv[8];
+        if (r < s) {
+            ld4<T>(base, (long)r * rowstride + e + 8 * c, kv);
+            ld4<T>(base, (long)r * rowstride + e + 8 * c + 4, kv + 4);
+            ld4<T>(base, (long)r * rowstride + 2 * e + 8 * c, vv);
+            ld4<T>(base, (long)r * rowstride + 2 * e + 8 * c + 4, vv + 4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { kv[j] = 0.f; vv[j] = 0.f; }
+        }
+        uint32_t hw[4], lw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16_t h0 = f2bf(kv[2 * j]), h1 = f2bf(kv[2 * j + 1]);
+            hw[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            lw[j] = (uint32_t)f2bf(kv[2 * j] - bf2f(h0)) | ((uint32_t)f2bf(kv[2 * j + 1] - bf2f(h1)) << 16);
+        }
+        *reinterpret_cast<uint4*>(khi + att_swz(r, c)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        if (X3) *reinterpret_cast<uint4*>(klo + att_swz(r, c)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        // V^T: key r sits at k-position (r>>5)*32 + ((r&15)>>2)*8 + ((r>>4)&1)*4 + (r&3) of every head-dim row
+        const int kpos = (r >> 5) * 32 + ((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bf16_t hv = f2bf(vv[j]);
+            *reinterpret_cast<bf16_t*>(vhi + (8 * c + j) * VROW + kpos * 2) = hv;
+            if (X3) *reinterpret_cast<bf16_t*>(vlo + (8 * c + j) * VROW + kpos * 2) = f2bf(vv[j] - bf2f(hv));
+        }
+    }
+    __syncthreads();
+
+    const int nqt = (s + 15) >> 4;
+    for (int tq = wv; tq < nqt; tq += 4) {
+        const int qrow = tq * 16 + q16;
+        // ---- Q fragments (B operand): this lane's query row, head-dim 32ks + 8g .. +7, pre-scaled
+        att_bf16x8_t qh[2], ql[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float qv[8];
+            if (qrow < s) {
+                ld4<T>(base, (long)qrow * rowstride + 32 * ks + 8 * g, qv);
+                ld4<T>(base, (long)qrow * rowstride + 32 * ks + 8 * g + 4, qv + 4);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qv[j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = qv[j] * scale;
+                const __bf16 hh = (__bf16)x;
+                qh[ks][j] = hh;
+                ql[ks][j] = (__bf16)(x - (float)hh);
+            }
+        }
+        // ---- scores^T: key tiles x this query tile
+        att_f32x4_t sc[NKT];
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            sc[t] = att_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = att_swz(t * 16 + q16, ks * 4 + g);
+                const att_bf16x8_t kh = *reinterpret_cast<const att_bf16x8_t*>(khi + off);
+                if (X3) {
+                    const att_bf16x8_t kl = *reinterpret_cast<const att_bf16x8_t*>(klo + off);
+                    sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[ks], sc[t], 0, 0, 0);
+                    sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[ks], sc[t], 0, 0, 0);
+                }
+                sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[ks], sc[t], 0, 0, 0);
+            }
+        }
+        // ---- softmax over keys (register r of tile t is key 16t + 4g + r); padded keys contribute nothing
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (16 * t + 4 * g + r >= s) sc[t][r] = -INFINITY;
+                mx = fmaxf(mx, sc[t][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float den = 0.f;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = (16 * t + 4 * g + r < s) ? expf(sc[t][r] - mx) : 0.f;
+                sc[t][r] = pv;
+                den += pv;
+            }
+        den += __shfl_xor(den, 16, 64);
+        den += __shfl_xor(den, 32, 64);
+        // ---- O^T = V^T . P^T over key blocks of 32
+        att_f32x4_t oc[4];
+#pragma unroll
+        for (int tv = 0; tv < 4; ++tv) oc[tv] = att_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NKT / 2; ++kb) {
+            att_bf16x8_t ph, pl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = sc[2 * kb + (j >> 2)][j & 3];
+                const __bf16 hh = (__bf16)x;
+                ph[j] = hh;
+                pl[j] = (__bf16)(x - (float)hh);
+            }
+#pragma unroll
+            for (int tv = 0; tv < 4; ++tv) {
+                const int off = (tv * 16 + q16) * VROW + (kb * 4 + g) * 16;
+                const att_bf16x8_t vh = *reinterpret_cast<const att_bf16x8_t*>(vhi + off);
+                if (X3) {
+                    const att_bf16x8_t vl = *reinterpret_cast<const att_bf16x8_t*>(vlo + off);
+                    oc[tv] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, oc[tv], 0, 0, 0);
+                    oc[tv] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, oc[tv], 0, 0, 0);
+                }
+                oc[tv] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, oc[tv], 0, 0, 0);
+            }
+        }
+        // ---- normalise and store: registers of tile tv are head-dim 16tv + 4g + r of query lane&15
+        if (qrow < s) {
+            const float inv = 1.f / den;
+#pragma unroll
+            for (int tv = 0; tv < 4; ++tv) {
+                float o4[4] = {oc[tv][0] * inv, oc[tv][1] * inv, oc[tv][2] * inv, oc[tv][3] * inv};
+                st4<TO>(out, ((long)b * s + qrow) * e + h * D + 16 * tv + 4 * g, o4);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ audio head
 // audio_8_cl.py:151-152: MaxPool1d(5) (stride 5, floor) then ReLU over time of [n, t_in, c].
 __global__ void maxpool1d_relu_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int t_in, int t_out,
@@ -780,8 +948,30 @@ int k_attention(avcer_ctx* ctx, const void* qkv, void* out, int n, int s, int he
     if (d != 32 && d != 64) return set_err(ctx, AVCER_EINVAL, "attention: head dim %d", d);
     if (in_kind == 2 || (in_kind == 1) != (out_kind == 1))
         return set_err(ctx, AVCER_EINVAL, "attention: unsupported storage combination %d -> %d", in_kind, out_kind);
-    const size_t lds = ((size_t)s * (d + 4) + (size_t)s * d + ATT_WAVES * 256 + ATT_WAVES * d) * sizeof(float);
     const int grid = n * heads;
+    // 64-wide heads in the bf16 / split-bf16 modes: QK^T and PV on the MFMA (the f32 mode keeps exact f32 arithmetic)
+    static const bool mfma_off = getenv("AVCER_ATTN_VALU") != nullptr;  // test knob: force the VALU kernel
+    if (d == 64 && !mfma_off && (in_kind == 1 || out_kind == 2)) {
+        const int nkt = s <= 128 ? 8 : 16;
+        const int sp = nkt * 16, x3 = out_kind == 2;
+        const size_t lds_m = (size_t)sp * 128 * (x3 ? 2 : 1) + (size_t)64 * (sp * 2 + 16) * (x3 ? 2 : 1);
+#define ATTM(T, TO, NKT, X3)                                                                                          \
+    do {                                                                                                              \
+        static bool attr_set = false;                                                                                 \
+        if (!attr_set) {                                                                                              \
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)attention_mfma_kernel<T, TO, NKT, X3>,                      \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));               \
+            attr_set = true;                                                                                          \
+        }                                                                                                             \
+        attention_mfma_kernel<T, TO, NKT, X3><<<grid, 256, lds_m, st>>>((const T*)qkv, (TO*)out, s, heads, scale);    \
+    } while (0)
+        if (x3) { if (nkt == 8) ATTM(float, sp32_t, 8, 1); else ATTM(float, sp32_t, 16, 1); }
+        else { if (nkt == 8) ATTM(bf16_t, bf16_t, 8, 0); else ATTM(bf16_t, bf16_t, 16, 0); }
+#undef ATTM
+        CHECK_LAUNCH(ctx, "attention_mfma");
+        return AVCER_OK;
+    }
+    const size_t lds = ((size_t)s * (d + 4) + (size_t)s * d + ATT_WAVES * 256 + ATT_WAVES * d) * sizeof(float);
 #define ATT(T, TO, D)                                                                                                \
     do {                                                                                                             \
         static bool attr_set = false;                                                                                \

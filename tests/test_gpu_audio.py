@@ -138,3 +138,20 @@ def test_seven_class_variant(engine, golden):
         p_ref = torch.softmax(torch.from_numpy(ref), 1).numpy()
         assert np.abs(out - ref).max() < tol and np.abs(p_got - p_ref).max() < 1e-4
     eng.close()
+
+
+@pytest.mark.parametrize("mode,tol", [(MODE_BF16X3, 1e-4), (MODE_BF16, 0.1)])
+def test_four_second_windows_mfma_attention(engine_audio, golden, mode, tol):
+    """T = 64000 -> 199 tokens: the 16-key-tile instantiation of the MFMA attention kernel (the reference's run-time
+    window), batch of 3 to exercise several (window, head) blocks; row 0 is the golden's input."""
+    g = golden("audio_model")
+    wav = np.concatenate([synth.waveforms(5679, 1, 64000), synth.waveforms(5680, 2, 64000)])
+    out = engine_audio.audio_forward(torch.from_numpy(wav), normalize=True, mode=mode).cpu().numpy()
+    ref = g["t64000_logits"].reshape(1, 8)
+    p_got = torch.softmax(torch.from_numpy(out[:1, :7]), 1).numpy()
+    p_ref = torch.softmax(torch.from_numpy(ref[:, :7]), 1).numpy()
+    print("t64000 mode", mode, "max|dlogit|", np.abs(out[:1] - ref).max(), "max|dprob|", np.abs(p_got - p_ref).max())
+    assert np.isfinite(out).all() and np.abs(p_got - p_ref).max() < tol
+    fp32 = engine_audio.audio_forward(torch.from_numpy(wav), normalize=True, mode=MODE_FP32).cpu().numpy()
+    assert np.abs(torch.softmax(torch.from_numpy(out[:, :7]), 1).numpy()
+                  - torch.softmax(torch.from_numpy(fp32[:, :7]), 1).numpy()).max() < tol
