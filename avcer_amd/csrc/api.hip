@@ -343,13 +343,26 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     if (mode == AVCER_MODE_BF16X3) TRY(ensure_all_x3(ctx, ctx->stat, st));
     const size_t es = bf ? 2 : 4;
     const int NB = std::min(n, ctx->static_batch);
+    // Depth-first front end: the stem and the first `front` stages run over chunks of CH frames so that every tensor
+    // a chunk touches between two uses (block input re-read as residual, T1/T2, the next block's input) stays in the
+    // 256 MiB memory-side cache instead of streaming through HBM; the later stages need the whole pass to fill the
+    // chip.  AVCER_STATIC_CHUNK=0 restores the layer-by-layer schedule.
+    static const int env_chunk = getenv("AVCER_STATIC_CHUNK") ? atoi(getenv("AVCER_STATIC_CHUNK")) : ctx->static_chunk;
+    static const int env_front = getenv("AVCER_STATIC_FRONT") ? atoi(getenv("AVCER_STATIC_FRONT")) : 2;
+    const int CH = env_chunk > 0 ? std::min(env_chunk, NB) : NB;
+    const int front = env_chunk > 0 && CH < NB ? std::max(0, std::min(env_front, 3)) : 0;
     const size_t act_elems = (size_t)NB * 112 * 112 * 64;  // largest activation (stem output)
-    const size_t pre_elems = (size_t)NB * 230 * 230 * 4;
-    const size_t total = pre_elems * es + 4 * (act_elems * es + 256) + (size_t)NB * (2048 + 512) * 4 + 4096;
+    const size_t cact_elems = (size_t)CH * 112 * 112 * 64;
+    const size_t pre_elems = (size_t)(front ? CH : NB) * 230 * 230 * 4;
+    const size_t total = pre_elems * es + 4 * (act_elems * es + 256) + (front ? 4 * (cact_elems * es + 256) : 0) +
+                         (size_t)NB * (2048 + 512) * 4 + 4096;
     void* wsp = nullptr;
     TRY(ws_reserve(ctx, 0, total, &wsp));
     Arena ar(wsp, ctx->ws[0].cap);
     void* P = ar.get(pre_elems * es);
+    void* cbuf[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (front)
+        for (auto& b : cbuf) b = ar.get(cact_elems * es);
     void* buf[4];
     for (auto& b : buf) b = ar.get(act_elems * es);
     float* pooled = (float*)ar.get((size_t)NB * 2048 * 4);
@@ -357,60 +370,80 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     if (!feat_ws) return set_err(ctx, AVCER_ENOMEM, "static workspace arithmetic");
 
     Net net{ctx, ctx->stat, bf, st, mode == AVCER_MODE_BF16X3};
+    // stem + max-pool of `nb` frames starting at frame f0 of the call: -> B[1] (55x55x64), B[0] is scratch
+    auto run_stem = [&](int f0, int nb, void** B) {
+        if (frames) net.chk(k_preprocess(ctx, frames + (size_t)f0 * in_h * in_w * 3, nb, in_h, in_w, P, bf, st));
+        else net.chk(k_pack_nchw(ctx, nchw + (size_t)f0 * 3 * 224 * 224, nb, P, bf, st));
+        // 8 tap rows x (8 pixels x 4 channels) over the zero-bordered 230x230x4 image, stride 2
+        avcer_conv_desc d;
+        memset(&d, 0, sizeof(d));
+        d.batch = nb; d.in_h = 230; d.in_w = 230; d.out_h = 112; d.out_w = 112;
+        d.cin = 32; d.kh = 8; d.kw = 1;
+        d.stride_h = 2; d.stride_w = 2; d.dil_h = d.dil_w = 1;
+        d.x_stride_b = 230L * 230 * 4; d.x_stride_h = 230 * 4; d.x_stride_w = 4;
+        d.n = 64; d.y_ld = 64; d.r_ld = 64; d.act = 1;
+        net.gemm(d, "stem.w", net.F("stem.s"), net.F("stem.b"), P, nullptr, B[0], bf, act);  // P is f32 unless bf16
+        net.tap("pre", P, (size_t)nb * 230 * 230 * 4 * es);
+        net.tap("stem_conv", B[0], (size_t)nb * 112 * 112 * 64 * es);
+        net.chk(k_maxpool3s2(ctx, B[0], B[1], nb, 112, 112, 64, 55, 55, act, st));
+        net.tap("stem", B[1], (size_t)nb * 55 * 55 * 64 * es);
+    };
+    // one stage (li) of bottlenecks on nb frames; the last block writes to `last_out` when given
+    auto run_stage = [&](int li, int nb, void*& X, void*& T1, void*& T2, void*& OUT, int& h, int& cin, void* last_out) {
+        const int planes = kStages[li][0], blocks = kStages[li][1];
+        for (int b = 0; b < blocks; ++b) {
+            const int stride = b == 0 ? kStages[li][2] : 1;
+            const std::string p = "l" + std::to_string(li + 1) + "." + std::to_string(b) + ".";
+            const int oh = (h - 1) / stride + 1;
+            void* dst = (b == blocks - 1 && last_out) ? last_out : OUT;
+            net.gemm(conv2d_desc(nb, h, h, cin, 1, 1, stride, 0, planes, 1), p + "c1.w", net.F(p + "c1.s"),
+                     net.F(p + "c1.b"), X, nullptr, T1, act, act);
+            net.gemm(conv2d_desc(nb, oh, oh, planes, 3, 3, 1, 1, planes, 1), p + "c2.w", net.F(p + "c2.s"),
+                     net.F(p + "c2.b"), T1, nullptr, T2, act, act);
+            if (b == 0) {
+                // conv3 + downsample fused: K = [T2 (planes) | X at stride (cin)], BN scales folded into the weights
+                avcer_conv_desc d = conv2d_desc(nb, oh, oh, planes, 1, 1, 1, 0, planes * 4, 1);
+                d.x2_cin = cin; d.x2_stride = stride;
+                d.x2_stride_b = (int64_t)h * h * cin; d.x2_stride_h = (int64_t)h * cin; d.x2_stride_w = cin;
+                net.gemm(d, p + "c3d.w", nullptr, net.F(p + "c3d.b"), T2, nullptr, dst, act, act, X);
+            } else {
+                net.gemm(conv2d_desc(nb, oh, oh, planes, 1, 1, 1, 0, planes * 4, 1), p + "c3.w", net.F(p + "c3.s"),
+                         net.F(p + "c3.b"), T2, X, dst, act, act);
+            }
+            if (dst == OUT) std::swap(X, OUT);
+            else X = dst;
+            h = oh;
+            cin = planes * 4;
+            if (li == 0 && b == 0) {
+                net.tap("l1b0_c1", T1, (size_t)nb * h * h * planes * es);
+                net.tap("l1b0_c2", T2, (size_t)nb * h * h * planes * es);
+                net.tap("l1b0", X, (size_t)nb * h * h * cin * es);
+            }
+        }
+        net.tap(("layer" + std::to_string(li + 1)).c_str(), X, (size_t)nb * h * h * cin * es);
+    };
     for (int s0 = 0; s0 < n; s0 += NB) {
         const int nb = std::min(NB, n - s0);
-        if (frames) net.chk(k_preprocess(ctx, frames + (size_t)s0 * in_h * in_w * 3, nb, in_h, in_w, P, bf, st));
-        else net.chk(k_pack_nchw(ctx, nchw + (size_t)s0 * 3 * 224 * 224, nb, P, bf, st));
-        {  // stem: 8 tap rows x (8 pixels x 4 channels) over the zero-bordered 230x230x4 image, stride 2
-            avcer_conv_desc d;
-            memset(&d, 0, sizeof(d));
-            d.batch = nb; d.in_h = 230; d.in_w = 230; d.out_h = 112; d.out_w = 112;
-            d.cin = 32; d.kh = 8; d.kw = 1;
-            d.stride_h = 2; d.stride_w = 2; d.dil_h = d.dil_w = 1;
-            d.x_stride_b = 230L * 230 * 4; d.x_stride_h = 230 * 4; d.x_stride_w = 4;
-            d.n = 64; d.y_ld = 64; d.r_ld = 64; d.act = 1;
-            net.gemm(d, "stem.w", net.F("stem.s"), net.F("stem.b"), P, nullptr, buf[0], bf, act);  // P is f32 unless bf16
-        }
-        net.tap("pre", P, (size_t)nb * 230 * 230 * 4 * es);
-        net.tap("stem_conv", buf[0], (size_t)nb * 112 * 112 * 64 * es);
-        net.chk(k_maxpool3s2(ctx, buf[0], buf[1], nb, 112, 112, 64, 55, 55, act, st));
-        net.tap("stem", buf[1], (size_t)nb * 55 * 55 * 64 * es);
-        void* X = buf[1];
-        void* T1 = buf[2];
-        void* T2 = buf[3];
-        void* OUT = buf[0];
+        void *X, *T1 = buf[2], *T2 = buf[3], *OUT = buf[0];
         int h = 55, cin = 64;
-        for (int li = 0; li < 4; ++li) {
-            const int planes = kStages[li][0], blocks = kStages[li][1];
-            for (int b = 0; b < blocks; ++b) {
-                const int stride = b == 0 ? kStages[li][2] : 1;
-                const std::string p = "l" + std::to_string(li + 1) + "." + std::to_string(b) + ".";
-                const int oh = (h - 1) / stride + 1;
-                net.gemm(conv2d_desc(nb, h, h, cin, 1, 1, stride, 0, planes, 1), p + "c1.w", net.F(p + "c1.s"),
-                         net.F(p + "c1.b"), X, nullptr, T1, act, act);
-                net.gemm(conv2d_desc(nb, oh, oh, planes, 3, 3, 1, 1, planes, 1), p + "c2.w", net.F(p + "c2.s"),
-                         net.F(p + "c2.b"), T1, nullptr, T2, act, act);
-                if (b == 0) {
-                    // conv3 + downsample fused: K = [T2 (planes) | X at stride (cin)], BN scales folded into the weights
-                    avcer_conv_desc d = conv2d_desc(nb, oh, oh, planes, 1, 1, 1, 0, planes * 4, 1);
-                    d.x2_cin = cin; d.x2_stride = stride;
-                    d.x2_stride_b = (int64_t)h * h * cin; d.x2_stride_h = (int64_t)h * cin; d.x2_stride_w = cin;
-                    net.gemm(d, p + "c3d.w", nullptr, net.F(p + "c3d.b"), T2, nullptr, OUT, act, act, X);
-                } else {
-                    net.gemm(conv2d_desc(nb, oh, oh, planes, 1, 1, 1, 0, planes * 4, 1), p + "c3.w", net.F(p + "c3.s"),
-                             net.F(p + "c3.b"), T2, X, OUT, act, act);
-                }
-                std::swap(X, OUT);
-                h = oh;
-                cin = planes * 4;
-                if (li == 0 && b == 0) {
-                    net.tap("l1b0_c1", T1, (size_t)nb * h * h * planes * es);
-                    net.tap("l1b0_c2", T2, (size_t)nb * h * h * planes * es);
-                    net.tap("l1b0", X, (size_t)nb * h * h * cin * es);
-                }
+        if (front) {
+            int fh = 55, fc = 64;  // geometry after the chunked stages
+            for (int li = 0; li < front; ++li) { fh = (fh - 1) / kStages[li][2] + 1; fc = kStages[li][0] * 4; }
+            for (int c0 = 0; c0 < nb; c0 += CH) {
+                const int cn = std::min(CH, nb - c0);
+                run_stem(s0 + c0, cn, cbuf);
+                void *cX = cbuf[1], *cT1 = cbuf[2], *cT2 = cbuf[3], *cOUT = cbuf[0];
+                h = 55; cin = 64;
+                for (int li = 0; li < front; ++li)
+                    run_stage(li, cn, cX, cT1, cT2, cOUT, h, cin,
+                              li == front - 1 ? (char*)buf[1] + (size_t)c0 * fh * fh * fc * es : nullptr);
             }
-            net.tap(("layer" + std::to_string(li + 1)).c_str(), X, (size_t)nb * h * h * cin * es);
+            X = buf[1];
+        } else {
+            run_stem(s0, nb, buf);
+            X = buf[1];
         }
+        for (int li = front; li < 4; ++li) run_stage(li, nb, X, T1, T2, OUT, h, cin, nullptr);
         net.chk(k_avgpool_hw(ctx, X, pooled, nb, h * h, 2048, act, st));
         net.tap("avgpool", pooled, (size_t)nb * 2048 * 4);
         float* fo = feats ? feats + (size_t)s0 * 512 : feat_ws;
