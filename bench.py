@@ -95,7 +95,7 @@ def parse():
     ap.add_argument("--mode", choices=["x3", "fp32", "bf16"], default="x3", help="arithmetic of the headline value")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other arithmetic modes")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-clips", type=int, default=8, help="bounded sample for the CPU baseline")
+    ap.add_argument("--cpu-clips", type=int, default=64, help="upper bound of the CPU baseline sample (sized to ~12 s)")
     ap.add_argument("--parity-clips", type=int, default=2)
     return ap.parse_args()
 
@@ -200,6 +200,10 @@ def cpu_baseline(n_clips):
     warm = time.perf_counter() - t0
     if warm > 8.0:  # slow host: shrink the sample so the default run stays within minutes
         n_clips = max(1, min(n_clips, int(30.0 / warm)))
+    else:  # bounded sample of about 12 s of CPU work
+        t0 = time.perf_counter()
+        clip(0)
+        n_clips = max(1, min(n_clips, int(12.0 / max(time.perf_counter() - t0, 1e-3))))
     t0 = time.perf_counter()
     for c in range(n_clips):
         clip(c)
