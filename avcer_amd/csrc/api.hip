@@ -704,6 +704,25 @@ extern "C" int avcer_audio_frame_mean(avcer_ctx* ctx, const float* win_logits, c
     return k_frame_mean(ctx, win_logits, frame_lo, frame_hi, n_win, c, n_frames, out, count, (hipStream_t)stream);
 }
 
+extern "C" int avcer_face_decode(avcer_ctx* ctx, const float* loc, const float* conf, const float* landms,
+                                 const float* priors, int n_priors, int im_h, int im_w, float var0, float var1,
+                                 float* dets, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (!loc || !conf || !landms || !priors || !dets || n_priors <= 0 || im_h <= 0 || im_w <= 0)
+        return set_err(ctx, AVCER_EINVAL, "face_decode: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return k_face_decode(ctx, loc, conf, landms, priors, n_priors, im_h, im_w, var0, var1, dets, (hipStream_t)stream);
+}
+
+extern "C" int avcer_crop_tiles(avcer_ctx* ctx, const uint8_t* frames, int n_frames, int h, int w, const int32_t* rects,
+                                int n, int swap_rb, uint8_t* tiles, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (!frames || !rects || !tiles || n_frames <= 0 || h <= 0 || w <= 0 || n <= 0)
+        return set_err(ctx, AVCER_EINVAL, "crop_tiles: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return k_crop_tiles(ctx, frames, n_frames, h, w, rects, n, swap_rb ? 1 : 0, tiles, (hipStream_t)stream);
+}
+
 extern "C" int avcer_fuse(avcer_ctx* ctx, const float* stat, const float* dyn_logits, const float* aud_mean, int n,
                           int n_aud, int aud_c, const double* w1, const double* w2, int ce_weights_type, int ce_mask,
                           double* comp_prob, int32_t* comp_argmax, avcer_stream_t stream) {

@@ -135,6 +135,72 @@ __global__ void pack_nchw_kernel(const float* __restrict__ in, T* __restrict__ o
     st4<T>(out, idx * 4, v);
 }
 
+// ------------------------------------------------------------------------------------------------ face stage (row f4)
+// retina_face_predictor.py:70-82 with box_utils.py:210-249: every prior's box, score and five landmarks in pixels.
+// The arithmetic follows torch's evaluation order in f32 with contraction off, so only expf may differ (<= 2 ulp).
+__global__ void face_decode_kernel(const float* __restrict__ loc, const float* __restrict__ conf,
+                                   const float* __restrict__ landms, const float* __restrict__ priors, int P, float im_w,
+                                   float im_h, float var0, float var1, float* __restrict__ dets) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float4 pr = *reinterpret_cast<const float4*>(priors + 4L * i);
+    const float4 l = *reinterpret_cast<const float4*>(loc + 4L * i);
+    const float cx = pr.x + (l.x * var0) * pr.z;
+    const float cy = pr.y + (l.y * var0) * pr.w;
+    const float w = pr.z * expf(l.z * var1);
+    const float h = pr.w * expf(l.w * var1);
+    const float x0 = cx - w / 2.0f, y0 = cy - h / 2.0f;
+    float* o = dets + 15L * i;
+    o[0] = x0 * im_w;
+    o[1] = y0 * im_h;
+    o[2] = (w + x0) * im_w;
+    o[3] = (h + y0) * im_h;
+    o[4] = conf[2L * i + 1];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        o[5 + 2 * k] = (pr.x + (landms[10L * i + 2 * k] * var0) * pr.z) * im_w;
+        o[6 + 2 * k] = (pr.y + (landms[10L * i + 2 * k + 1] * var0) * pr.w) * im_h;
+    }
+}
+
+// get_face_images.py:52-56 (crop of the decoded frame) + data/utils.py:34 (PIL NEAREST resize to 224x224) in one pass:
+// tile pixel (y, x) = frame[f][y0 + floor((y + .5) * ch / 224)][x0 + floor((x + .5) * cw / 224)], channels swapped
+// when the frames are BGR (cv2) so that the tile is RGB like the image PIL reads back.  One thread per 4 tile pixels.
+__global__ void crop_tiles_kernel(const uint8_t* __restrict__ frames, int T, int H, int W, const int32_t* __restrict__ rects,
+                                  int n, int swap_rb, uint8_t* __restrict__ tiles) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n * 224 * 56;
+    if (idx >= total) return;
+    const int xq = idx % 56;
+    const int y = (idx / 56) % 224;
+    const int t = idx / (56L * 224);
+    const int32_t* r = rects + 5L * t;
+    const int f = r[0], x0 = r[1], y0 = r[2], cw = r[3] - r[1], ch = r[4] - r[2];
+    uint8_t px[12];
+    const bool ok = f >= 0 && f < T && x0 >= 0 && y0 >= 0 && cw > 0 && ch > 0 && x0 + cw <= W && y0 + ch <= H;
+    if (ok) {
+        const int sy = y0 + min((int)(((double)y + 0.5) * ((double)ch / 224.0)), ch - 1);
+        const uint8_t* row = frames + ((long)f * H + sy) * W * 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = xq * 4 + j;
+            const int sx = x0 + min((int)(((double)x + 0.5) * ((double)cw / 224.0)), cw - 1);
+            const uint8_t* s = row + 3L * sx;
+            px[3 * j + 0] = swap_rb ? s[2] : s[0];
+            px[3 * j + 1] = s[1];
+            px[3 * j + 2] = swap_rb ? s[0] : s[2];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) px[j] = 0;
+    }
+    uint32_t* o = reinterpret_cast<uint32_t*>(tiles + ((long)t * 224 + y) * 224 * 3 + xq * 12);  // 12-byte aligned to 4
+    o[0] = px[0] | (px[1] << 8) | (px[2] << 16) | ((uint32_t)px[3] << 24);
+    o[1] = px[4] | (px[5] << 8) | (px[6] << 16) | ((uint32_t)px[7] << 24);
+    o[2] = px[8] | (px[9] << 8) | (px[10] << 16) | ((uint32_t)px[11] << 24);
+}
+
 // get_prob_video.py:115-123: window rows = relu(features) gathered by index into [nwin, 10, 512]
 __global__ void gather_windows_kernel(const float* __restrict__ feats, const int32_t* __restrict__ idx, float* __restrict__ out,
                                       long total4) {
@@ -1036,6 +1102,20 @@ int k_fuse(avcer_ctx* ctx, const float* stat, const float* dyn, const float* aud
     fp.cmask = cmask;
     fuse_kernel<<<cdiv(n, 64), 64, 0, st>>>(stat, dyn, aud, n, n_aud, aud_c, fp, comp_prob, comp_argmax);
     CHECK_LAUNCH(ctx, "fuse");
+    return AVCER_OK;
+}
+
+int k_face_decode(avcer_ctx* ctx, const float* loc, const float* conf, const float* landms, const float* priors, int P,
+                  int im_h, int im_w, float var0, float var1, float* dets, hipStream_t st) {
+    face_decode_kernel<<<cdiv(P, 256), 256, 0, st>>>(loc, conf, landms, priors, P, (float)im_w, (float)im_h, var0, var1, dets);
+    CHECK_LAUNCH(ctx, "face_decode");
+    return AVCER_OK;
+}
+
+int k_crop_tiles(avcer_ctx* ctx, const uint8_t* frames, int T, int H, int W, const int32_t* rects, int n, int swap_rb,
+                 uint8_t* tiles, hipStream_t st) {
+    crop_tiles_kernel<<<cdiv((long)n * 224 * 56, 256), 256, 0, st>>>(frames, T, H, W, rects, n, swap_rb, tiles);
+    CHECK_LAUNCH(ctx, "crop_tiles");
     return AVCER_OK;
 }
 

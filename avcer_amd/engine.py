@@ -167,6 +167,31 @@ class Engine:
                                                     int(x.shape[1]), int(n_frames), _ptr(out), _ptr(cnt), self._stream()))
         return out, cnt
 
+    def face_decode(self, loc, conf, landms, priors, image_size, variance=(0.1, 0.2)):
+        """RetinaFace head outputs [P,4], [P,2], [P,10] + priors [P,4] -> dets [P,15] in pixels (before filtering)."""
+        loc, conf = self._dev(loc, torch.float32), self._dev(conf, torch.float32)
+        landms, priors = self._dev(landms, torch.float32), self._dev(priors, torch.float32)
+        p = int(priors.shape[0])
+        if tuple(loc.shape) != (p, 4) or tuple(conf.shape) != (p, 2) or tuple(landms.shape) != (p, 10) or priors.shape[1] != 4:
+            raise ValueError("face_decode: loc [P,4], conf [P,2], landms [P,10], priors [P,4]")
+        dets = self._new(p, 15)
+        self._check(self.lib.avcer_face_decode(self.ctx, _ptr(loc), _ptr(conf), _ptr(landms), _ptr(priors), p,
+                                               int(image_size[0]), int(image_size[1]), float(variance[0]),
+                                               float(variance[1]), _ptr(dets), self._stream()))
+        return dets
+
+    def crop_tiles(self, frames_u8, rects, bgr: bool = True):
+        """frames u8 [T,H,W,3] + rects i32 [n,5] (frame, x0, y0, x1, y1; validated by the caller) -> RGB tiles [n,224,224,3]."""
+        x = self._dev(frames_u8, torch.uint8)
+        r = self._dev(rects, torch.int32)
+        if x.dim() != 4 or x.shape[-1] != 3 or r.dim() != 2 or r.shape[1] != 5:
+            raise ValueError("crop_tiles: frames [T,H,W,3] uint8, rects [n,5] int32")
+        n = int(r.shape[0])
+        tiles = self._new(n, 224, 224, 3, dtype=torch.uint8)
+        self._check(self.lib.avcer_crop_tiles(self.ctx, _ptr(x), int(x.shape[0]), int(x.shape[1]), int(x.shape[2]),
+                                              _ptr(r), n, 1 if bgr else 0, _ptr(tiles), self._stream()))
+        return tiles
+
     def fuse(self, stat, dyn_logits, aud_mean, n_aud: int, weights_1=None, weights_2=(1, 1, 1),
              ce_weights_type: bool = False, ce_mask: bool = True):
         stat = self._dev(stat, torch.float32)

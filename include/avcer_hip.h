@@ -114,6 +114,22 @@ int avcer_audio_chunks(avcer_ctx* ctx, const float* wav, const int32_t* starts, 
 int avcer_audio_frame_mean(avcer_ctx* ctx, const float* win_logits, const int32_t* frame_lo, const int32_t* frame_hi,
                            int n_win, int c, int n_frames, float* out, int32_t* count, avcer_stream_t stream);
 
+/* Face stage ("next" row f4): the arithmetic either side of the RetinaFace network.
+ *   avcer_face_decode  ref: data/face_detection/ibug/face_detection/retina_face/retina_face_predictor.py:70-82,
+ *                            box_utils.py:210-249 (decode, decode_landm), scaled to pixels
+ *     loc f32 [P,4], conf f32 [P,2] (softmaxed), landms f32 [P,10], priors f32 [P,4] (cx, cy, w, h; prior_box.py:16-33)
+ *     -> dets f32 [P,15] = x0, y0, x1, y1, score, 5 x (lx, ly): the row layout the predictor returns, BEFORE its
+ *     confidence filter / NMS / top-k (host side, avcer_amd/face_tiles.py, as in the reference).
+ *   avcer_crop_tiles   ref: data/get_face_images.py:52-56 (crop fr[y0:y1, x0:x1]) + data/utils.py:34 (PIL NEAREST
+ *                            resize to 224x224), without the JPEG file in between
+ *     frames u8 [T,H,W,3], rects i32 [n,5] = frame, x0, y0, x1, y1 (end-exclusive, inside the frame),
+ *     swap_rb != 0 when the frames are BGR (cv2 order) -> tiles u8 [n,224,224,3] RGB, the input of
+ *     avcer_static_forward.  A rect that is empty or leaves the frame yields an all-zero tile. */
+int avcer_face_decode(avcer_ctx* ctx, const float* loc, const float* conf, const float* landms, const float* priors,
+                      int n_priors, int im_h, int im_w, float var0, float var1, float* dets, avcer_stream_t stream);
+int avcer_crop_tiles(avcer_ctx* ctx, const uint8_t* frames, int n_frames, int h, int w, const int32_t* rects, int n,
+                     int swap_rb, uint8_t* tiles, avcer_stream_t stream);
+
 /* Probability fusion and compound-expression rule.
  *   ref: run.py:25-165 (get_c_expr_db_pred), data/utils.py:125-127 (softmax), :222-241 (get_compound_expression)
  * stat f32 [n,7] softmaxed static probs and dyn_logits f32 [n,7], both in VIDEO column order;

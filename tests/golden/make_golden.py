@@ -9,6 +9,9 @@ the vectors are its outputs on the synthetic weights/inputs of avcer_amd/synth.p
 Harness-side shims (none of them touch arithmetic on the hot path):
   * cv2 / torchvision / torchaudio are absent: stubbed in sys.modules. PILToTensor is restated as the u8
     HWC->CHW view it is; cv2.imread serves in-memory frames; torch.load / os.listdir serve synthetic data.
+  * face stage (row f4): the RetinaFace network needs torchvision (absent) and weights (absent), so
+    RetinaFacePredictor.__call__ and VideoPredictor.process run UNMODIFIED around a stand-in `net` / `model` that
+    returns seeded tensors; cv2.VideoCapture / cv2.imwrite serve and capture in-memory frames.
   * transformers 5.x (installed) vs 4.36.2 (pinned): `init_weights()` is made a no-op (all weights are
     overwritten by load_state_dict) and attention is forced to the pinned eager matmul-softmax-matmul.
 """
@@ -74,8 +77,13 @@ def install_stubs():
 
     tr.Compose, tr.PILToTensor = Compose, PILToTensor
     tv.transforms = tr
+    tvm = types.ModuleType("torchvision.models")  # only named at RetinaFace construction time, never called here
+    tvm._utils = types.ModuleType("torchvision.models._utils")
+    tv.models = tvm
     sys.modules["torchvision"] = tv
     sys.modules["torchvision.transforms"] = tr
+    sys.modules["torchvision.models"] = tvm
+    sys.modules["torchvision.models._utils"] = tvm._utils
     sys.modules["torchaudio"] = types.ModuleType("torchaudio")
     vis = types.ModuleType("visualization.visualize")
     vis.show_cam_on_image = None
@@ -446,13 +454,164 @@ def gen_fusion():
     print("fusion cases", case, "prob dtype", out["c0_w_01_prob"].dtype)
 
 
+
+# ----------------------------------------------------------------------------- F9 face stage (row f4)
+def face_frame(t, h, w):
+    """BGR frame whose pixels encode their own position (so crops are self-describing)."""
+    y, x = np.mgrid[0:h, 0:w]
+    return np.stack([x & 255, y & 255, (3 * x + 5 * y + 17 * t) & 255], axis=-1).astype(np.uint8)
+
+
+def fake_head_outputs(seed, h, w, priors, faces):
+    """Seeded (loc, conf, landms) a RetinaFace head could emit: priors near a face regress to it with high score."""
+    P = priors.shape[0]
+    pc = priors[:, :2] * np.array([w, h], dtype=np.float32)
+    ps = priors[:, 2:] * np.array([w, h], dtype=np.float32)
+    loc = synth.centered(seed, "loc", (P, 4), 1.0).astype(np.float32)
+    score = synth.uniform(seed, "low", (P,), 0.0, 0.05)
+    for fi, (cx, cy, fw, fh) in enumerate(faces):
+        d = np.hypot((pc[:, 0] - cx) / fw, (pc[:, 1] - cy) / fh)
+        ratio = np.abs(np.log(ps[:, 0] / fw))
+        s = np.clip(1.08 - 1.5 * d - 0.6 * ratio, 0.0, 0.999).astype(np.float32)
+        hit = s > score
+        noise = synth.centered(seed + 1 + fi, "noise", (P, 4), 0.3).astype(np.float32)
+        enc = np.stack([(cx - pc[:, 0]) / (0.1 * ps[:, 0]), (cy - pc[:, 1]) / (0.1 * ps[:, 1]),
+                        np.log(fw / ps[:, 0]) / 0.2, np.log(fh / ps[:, 1]) / 0.2], axis=1).astype(np.float32) + noise
+        loc[hit] = enc[hit]
+        score[hit] = s[hit]
+    conf = np.stack([1.0 - score, score], axis=1).astype(np.float32)
+    landms = synth.centered(seed + 9, "landms", (P, 10), 1.0).astype(np.float32)
+    return loc, conf, landms
+
+
+def gen_face():
+    import tempfile
+    from types import SimpleNamespace
+    from PIL import Image
+
+    import data.get_face_images as gfi
+    from data.face_detection.ibug.face_detection.retina_face.config import cfg_re50
+    from data.face_detection.ibug.face_detection.retina_face.prior_box import PriorBox
+    from data.face_detection.ibug.face_detection.retina_face.py_cpu_nms import py_cpu_nms
+    from data.face_detection.ibug.face_detection.retina_face.retina_face_predictor import RetinaFacePredictor
+    from data.face_detection.ibug.face_detection.utils import SimpleFaceTracker
+    import cv2
+
+    out = {}
+    # priors for two image sizes (one not a multiple of the strides)
+    for name, size in (("a", (120, 160)), ("b", (233, 311))):
+        out[f"priors_{name}"] = PriorBox(cfg_re50, image_size=size).forward().numpy()
+        out[f"size_{name}"] = np.array(size)
+
+    # RetinaFacePredictor.__call__ (retina_face_predictor.py:58-108) around a stand-in net
+    cases = {"b": [(80.0, 70.0, 48.0, 60.0), (200.0, 120.0, 90.0, 110.0), (250.0, 40.0, 24.0, 30.0)],
+             "a": [(60.0, 50.0, 40.0, 44.0)]}
+    for name, faces in cases.items():
+        h, w = (int(v) for v in out[f"size_{name}"])
+        loc, conf, landms = fake_head_outputs(700 + len(faces), h, w, out[f"priors_{name}"], faces)
+        for thr_name, thr in (("t80", 0.8), ("t30", 0.3)):
+            pred = object.__new__(RetinaFacePredictor)
+            pred.threshold = thr
+            pred.device = "cpu"
+            pred.config = SimpleNamespace(**cfg_re50, **RetinaFacePredictor.create_config().__dict__)
+            pred.net = lambda image, l=loc, c=conf, m=landms: (torch.from_numpy(l)[None], torch.from_numpy(c)[None],
+                                                               torch.from_numpy(m)[None])
+            pred.priors = None
+            pred.previous_size = None
+            dets = pred(face_frame(0, h, w), rgb=False)
+            out[f"pred_{name}_{thr_name}"] = dets
+        out[f"loc_{name}"], out[f"conf_{name}"], out[f"landms_{name}"] = loc, conf, landms
+        print("face predictor", name, {k: out[k].shape for k in out if k.startswith(f"pred_{name}")})
+    # nothing above the confidence floor
+    pred.net = lambda image: (torch.zeros(1, len(out["priors_a"]), 4), torch.tensor([[[1.0, 0.0]]]).repeat(1, len(out["priors_a"]), 1),
+                              torch.zeros(1, len(out["priors_a"]), 10))
+    out["pred_empty"] = pred(face_frame(0, 120, 160), rgb=False)
+
+    # NMS alone on seeded boxes
+    n = 300
+    ctr = synth.uniform(31, "ctr", (n, 2), 0.0, 1.0) * np.array([300.0, 200.0])
+    wh = synth.uniform(32, "wh", (n, 2), 10.0, 70.0)
+    sc = synth.uniform(33, "sc", (n,), 0.0, 1.0)
+    dets = np.concatenate([ctr - wh / 2, ctr + wh / 2, sc[:, None]], axis=1).astype(np.float32)
+    out["nms_dets"] = dets
+    out["nms_keep_04"] = np.array(py_cpu_nms(dets, 0.4, 5000), dtype=np.int64)
+    out["nms_keep_02_top50"] = np.array(py_cpu_nms(dets, 0.2, 50), dtype=np.int64)
+
+    # VideoPredictor.process (get_face_images.py:38-63): tracker + crop clamp + file naming, around a stand-in model
+    H, W, T = 120, 160, 14
+    script = []
+    for t in range(T):
+        rows = []
+        if t != 12:
+            ax = 20.3 + 4.6 * t + (70.0 if t >= 6 else 0.0)   # face A drifts, jumps at t = 6 (IoU < 0.4 -> new id)
+            rows.append([ax, 30.7 - 0.4 * t, ax + 36.2, 75.9 - 0.4 * t, 0.97])
+        if 3 <= t < 8 or t >= 10:                              # face B comes, goes, comes back
+            rows.append([-6.5 + t, 80.2, 31.4 + t, 131.8, 0.91])  # sticks out left and below the image
+        if t in (4, 5):
+            rows.append([130.6, -4.2, 171.3, 38.9, 0.88])      # sticks out top-right
+        a = np.zeros((len(rows), 15), dtype=np.float32)
+        if rows:
+            a[:, :5] = np.array(rows, dtype=np.float32)
+        script.append(a)
+
+    class Capture:
+        def __init__(self, path):
+            self.t = 0
+
+        def get(self, prop):
+            return {cv2.CAP_PROP_FRAME_WIDTH: W, cv2.CAP_PROP_FRAME_HEIGHT: H, cv2.CAP_PROP_FPS: 25,
+                    cv2.CAP_PROP_FRAME_COUNT: T}[prop]
+
+        def read(self):
+            if self.t >= T:
+                return False, None
+            self.t += 1
+            return True, face_frame(self.t - 1, H, W)
+
+        def release(self):
+            pass
+
+    cv2.CAP_PROP_FRAME_WIDTH, cv2.CAP_PROP_FRAME_HEIGHT, cv2.CAP_PROP_FPS, cv2.CAP_PROP_FRAME_COUNT = 3, 4, 5, 7
+    cv2.VideoCapture = Capture
+    writes = []
+    cv2.imwrite = lambda path, img: writes.append((path, img.copy()))
+    vp = object.__new__(gfi.VideoPredictor)
+    vp.video_stream = None
+    vp.face_tracker = SimpleFaceTracker(iou_threshold=0.4, minimum_face_size=0.0)
+    calls = iter(script)
+    vp.model = lambda fr, rgb=False: next(calls)
+    tmp = tempfile.mkdtemp()
+    vp.process("/nonexistent/clip_x.mp4", tmp)
+    recs, tiles = [], []
+    for path, crop in writes:
+        rel = os.path.relpath(path, tmp).replace(os.sep, "/")
+        video, track, fname = rel.split("/")
+        assert video == "clip_x"
+        x0, y0 = int(crop[0, 0, 0]), int(crop[0, 0, 1])
+        recs.append([int(fname[:-4]), int(track), x0, y0, x0 + crop.shape[1], y0 + crop.shape[0]])
+        rgb = Image.fromarray(np.ascontiguousarray(crop[..., ::-1]))       # what PIL reads back from a lossless file
+        tiles.append(np.asarray(rgb.resize((224, 224), Image.Resampling.NEAREST)).copy())   # data/utils.py:34
+    import shutil
+    shutil.rmtree(tmp)
+    for t, a in enumerate(script):
+        out[f"track_dets_{t}"] = a
+    out["track_T"] = np.array(T)
+    out["track_hw"] = np.array([H, W])
+    out["track_records"] = np.array(recs, dtype=np.int64)   # frame, track dir, x0, y0, x1, y1 (crop = fr[y0:y1, x0:x1])
+    out["track_tiles"] = np.stack(tiles)
+    np.savez_compressed(os.path.join(HERE, "face.npz"), **out)
+    print("face: writes", len(writes), "tracks", sorted(set(r[1] for r in recs)))
+
+
 if __name__ == "__main__":
     import transformers  # noqa: F401  (must be imported before the torchvision stub exists)
     from transformers import Wav2Vec2FeatureExtractor  # noqa: F401
     from transformers.models.wav2vec2 import modeling_wav2vec2  # noqa: F401
 
     install_stubs()
-    which = sys.argv[1:] or ["visual", "audio", "fusion", "audio7", "dataset"]
+    which = sys.argv[1:] or ["face", "visual", "audio", "fusion", "audio7", "dataset"]
+    if "face" in which:  # first: gen_fusion replaces data.get_face_images by a stand-in module
+        gen_face()
     if "visual" in which:
         gen_visual()
     if "audio" in which:

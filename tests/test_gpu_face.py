@@ -1,0 +1,84 @@
+"""Face stage (row f4) on the GPU: box decoding and crop -> tile kernels against the reference-generated vectors of
+tests/golden/face.npz and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from avcer_amd import face_tiles as ft
+from avcer_amd import video_pipeline as vp
+from avcer_amd.engine import MODE_FP32
+from oracle import face as of
+from oracle import video as ov
+from test_face_cpu import G, golden_frames, golden_script
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_decode_all_priors(engine, name):
+    size = tuple(int(v) for v in G[f"size_{name}"])
+    pri = of.prior_boxes(size)
+    dets = engine.face_decode(G[f"loc_{name}"], G[f"conf_{name}"], G[f"landms_{name}"], pri, size).cpu().numpy()
+    h, w = size
+    ref_b = of.decode(G[f"loc_{name}"], pri) * np.array([w, h, w, h], np.float32)
+    ref_l = of.decode_landm(G[f"landms_{name}"], pri) * np.array([w, h] * 5, np.float32)
+    np.testing.assert_allclose(dets[:, :4], ref_b, rtol=3e-6, atol=3e-5)        # expf: <= 2 ulp apart
+    np.testing.assert_array_equal(dets[:, 4], G[f"conf_{name}"][:, 1])
+    np.testing.assert_array_equal(dets[:, 5:], ref_l)                              # no transcendental: bit-exact
+
+
+@pytest.mark.parametrize("name,thr", [("a", 0.8), ("a", 0.3), ("b", 0.8), ("b", 0.3)])
+def test_detections_match_reference_predictor(engine, name, thr):
+    size = tuple(int(v) for v in G[f"size_{name}"])
+    got = ft.FaceDetections(engine, threshold=thr)(G[f"loc_{name}"], G[f"conf_{name}"], G[f"landms_{name}"], size)
+    ref = G[f"pred_{name}_t{int(thr * 100)}"]
+    assert got.shape == ref.shape and got.dtype == np.float32
+    np.testing.assert_allclose(got, ref, rtol=3e-6, atol=3e-5)
+
+
+def test_detections_empty(engine):
+    p = len(G["priors_a"])
+    conf = np.tile(np.array([[1.0, 0.0]], dtype=np.float32), (p, 1))
+    got = ft.FaceDetections(engine)(np.zeros((p, 4), np.float32), conf, np.zeros((p, 10), np.float32), (120, 160))
+    assert got.shape == (0, 15) and got.dtype == np.float32
+
+
+def test_video_tiler_matches_reference_process(engine):
+    records, tiles = ft.VideoTiler(engine).process(golden_frames(), golden_script())
+    np.testing.assert_array_equal(records, G["track_records"])
+    assert tiles.dtype == torch.uint8 and tiles.is_cuda
+    np.testing.assert_array_equal(tiles.cpu().numpy(), G["track_tiles"])           # bit-exact u8, BGR -> RGB + NEAREST
+
+
+def test_crop_tiles_rgb_identity_and_bad_rects(engine):
+    fr = np.random.default_rng(3).integers(0, 256, (2, 300, 260, 3), dtype=np.uint8)
+    rects = np.array([[0, 10, 20, 234, 244],      # 224x224 crop: plain copy
+                      [1, 0, 0, 260, 300],        # whole frame, down-sampled
+                      [1, 5, 7, 6, 8],            # 1x1 crop replicated
+                      [0, 100, 100, 100, 150],    # empty -> zeros
+                      [2, 0, 0, 10, 10],          # frame out of range -> zeros
+                      [0, 200, 0, 270, 50]],      # leaves the frame -> zeros
+                     dtype=np.int32)
+    t = engine.crop_tiles(fr, rects, bgr=False).cpu().numpy()
+    np.testing.assert_array_equal(t[0], fr[0, 20:244, 10:234])
+    np.testing.assert_array_equal(t[1], ov.nearest_resize_u8(fr[1]))
+    assert (t[2] == fr[1, 7, 5]).all()
+    assert not t[3].any() and not t[4].any() and not t[5].any()
+    tb = engine.crop_tiles(fr, rects[:2], bgr=True).cpu().numpy()
+    np.testing.assert_array_equal(tb, t[:2, :, :, ::-1])
+
+
+def test_track_feeds_visual_path(engine_static, sd_static, sd_dynamic):
+    """tiles of one track -> the visual path, against the oracle run on the reference-generated tiles."""
+    engine_static.load_dynamic(sd_dynamic)
+    records, tiles = ft.VideoTiler(engine_static).process(golden_frames(), golden_script())
+    total = int(G["track_T"])
+    frames, present = ft.track_clip(records, tiles, 1, total)          # face B's first visit: frames 3..7
+    assert present.tolist() == [3 <= t < 8 for t in range(total)]
+    stat, dyn = vp.visual_forward(engine_static, frames, present, 25, MODE_FP32)
+    rows = np.where(G["track_records"][:, 1] == 1)[0]
+    ref_frames = np.zeros((total, 224, 224, 3), np.uint8)
+    ref_frames[G["track_records"][rows, 0]] = G["track_tiles"][rows]
+    rs, rd = ov.visual_forward(sd_static, sd_dynamic, ref_frames, present, 25, batched=True)
+    np.testing.assert_allclose(stat.cpu().numpy(), rs, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(dyn.cpu().numpy(), rd, rtol=0, atol=2e-3)
