@@ -11,9 +11,10 @@
 //   LSTM input / recurrent projections           architectures/video.py:169-185
 //
 // Design (CDNA4):
-//   * 256 threads = 4 waves (2x2, wave tile 64 x BN/2); block tile 128(m) x BN(n), BN in {128, 64}; one K-step =
-//     128 bytes per row for every element type (32 f32 / sp32 or 64 bf16), so the DMA pattern is type-independent.
-//     64 KiB (BN=128) / 48 KiB (BN=64) of LDS per block: two / three blocks per CU cover each other's barrier stalls.
+//   * 256 threads = 4 waves (2x2, wave tile BM/2 x BN/2); block tile BM(m) x BN(n) = 128x128, 128x64 or 192x128; one
+//     K-step = 128 bytes per row for every element type (32 f32 / sp32 or 64 bf16), so the DMA pattern is
+//     type-independent.  64 / 48 / 80 KiB of LDS per block: two / three / two blocks per CU cover each other's barrier
+//     stalls.  The 192-row tile moves 17 % fewer L2->LDS bytes per flop and keeps 80 instead of 64 KiB in flight per CU.
 //   * A and W tiles go global -> LDS by DMA (buffer_load_dwordx4 ... lds, no VGPR staging, no ds_write); the
 //     hardware bounds check of the buffer descriptor supplies the zeros of image borders and of rows past M.
 //     The double-buffered LDS image has 128-byte rows whose 16-byte chunks are XOR-swizzled with a searched key of
@@ -37,7 +38,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int ROWB = 128;  // bytes per tile row per K-step
 
 struct GemmParams {
@@ -181,8 +181,9 @@ __device__ __forceinline__ void finish8(const GemmParams& p, long m, int n0, con
 template <int BN>
 __device__ __forceinline__ int stage_off(int row, int chunk) { return row * (BN * 4) + ((chunk ^ (row & 7)) << 4); }
 
+// row0 = first row of this wave's accumulators inside the staging image
 template <int MODE, int BN, typename AccT, int NFN, int NFM>
-__device__ __forceinline__ void stage_acc(const GemmParams& p, char* smem, AccT (&acc)[NFN][NFM], int n_base, int wm, int wn,
+__device__ __forceinline__ void stage_acc(const GemmParams& p, char* smem, AccT (&acc)[NFN][NFM], int n_base, int row0, int wn,
                                           int lane) {
     constexpr int WN = BN / 2;
     if constexpr (MODE == 0) {
@@ -196,7 +197,7 @@ __device__ __forceinline__ void stage_acc(const GemmParams& p, char* smem, AccT 
                 if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + n_base + nl);
 #pragma unroll
                 for (int fm = 0; fm < NFM; ++fm) {
-                    const int ml = wm * 64 + fm * 32 + (lane & 31);
+                    const int ml = row0 + fm * 32 + (lane & 31);
                     *reinterpret_cast<float4*>(smem + stage_off<BN>(ml, nl >> 2)) =
                         make_float4(acc[fn][fm][4 * g + 0] * sc.x + bi.x, acc[fn][fm][4 * g + 1] * sc.y + bi.y,
                                     acc[fn][fm][4 * g + 2] * sc.z + bi.z, acc[fn][fm][4 * g + 3] * sc.w + bi.w);
@@ -211,7 +212,7 @@ __device__ __forceinline__ void stage_acc(const GemmParams& p, char* smem, AccT 
             if (p.bias) bi = *reinterpret_cast<const float4*>(p.bias + n_base + nl);
 #pragma unroll
             for (int fm = 0; fm < NFM; ++fm) {
-                const int ml = wm * 64 + fm * 16 + (lane & 15);
+                const int ml = row0 + fm * 16 + (lane & 15);
                 *reinterpret_cast<float4*>(smem + stage_off<BN>(ml, nl >> 2)) =
                     make_float4(acc[fn][fm][0] * sc.x + bi.x, acc[fn][fm][1] * sc.y + bi.y, acc[fn][fm][2] * sc.z + bi.z,
                                 acc[fn][fm][3] * sc.w + bi.w);
@@ -220,16 +221,17 @@ __device__ __forceinline__ void stage_acc(const GemmParams& p, char* smem, AccT 
     }
 }
 
-template <int BN> struct DrainMap {
-    static constexpr int TPR = BN / 8;     // threads per row (8 channels each)
-    static constexpr int RPP = 256 / TPR;  // rows per pass
-    static constexpr int NP = BM / RPP;    // passes
+template <int BMT, int BN> struct DrainMap {
+    static constexpr int EP_ROWS = BMT == 192 ? 96 : BMT;  // rows per epilogue round: the f32 image must fit the tile buffers
+    static constexpr int TPR = BN / 8;          // threads per row (8 channels each)
+    static constexpr int RPP = 256 / TPR;       // rows per pass
+    static constexpr int NP = EP_ROWS / RPP;    // passes per round
 };
 
-template <int OUT, int BN>
+template <int OUT, int BMT, int BN>
 __device__ __forceinline__ void res_prefetch(const GemmParams& p, int m_base, int n_base, int tid,
-                                             uint4 (&rr)[DrainMap<BN>::NP][2]) {
-    using D = DrainMap<BN>;
+                                             uint4 (&rr)[DrainMap<BMT, BN>::NP][2]) {
+    using D = DrainMap<BMT, BN>;
     const int c8 = tid % D::TPR, r0 = tid / D::TPR;
 #pragma unroll
     for (int pass = 0; pass < D::NP; ++pass) {
@@ -240,10 +242,10 @@ __device__ __forceinline__ void res_prefetch(const GemmParams& p, int m_base, in
     }
 }
 
-template <int OUT, int BN, int ACT>
+template <int OUT, int BMT, int BN, int ACT>
 __device__ __forceinline__ void drain_stage(const GemmParams& p, const char* smem, int m_base, int n_base, int tid,
-                                            const uint4 (&rr)[DrainMap<BN>::NP][2]) {
-    using D = DrainMap<BN>;
+                                            const uint4 (&rr)[DrainMap<BMT, BN>::NP][2]) {
+    using D = DrainMap<BMT, BN>;
     const int c8 = tid % D::TPR, r0 = tid / D::TPR;
 #pragma unroll
     for (int pass = 0; pass < D::NP; ++pass) {
@@ -274,13 +276,14 @@ __device__ __forceinline__ void split8(const float4 x, const float4 y, bf16x8_t&
 // results (relative error ~2^-17 per product) at a third of the bf16 MFMA rate instead of a sixteenth.
 // MODE 3: as MODE 2 but the activations are ALREADY stored as sp32 pairs (written by a producer's epilogue), so the
 // A fragments are read like the weights and the main loop has no conversion arithmetic at all.
-template <int MODE, int BN, int TILE_BYTES, typename AccT, int NFN, int NFM>
+template <int MODE, int BMT, int BN, int TILE_BYTES, typename AccT, int NFN, int NFM>
 __device__ __forceinline__ void mfma_step(const GemmParams& p, const char* smem, int cur, AccT (&acc)[NFN][NFM], int wm, int wn,
                                       int lane) {
     constexpr bool IS_F32 = MODE == 0;
     constexpr int WN = BN / 2;
+    constexpr int WM = BMT / 2;
     const char* sa = smem + cur * TILE_BYTES;
-    const char* sb = sa + BM * ROWB;
+    const char* sb = sa + BMT * ROWB;
     if (p.ablate == 1) {
         // ablation: no fragment reads / MFMA
     } else if constexpr (IS_F32) {
@@ -290,7 +293,7 @@ __device__ __forceinline__ void mfma_step(const GemmParams& p, const char* smem,
             float4 af[NFM], wf[NFN];
 #pragma unroll
             for (int fm = 0; fm < NFM; ++fm)
-                af[fm] = *reinterpret_cast<const float4*>(sa + swz(wm * 64 + fm * 32 + (lane & 31), ch));
+                af[fm] = *reinterpret_cast<const float4*>(sa + swz(wm * WM + fm * 32 + (lane & 31), ch));
 #pragma unroll
             for (int fn = 0; fn < NFN; ++fn)
                 wf[fn] = *reinterpret_cast<const float4*>(sb + swz(wn * WN + fn * 32 + (lane & 31), ch));
@@ -309,7 +312,7 @@ __device__ __forceinline__ void mfma_step(const GemmParams& p, const char* smem,
         bf16x8_t ahi[NFM], alo[NFM];
 #pragma unroll
         for (int fm = 0; fm < NFM; ++fm) {
-            const int row = wm * 64 + fm * 16 + (lane & 15);
+            const int row = wm * WM + fm * 16 + (lane & 15);
             if constexpr (MODE == 3) {
                 ahi[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, g));
                 alo[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, 4 + g));
@@ -343,7 +346,7 @@ __device__ __forceinline__ void mfma_step(const GemmParams& p, const char* smem,
             bf16x8_t af[NFM], wf[NFN];
 #pragma unroll
             for (int fm = 0; fm < NFM; ++fm)
-                af[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(wm * 64 + fm * 16 + (lane & 15), ch));
+                af[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(wm * WM + fm * 16 + (lane & 15), ch));
 #pragma unroll
             for (int fn = 0; fn < NFN; ++fn)
                 wf[fn] = *reinterpret_cast<const bf16x8_t*>(sb + swz(wn * WN + fn * 16 + (lane & 15), ch));
@@ -360,14 +363,16 @@ __device__ __forceinline__ void mfma_step(const GemmParams& p, const char* smem,
 // only read fragments and issue MFMAs, waves 4-7 only issue the LDS-DMA of the next K-step (an LDS-DMA instruction costs its issuing wave
 // ~100 cycles inside a busy phase -- MI355X_MICROARCH.md, 'LDS-DMA piece issue cost' -- and eight of them per K-step
 // rival the MFMA time of a 64x64 wave tile).
-template <int MODE, int OUT, int BN, int LW>
+template <int MODE, int OUT, int BN, int LW, int BMT>
 __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kernel(const GemmParams p) {
+    static_assert(BMT == 128 || (BMT == 192 && BN == 128 && LW == 0), "tile shapes: 128x128, 128x64, 192x128");
     constexpr bool IS_F32 = MODE == 0;
     constexpr int ES = MODE == 1 ? 2 : 4;
     constexpr int VEC = 16 / ES;
     constexpr int BK = ROWB / ES;
-    constexpr int TILE_BYTES = (BM + BN) * ROWB;
+    constexpr int TILE_BYTES = (BMT + BN) * ROWB;
     constexpr int WN = BN / 2;
+    constexpr int WM = BMT / 2;
     __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
 
     const int tid = threadIdx.x;
@@ -399,7 +404,7 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
         tile_n = bid % p.ntn;
         tile_m = bid / p.ntn;
     }
-    const int m_base = tile_m * BM;
+    const int m_base = tile_m * BMT;
     const int grp = blockIdx.y;
     const int n_base = grp * p.N + tile_n * BN;  // row of W / entry of scale, bias; output channel = yoff + n_base
     const int x_coff = p.coff + grp * p.Cin;
@@ -414,13 +419,14 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
     // lane i landing at (row i>>3, 16-byte slot i&7).  The XOR swizzle of the LDS image is therefore applied to the
     // SOURCE: lane i fetches data chunk c = slot ^ ((row>>1)&7) of its row.  Padding taps / rows past M use an
     // out-of-range offset, for which the buffer load writes zeros.
-    constexpr int A_ISS = BM / 8 / NDW;  // DMA instructions per issuing wave per K-step for the A tile
+    constexpr int A_ISS = BMT / 8 / NDW;  // DMA instructions per issuing wave per K-step for the A tile
     constexpr int B_ISS = BN / 8 / NDW;
     const int lrow8 = lane >> 3;
     const int slot = lane & 7;
 #define AVCER_DMA_SETUP()                                                                                           \
     unsigned a_off[A_ISS];                                                                                          \
     unsigned a_off2[A_ISS];                                                                                         \
+    unsigned a_offk[A_ISS];                                                                                         \
     int a_iy[A_ISS], a_ix[A_ISS], a_kc[A_ISS];                                                                      \
     _Pragma("unroll") for (int j = 0; j < A_ISS; ++j) {                                                             \
         const int lrow = dw * (A_ISS * 8) + j * 8 + lrow8;                                                          \
@@ -437,6 +443,7 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
         a_ix[j] = ix;                                                                                               \
         a_off[j] = (unsigned)(((long)b * p.sB + (long)iy * p.sH + (long)ix * p.sW + x_coff) * ES);                  \
         a_kc[j] = (slot ^ swz_key(lrow)) * VEC;                                                                     \
+        a_offk[j] = a_off[j] + (unsigned)(a_kc[j] * ES);                                                            \
         a_off2[j] = ok ? (unsigned)(((long)b * p.sB2 + (long)oy * p.st2 * p.sH2 + (long)ox * p.st2 * p.sW2 + p.coff2) * ES) : OOB;\
     }                                                                                                               \
     unsigned w_off[B_ISS];                                                                                          \
@@ -450,11 +457,19 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
 #define AVCER_ISSUE_TILES(buf)                                                                                      \
     do {                                                                                                            \
         char* sa_ = smem + (buf) * TILE_BYTES + dw * (A_ISS * 1024);                                                \
-        char* sb_ = smem + (buf) * TILE_BYTES + BM * ROWB + dw * (B_ISS * 1024);                                    \
+        char* sb_ = smem + (buf) * TILE_BYTES + BMT * ROWB + dw * (B_ISS * 1024);                                   \
         if (kdone >= p.K1) {                                                                                        \
             _Pragma("unroll") for (int j = 0; j < A_ISS; ++j) {                                                     \
                 const unsigned vo = a_off2[j] + (unsigned)((kdone - p.K1 + a_kc[j]) * ES);                          \
                 dma16(x2rs, sa_ + j * 1024, (a_off2[j] != OOB && p.ablate < 2) ? vo : OOB);                         \
+            }                                                                                                       \
+        } else if (tap_uniform) {                                                                                   \
+            const int dy = ky * p.dh, dx = kx * p.dw;                                                               \
+            const unsigned tap = (unsigned)(((long)dy * p.sH + (long)dx * p.sW + kc) * ES);                         \
+            _Pragma("unroll") for (int j = 0; j < A_ISS; ++j) {                                                     \
+                const int iy = a_iy[j] + dy, ix = a_ix[j] + dx;                                                     \
+                const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.Wd) & (p.ablate < 2);  \
+                dma16(xrs, sa_ + j * 1024, ok ? a_offk[j] + tap : OOB);                                             \
             }                                                                                                       \
         } else {                                                                                                    \
             _Pragma("unroll") for (int j = 0; j < A_ISS; ++j) {                                                     \
@@ -488,6 +503,9 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
     } while (0)
 
     const int nk = p.K / BK;
+    // Cin a multiple of the K-step: a K-step never straddles two filter taps, so the tap offset is one scalar per step
+    // and the per-lane gather address is two adds and a bounds test instead of a per-lane (ky, kx, c) decomposition
+    const bool tap_uniform = p.Cin % BK == 0;
     int cur = 0;
     if constexpr (LW > 0) {
         if (is_loader) {
@@ -507,11 +525,13 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
     }
 
     // residual tile of this thread's epilogue rows: requested now, consumed after the last MFMA
-    uint4 rres[DrainMap<BN>::NP][2];
-    res_prefetch<OUT, BN>(p, m_base, n_base, tid, rres);
+    using D = DrainMap<BMT, BN>;
+    constexpr int EPN = BMT / D::EP_ROWS;  // epilogue rounds (2 for the 192-row tile, whose f32 image exceeds the LDS)
+    uint4 rres[D::NP][2];
+    if constexpr (EPN == 1) res_prefetch<OUT, BMT, BN>(p, m_base, n_base, tid, rres);
 
     constexpr int NFN = IS_F32 ? WN / 32 : WN / 16;
-    constexpr int NFM = IS_F32 ? 2 : 4;
+    constexpr int NFM = IS_F32 ? WM / 32 : WM / 16;
     static_assert(MODE < 2 || OUT != 1, "split-bf16 modes write f32 or sp32");
     using acc_t = typename std::conditional<IS_F32, f32x16_t, f32x4_t>::type;
     acc_t acc[NFN][NFM];
@@ -523,7 +543,7 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
 #define AVCER_MFMA_LOOP(ISSUE_NEXT, STEP_SYNC)                                                                      \
     for (int step = 0; step < nk; ++step) {                                                                         \
         ISSUE_NEXT;                                                                                                 \
-        mfma_step<MODE, BN, TILE_BYTES>(p, smem, cur, acc, wm, wn, lane);                                           \
+        mfma_step<MODE, BMT, BN, TILE_BYTES>(p, smem, cur, acc, wm, wn, lane);                                           \
         STEP_SYNC;                                                                                                  \
         cur ^= 1;                                                                                                   \
     }
@@ -543,24 +563,48 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
 #undef AVCER_MEET
 
     // epilogue through LDS (the tile buffers are free: the loop ended on a barrier)
-    stage_acc<MODE, BN>(p, smem, acc, n_base, wm, wn, lane);
-    __syncthreads();
-    if (p.act == 2) drain_stage<OUT, BN, 2>(p, smem, m_base, n_base, tid, rres);
-    else if (p.act == 1) drain_stage<OUT, BN, 1>(p, smem, m_base, n_base, tid, rres);
-    else drain_stage<OUT, BN, 0>(p, smem, m_base, n_base, tid, rres);
+    if constexpr (EPN == 1) {
+        stage_acc<MODE, BN>(p, smem, acc, n_base, wm * WM, wn, lane);
+        __syncthreads();
+        if (p.act == 2) drain_stage<OUT, BMT, BN, 2>(p, smem, m_base, n_base, tid, rres);
+        else if (p.act == 1) drain_stage<OUT, BMT, BN, 1>(p, smem, m_base, n_base, tid, rres);
+        else drain_stage<OUT, BMT, BN, 0>(p, smem, m_base, n_base, tid, rres);
+    } else {
+        // two rounds of 96 rows: round e stages the accumulators of the waves with wm == e (wave tile = 96 rows);
+        // the residual of a round is requested before its staging barrier
+#pragma unroll
+        for (int e = 0; e < EPN; ++e) {
+            const int m0 = m_base + e * D::EP_ROWS;
+            res_prefetch<OUT, BMT, BN>(p, m0, n_base, tid, rres);
+            if (wm == e) stage_acc<MODE, BN>(p, smem, acc, n_base, 0, wn, lane);
+            __syncthreads();
+            if (p.act == 2) drain_stage<OUT, BMT, BN, 2>(p, smem, m0, n_base, tid, rres);
+            else if (p.act == 1) drain_stage<OUT, BMT, BN, 1>(p, smem, m0, n_base, tid, rres);
+            else drain_stage<OUT, BMT, BN, 0>(p, smem, m0, n_base, tid, rres);
+            if (e + 1 < EPN) __syncthreads();
+        }
+    }
 }
 
 template <int MODE, int OUT, int LW>
-void launch_lw(GemmParams& p, hipStream_t st, bool bn128) {
+void launch_lw(GemmParams& p, hipStream_t st, bool bn128, int bm) {
     constexpr int threads = 256 + 64 * LW;
-    if (bn128) conv_gemm_kernel<MODE, OUT, 128, LW><<<dim3(p.nwg, p.groups), dim3(threads), 0, st>>>(p);
-    else conv_gemm_kernel<MODE, OUT, 64, LW><<<dim3(p.nwg, p.groups), dim3(threads), 0, st>>>(p);
+    if constexpr (LW == 0) {
+        if (bm == 192) {
+            conv_gemm_kernel<MODE, OUT, 128, 0, 192><<<dim3(p.nwg, p.groups), dim3(threads), 0, st>>>(p);
+            return;
+        }
+    }
+    if (bn128) conv_gemm_kernel<MODE, OUT, 128, LW, 128><<<dim3(p.nwg, p.groups), dim3(threads), 0, st>>>(p);
+    else conv_gemm_kernel<MODE, OUT, 64, LW, 128><<<dim3(p.nwg, p.groups), dim3(threads), 0, st>>>(p);
 }
+
+// Tile-height choice (filled in from measurements; see profiles/experiments)
+inline bool prefer_bm192(long M, int N, int K) { return false; }
 
 template <int MODE, int OUT>
 void launch_t(const GemmParams& p0, hipStream_t st) {
     GemmParams p = p0;
-    const int ntm = (p.M + BM - 1) / BM;
     // K <= bn64_max_k: bandwidth-bound 1x1 convolutions; the 48 KiB BN=64 tile lets three blocks share a CU
     static const int bn64_max_k = getenv("AVCER_GEMM_BN64_MAXK") ? atoi(getenv("AVCER_GEMM_BN64_MAXK")) : 128;
     static const int gm_env = getenv("AVCER_GEMM_GM") ? atoi(getenv("AVCER_GEMM_GM")) : 8;
@@ -568,13 +612,18 @@ void launch_t(const GemmParams& p0, hipStream_t st) {
     // MFMA-bound bf16 / sp32 layers, nothing for f32, and -1.4 % on the whole x3 pipeline (profiles/experiments).
     static const int lw_env = getenv("AVCER_GEMM_LW") ? atoi(getenv("AVCER_GEMM_LW")) : 0;
     const int lw = (lw_env == 4 && MODE != 2) ? 4 : 0;
+    // AVCER_GEMM_BM: 128, 192, or 0 = choose per shape
+    static const int bm_env = getenv("AVCER_GEMM_BM") ? atoi(getenv("AVCER_GEMM_BM")) : 128;
+    const bool bn128 = p.N % 128 == 0 && p.K > bn64_max_k;
+    int bm = 128;
+    if (bn128 && lw == 0 && (bm_env == 192 || (bm_env == 0 && prefer_bm192(p.M, p.N, p.K)))) bm = 192;
+    const int ntm = (p.M + bm - 1) / bm;
     p.ntm = ntm;
     p.gm = gm_env;
-    const bool bn128 = p.N % 128 == 0 && p.K > bn64_max_k;
     p.ntn = p.N / (bn128 ? 128 : 64);
     p.nwg = ntm * p.ntn;
-    if (lw == 4) launch_lw<MODE, OUT, 4>(p, st, bn128);
-    else launch_lw<MODE, OUT, 0>(p, st, bn128);
+    if (lw == 4) launch_lw<MODE, OUT, 4>(p, st, bn128, 128);
+    else launch_lw<MODE, OUT, 0>(p, st, bn128, bm);
 }
 
 }  // namespace
