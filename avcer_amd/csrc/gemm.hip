@@ -67,7 +67,10 @@ struct GemmParams {
     int ntn, ntm, nwg;
     int gm;  // m-tiles per group of the grouped block order (0 = plain n-fastest order)
     int groups;  // grid.y: group g shifts coff / yoff / roff by g*Cin / g*N and the weight/scale/bias rows by g*N
-    int ablate;  // test-only (env AVCER_GEMM_ABLATE): 1 = skip MFMA, 2 = skip DMA loads, 4 = skip the x3 operand split
+    int ablate;  // test-only (env AVCER_GEMM_ABLATE): 1 = skip MFMA, 2 = skip DMA loads, 4 = skip the x3 operand split,
+                 // 8 = skip the W-tile DMA (half the L2->LDS bytes; results are garbage, timing only)
+    int KH;
+    int tap_inner;  // K-steps walk (channel chunk, ky, kx) instead of (ky, kx, channel chunk): see launch_conv_gemm
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
@@ -452,7 +455,8 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
         w_off[j] = (unsigned)(((long)(n_base + lrow) * p.K + (slot ^ swz_key(lrow)) * VEC) * ES);                   \
     }                                                                                                               \
     int kc = 0, kx = 0, ky = 0;                                                                                     \
-    int kdone = 0;
+    int kdone = 0;                                                                                                  \
+    unsigned wk = 0;
 
 #define AVCER_ISSUE_TILES(buf)                                                                                      \
     do {                                                                                                            \
@@ -483,14 +487,20 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
             }                                                                                                       \
         }                                                                                                           \
         kdone += BK;                                                                                                \
-        _Pragma("unroll") for (int j = 0; j < B_ISS; ++j) {                                                         \
-            dma16(wrs, sb_ + j * 1024, p.ablate < 2 ? w_off[j] : OOB);                                             \
-            w_off[j] += ROWB;                                                                                       \
+        if (p.ablate != 8) {                                                                                        \
+            _Pragma("unroll") for (int j = 0; j < B_ISS; ++j)                                                       \
+                dma16(wrs, sb_ + j * 1024, p.ablate < 2 ? w_off[j] + wk : OOB);                                    \
         }                                                                                                           \
-        kc += BK;                                                                                                   \
-        while (kc >= p.Cin) {                                                                                       \
-            kc -= p.Cin;                                                                                            \
-            if (++kx == p.KW) { kx = 0; ++ky; }                                                                     \
+        if (p.tap_inner) {                                                                                          \
+            if (++kx == p.KW) { kx = 0; if (++ky == p.KH) { ky = 0; kc += BK; } }                                   \
+            wk = (unsigned)(((ky * p.KW + kx) * p.Cin + kc) * ES);                                                  \
+        } else {                                                                                                    \
+            wk += ROWB;                                                                                             \
+            kc += BK;                                                                                               \
+            while (kc >= p.Cin) {                                                                                   \
+                kc -= p.Cin;                                                                                        \
+                if (++kx == p.KW) { kx = 0; ++ky; }                                                                 \
+            }                                                                                                       \
         }                                                                                                           \
     } while (0)
 
@@ -661,7 +671,14 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
     p.X = (const char*)x; p.W = (const char*)w; p.scale = scale; p.bias = bias; p.R = (const char*)residual;
     p.Y = (char*)y;
     p.M = (int)M; p.N = d.n; p.K = (int)K;
-    p.OH = d.out_h; p.OW = d.out_w; p.H = d.in_h; p.Wd = d.in_w; p.Cin = d.cin; p.KW = d.kw;
+    p.OH = d.out_h; p.OW = d.out_w; p.H = d.in_h; p.Wd = d.in_w; p.Cin = d.cin; p.KW = d.kw; p.KH = d.kh;
+    // Multi-tap convolutions whose Cin is a multiple of the K-step walk K as (channel chunk, ky, kx): the taps of one
+    // chunk re-read the same or neighbouring pixels in consecutive K-steps, i.e. while they are still in the XCD's
+    // 4 MiB L2 (in (ky, kx, chunk) order a pixel comes back only after Cin/BK steps of every block on the XCD).
+    // The weight rows are addressed by the same (ky, kx, chunk) offset, so the [N][kh][kw][Cin] layout is unchanged;
+    // only the order of the f32 accumulation differs.
+    static const int tap_inner_env = getenv("AVCER_GEMM_TAP_INNER") ? atoi(getenv("AVCER_GEMM_TAP_INNER")) : 0;
+    p.tap_inner = tap_inner_env && !x2 && d.kh * d.kw > 1 && d.cin % bk == 0 && d.cin > bk;
     p.sh = d.stride_h; p.sw = d.stride_w; p.ph = d.pad_h; p.pw = d.pad_w; p.dh = d.dil_h; p.dw = d.dil_w;
     p.sB = d.x_stride_b; p.sH = d.x_stride_h; p.sW = d.x_stride_w; p.coff = d.x_coff;
     p.ldY = d.y_ld; p.yoff = d.y_coff; p.ldR = d.r_ld; p.roff = d.r_coff;
