@@ -147,36 +147,18 @@ def timed(pipe, frames, wav, n_total, steps, warmup, device, profile):
     return dt, kern_ms, launches
 
 
-def parity(pipe, n_clips):
-    """max |dprob| of this arithmetic mode against the CPU oracle on a few clips (checker only)."""
-    from oracle import audio as oa
-    from oracle import fusion as of
-    from oracle import video as ov
-
-    sds = [synth.to_torch(f(42)) for f in (synth.static_state_dict, synth.dynamic_state_dict, synth.audio_state_dict)]
-    frames = synth.face_frames(4242, n_clips * T_FRAMES).reshape(n_clips, T_FRAMES, 224, 224, 3)
-    wav = synth.waveforms(4243, n_clips, T_AUDIO)
+def gpu_outputs(pipe, frames, wav):
+    """Product-path outputs for the parity clips of one arithmetic mode, as numpy (no oracle involved)."""
     out = pipe.run_clips(torch.from_numpy(frames), torch.from_numpy(wav), FPS)
-    worst, same = 0.0, True
-    for c in range(n_clips):
-        st, dy = ov.visual_forward(sds[0], sds[1], frames[c], np.ones(T_FRAMES, bool), FPS, batched=True)
-        with torch.no_grad():
-            lg = oa.expr_model_v3_forward(sds[2], torch.from_numpy(oa.normalize(wav[c:c + 1]))).numpy().reshape(1, -1)
-        rows, fr = oa.replicate_per_frame(lg, [(0, T_AUDIO, 0, T_FRAMES)])
-        prob, am = of.fuse(st.astype(np.float32), dy.astype(np.float32), rows, fr)
-        p_aud = of.softmax(lg[:, :7])
-        g_aud = of.softmax(out["audio_logits"][c:c + 1, :7].cpu().numpy())
-        worst = max(worst, float(np.abs(out["static_probs"][c].cpu().numpy() - st).max()),
-                    float(np.abs(of.softmax(out["dynamic_logits"][c].cpu().numpy()) - of.softmax(dy.astype(np.float32))).max()),
-                    float(np.abs(g_aud - p_aud).max()),
-                    float(np.abs(out["compound_prob"][:, c].cpu().numpy() - prob).max()))
-        same = same and bool(np.array_equal(out["compound_argmax"][:, c].cpu().numpy(), am))
-    return worst, same
+    return {k: out[k].cpu().numpy() for k in ("static_probs", "dynamic_logits", "audio_logits", "compound_prob",
+                                              "compound_argmax")}
 
 
-def cpu_baseline(n_clips):
-    """The oracle (CPU restatement of the reference, kind = "port") timed on this box's host cores on a bounded
-    sample of the same workload: batched static CNN over a clip's 16 frames, 4 LSTM evaluations, one audio window."""
+def cpu_baseline(n_clips, gpu_by_mode, n_parity):
+    """The ONLY leg that touches oracle/: the CPU restatement of the reference (kind = "port") is timed on this box's
+    host cores on a bounded sample of the same workload (batched static CNN over a clip's 16 frames, 4 LSTM
+    evaluations, one audio window), and its outputs for the first `n_parity` clips check the GPU outputs of every
+    measured arithmetic mode (gpu_by_mode: name -> gpu_outputs on those same clips)."""
     from oracle import audio as oa
     from oracle import fusion as of
     from oracle import video as ov
@@ -185,19 +167,31 @@ def cpu_baseline(n_clips):
     torch.set_num_threads(cores)
     log(f"cpu baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
     sds = [synth.to_torch(f(42)) for f in (synth.static_state_dict, synth.dynamic_state_dict, synth.audio_state_dict)]
-    frames = synth.face_frames(1234, n_clips * T_FRAMES).reshape(n_clips, T_FRAMES, 224, 224, 3)
-    wav = synth.waveforms(5678, n_clips, T_AUDIO)
+    frames, wav = cpu_sample(n_clips)
 
     def clip(c):
         st, dy = ov.visual_forward(sds[0], sds[1], frames[c], np.ones(T_FRAMES, bool), FPS, batched=True)
         with torch.no_grad():
             lg = oa.expr_model_v3_forward(sds[2], torch.from_numpy(oa.normalize(wav[c:c + 1]))).numpy().reshape(1, -1)
         rows, fr = oa.replicate_per_frame(lg, [(0, T_AUDIO, 0, T_FRAMES)])
-        return of.fuse(st.astype(np.float32), dy.astype(np.float32), rows, fr)
+        prob, am = of.fuse(st.astype(np.float32), dy.astype(np.float32), rows, fr)
+        return st, dy, lg, prob, am
 
     t0 = time.perf_counter()
-    clip(0)  # warm-up
+    ref = [clip(0)]  # warm-up, also parity clip 0
     warm = time.perf_counter() - t0
+    for c in range(1, n_parity):
+        ref.append(clip(c))
+    parity = {}
+    for name, g in gpu_by_mode.items():
+        worst, same = 0.0, True
+        for c, (st, dy, lg, prob, am) in enumerate(ref):
+            worst = max(worst, float(np.abs(g["static_probs"][c] - st).max()),
+                        float(np.abs(of.softmax(g["dynamic_logits"][c]) - of.softmax(dy.astype(np.float32))).max()),
+                        float(np.abs(of.softmax(g["audio_logits"][c:c + 1, :7]) - of.softmax(lg[:, :7])).max()),
+                        float(np.abs(g["compound_prob"][:, c] - prob).max()))
+            same = same and bool(np.array_equal(g["compound_argmax"][:, c], am))
+        parity[name] = (worst, same)
     if warm > 8.0:  # slow host: shrink the sample so the default run stays within minutes
         n_clips = max(1, min(n_clips, int(30.0 / warm)))
     else:  # bounded sample of about 12 s of CPU work
@@ -208,9 +202,16 @@ def cpu_baseline(n_clips):
     for c in range(n_clips):
         clip(c)
     dt = time.perf_counter() - t0
-    return {"value": n_clips / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+    base = {"value": n_clips / dt, "unit": "clips/s", "cores": cores, "kind": "port",
             "sample": f"{n_clips} clips (16 frames batched + 4 LSTM evals + one 2 s window each), torch-CPU fp32 oracle, "
                       f"{dt:.1f} s"}
+    return base, parity
+
+
+def cpu_sample(n_clips):
+    """Inputs of the CPU leg (and of the parity check): same generator and shapes as the GPU workload."""
+    frames = synth.face_frames(1234, n_clips * T_FRAMES).reshape(n_clips, T_FRAMES, 224, 224, 3)
+    return frames, synth.waveforms(5678, n_clips, T_AUDIO)
 
 
 def main():
@@ -276,9 +277,17 @@ def main():
     others = {} if args.no_secondary else {m: measure(m, args.steps, args.warmup) for m in modes if m != args.mode}
 
     if rank == 0:
+        do_cpu = world == 1 and not args.no_cpu
+        gpu_by_mode = {}
+        if do_cpu:  # GPU outputs of every measured mode on the parity clips (the first clips of the CPU sample)
+            pf, pw = cpu_sample(args.cpu_clips)
+            pf, pw = pf[:args.parity_clips], pw[:args.parity_clips]
+            for name in [args.mode] + list(others):
+                set_mode(name)
+                gpu_by_mode[name] = gpu_outputs(pipe, pf, pw)
         set_mode(args.mode)
-        log("parity check against the CPU oracle")
-        dprob, same = parity(pipe, args.parity_clips)
+        base, par = cpu_baseline(args.cpu_clips, gpu_by_mode, args.parity_clips) if do_cpu else (None, {})
+        dprob, same = par.get(args.mode, (None, None))
         out = {
             "metric": "clips/sec (224x224x16f + 2s@16kHz), full AV path: static CNN + LSTM + wav2vec2 audio model + fusion",
             "value": head["clips_per_s"], "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -295,13 +304,13 @@ def main():
         if others:
             out["modes"] = {}
             for name, res in others.items():
-                set_mode(name)
-                d2, s2 = parity(pipe, args.parity_clips)
+                d2, s2 = par.get(name, (None, None))
                 out["modes"][name] = {"value": res["clips_per_s"], "unit": "clips/s", "ms_per_step": res["ms_per_step"],
                                       "dtype": DTYPE[name], "max_dprob_vs_cpu_oracle": d2, "argmax_identical": s2,
-                                      "meets_parity_gate": bool(d2 < 1e-4), "roofline": res["roofline"]}
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_clips)
+                                      "meets_parity_gate": bool(d2 < 1e-4) if d2 is not None else None,
+                                      "roofline": res["roofline"]}
+        if base is not None:
+            out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
