@@ -133,6 +133,51 @@ def static_state_dict(seed: int = 42) -> "OrderedDict[str, np.ndarray]":
     return sd
 
 
+# --------------------------------------------------------------------------- RetinaFace-R50 detector (row f4)
+def retina_state_dict(seed: int = 42) -> "OrderedDict[str, np.ndarray]":
+    """Keys of data/face_detection/ibug/face_detection/retina_face/retina_face.py:46-76 RetinaFace(cfg_re50).state_dict():
+    `body.*` = torchvision ResNet-50 children up to layer4 (IntermediateLayerGetter keeps their names), `fpn.*`,
+    `ssh{1,2,3}.*`, `ClassHead / BboxHead / LandmarkHead .{0,1,2}.conv1x1.*`."""
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    _conv2d(sd, seed, "body.conv1.weight", 64, 3, 7, gain=2.0 / (60.0 * 60.0))   # pixels minus (104, 117, 123)
+    _bn(sd, seed, "body.bn1", 64)
+    cin = 64
+    for li, (planes, blocks, stride) in enumerate(_RESNET_STAGES, start=1):
+        for b in range(blocks):
+            p = f"body.layer{li}.{b}"
+            _conv2d(sd, seed, p + ".conv1.weight", planes, cin, 1)
+            _bn(sd, seed, p + ".bn1", planes)
+            _conv2d(sd, seed, p + ".conv2.weight", planes, planes, 3)
+            _bn(sd, seed, p + ".bn2", planes)
+            _conv2d(sd, seed, p + ".conv3.weight", planes * 4, planes, 1)
+            _bn(sd, seed, p + ".bn3", planes * 4, 0.3, 0.5)
+            if b == 0:
+                _conv2d(sd, seed, p + ".downsample.0.weight", planes * 4, cin, 1, gain=1.0)
+                _bn(sd, seed, p + ".downsample.1", planes * 4)
+            cin = planes * 4
+    for i, c in enumerate((512, 1024, 2048), start=1):
+        _conv2d(sd, seed, f"fpn.output{i}.0.weight", 256, c, 1)
+        _bn(sd, seed, f"fpn.output{i}.1", 256)
+    for i in (1, 2):
+        _conv2d(sd, seed, f"fpn.merge{i}.0.weight", 256, 256, 3)
+        _bn(sd, seed, f"fpn.merge{i}.1", 256)
+    for i in (1, 2, 3):
+        for name, co, ci in (("conv3X3", 128, 256), ("conv5X5_1", 64, 256), ("conv5X5_2", 64, 64), ("conv7X7_2", 64, 64),
+                             ("conv7x7_3", 64, 64)):
+            _conv2d(sd, seed, f"ssh{i}.{name}.0.weight", co, ci, 3)
+            _bn(sd, seed, f"ssh{i}.{name}.1", co)
+    for head, n in (("ClassHead", 4), ("BboxHead", 8), ("LandmarkHead", 20)):
+        for i in range(3):
+            _conv2d(sd, seed, f"{head}.{i}.conv1x1.weight", n, 256, 1, gain=1.0)
+            sd[f"{head}.{i}.conv1x1.bias"] = uniform(seed, f"{head}.{i}.conv1x1.bias", (n,), -0.2, 0.2)
+    return sd
+
+
+def video_frames(seed: int, n: int, h: int, w: int) -> np.ndarray:
+    """uint8 BGR video frames [n, h, w, 3] for the detector."""
+    return u8(seed, "video", (n, h, w, 3))
+
+
 # --------------------------------------------------------------------------- dynamic LSTM
 def dynamic_state_dict(seed: int = 42) -> "OrderedDict[str, np.ndarray]":
     """Keys of architectures/video.py:169-185 LSTMPyTorch().state_dict()."""

@@ -9,9 +9,10 @@ the vectors are its outputs on the synthetic weights/inputs of avcer_amd/synth.p
 Harness-side shims (none of them touch arithmetic on the hot path):
   * cv2 / torchvision / torchaudio are absent: stubbed in sys.modules. PILToTensor is restated as the u8
     HWC->CHW view it is; cv2.imread serves in-memory frames; torch.load / os.listdir serve synthetic data.
-  * face stage (row f4): the RetinaFace network needs torchvision (absent) and weights (absent), so
-    RetinaFacePredictor.__call__ and VideoPredictor.process run UNMODIFIED around a stand-in `net` / `model` that
-    returns seeded tensors; cv2.VideoCapture / cv2.imwrite serve and capture in-memory frames.
+  * face stage (row f4): RetinaFacePredictor.__call__ and VideoPredictor.process run UNMODIFIED around a stand-in
+    `net` / `model` that returns seeded tensors; cv2.VideoCapture / cv2.imwrite serve and capture in-memory frames.
+    The RetinaFace class itself (FPN, SSH, heads) also runs unmodified, around a stand-in for torchvision's
+    `models.resnet50()` / `IntermediateLayerGetter` (torchvision is absent; its published ResNet-50 is restated).
   * transformers 5.x (installed) vs 4.36.2 (pinned): `init_weights()` is made a no-op (all weights are
     overwritten by load_state_dict) and attention is forced to the pinned eager matmul-softmax-matmul.
 """
@@ -603,15 +604,109 @@ def gen_face():
     print("face: writes", len(writes), "tracks", sorted(set(r[1] for r in recs)))
 
 
+# ----------------------------------------------------------------------------- F10 RetinaFace network (row f4)
+def torchvision_resnet50_standin():
+    """torchvision is absent: a stand-in `models.resnet50()` with torchvision's published ResNet-50 definition (children
+    conv1, bn1, relu, maxpool, layer1-4, avgpool, fc; Bottleneck with the stride on the 3x3 convolution; eps 1e-5) and
+    an `IntermediateLayerGetter` that walks named children, so that the REFERENCE's RetinaFace class (FPN, SSH, heads,
+    wiring, softmax) can be constructed and run unmodified."""
+    import torch.nn as nn
+    from collections import OrderedDict
+
+    class Bottleneck(nn.Module):
+        def __init__(self, cin, planes, stride, down):
+            super().__init__()
+            self.conv1 = nn.Conv2d(cin, planes, 1, bias=False); self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False); self.bn2 = nn.BatchNorm2d(planes)
+            self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False); self.bn3 = nn.BatchNorm2d(planes * 4)
+            self.relu = nn.ReLU(inplace=True)
+            self.downsample = nn.Sequential(nn.Conv2d(cin, planes * 4, 1, stride, bias=False),
+                                            nn.BatchNorm2d(planes * 4)) if down else None
+
+        def forward(self, x):
+            y = self.relu(self.bn1(self.conv1(x)))
+            y = self.relu(self.bn2(self.conv2(y)))
+            y = self.bn3(self.conv3(y))
+            return self.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+    class ResNet50(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False); self.bn1 = nn.BatchNorm2d(64)
+            self.relu = nn.ReLU(inplace=True); self.maxpool = nn.MaxPool2d(3, 2, 1)
+            cin = 64
+            for li, (planes, blocks, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)), 1):
+                layers = []
+                for b in range(blocks):
+                    layers.append(Bottleneck(cin, planes, stride if b == 0 else 1, b == 0))
+                    cin = planes * 4
+                setattr(self, f"layer{li}", nn.Sequential(*layers))
+            self.avgpool = nn.AdaptiveAvgPool2d((1, 1)); self.fc = nn.Linear(2048, 1000)
+
+    class IntermediateLayerGetter(nn.ModuleDict):
+        def __init__(self, model, return_layers):
+            layers, want = OrderedDict(), dict(return_layers)
+            for name, module in model.named_children():
+                layers[name] = module
+                want.pop(name, None)
+                if not want:
+                    break
+            super().__init__(layers)
+            self.return_layers = dict(return_layers)
+
+        def forward(self, x):
+            out = OrderedDict()
+            for name, module in self.items():
+                x = module(x)
+                if name in self.return_layers:
+                    out[self.return_layers[name]] = x
+            return out
+
+    return ResNet50, IntermediateLayerGetter
+
+
+def gen_face_net():
+    from data.face_detection.ibug.face_detection.retina_face.config import cfg_re50
+    from data.face_detection.ibug.face_detection.retina_face import retina_face as rf
+
+    rf.models.resnet50, rf._utils.IntermediateLayerGetter = torchvision_resnet50_standin()
+    net = rf.RetinaFace(cfg=cfg_re50, phase="test")
+    sd = synth.to_torch(synth.retina_state_dict(42))
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    net.eval()
+    out = {}
+    for name, (h, w) in (("a", (96, 128)), ("b", (75, 101))):   # b: not a multiple of the strides
+        frame = synth.video_frames(900, 1, h, w)[0]
+        x = torch.from_numpy((frame.astype(int) - np.array([104, 117, 123])).transpose(2, 0, 1)).unsqueeze(0).float()
+        taps = {}
+        hooks = [net.body.register_forward_hook(lambda m, i, o: taps.update({f"body{k}": v for k, v in o.items()})),
+                 net.fpn.register_forward_hook(lambda m, i, o: taps.update({f"fpn{k + 1}": v for k, v in enumerate(o)})),
+                 net.ssh1.register_forward_hook(lambda m, i, o: taps.__setitem__("ssh1", o))]
+        with torch.no_grad():
+            loc, conf, landms = net(x)
+        for hk in hooks:
+            hk.remove()
+        out[f"{name}_size"] = np.array([h, w])
+        out[f"{name}_loc"], out[f"{name}_conf"], out[f"{name}_landms"] = loc[0].numpy(), conf[0].numpy(), landms[0].numpy()
+        for k, v in taps.items():
+            out[f"{name}_{k}_stats"] = stats(v)
+            out[f"{name}_{k}_head16"] = head16(v)
+        print("face net", name, loc.shape, "conf spread", conf[0, :, 1].std().item(), {k: tuple(v.shape) for k, v in taps.items()})
+    np.savez_compressed(os.path.join(HERE, "face_net.npz"), **out)
+
+
 if __name__ == "__main__":
     import transformers  # noqa: F401  (must be imported before the torchvision stub exists)
     from transformers import Wav2Vec2FeatureExtractor  # noqa: F401
     from transformers.models.wav2vec2 import modeling_wav2vec2  # noqa: F401
 
     install_stubs()
-    which = sys.argv[1:] or ["face", "visual", "audio", "fusion", "audio7", "dataset"]
+    which = sys.argv[1:] or ["face", "facenet", "visual", "audio", "fusion", "audio7", "dataset"]
     if "face" in which:  # first: gen_fusion replaces data.get_face_images by a stand-in module
         gen_face()
+    if "facenet" in which:
+        gen_face_net()
     if "visual" in which:
         gen_visual()
     if "audio" in which:
