@@ -51,6 +51,10 @@ SIGNATURES = {
                                      c_stream]),
     "avcer_audio_frame_mean": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p, c_stream]),
+    "avcer_load_face": (C.c_int, [c_ctx, C.c_void_p, C.c_size_t]),
+    "avcer_face_num_priors": (C.c_int, [C.c_int, C.c_int]),
+    "avcer_face_forward": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, c_stream]),
     "avcer_face_decode": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_float, C.c_float, C.c_void_p, c_stream]),
     "avcer_crop_tiles": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,

@@ -297,6 +297,7 @@ extern "C" void avcer_ctx_destroy(avcer_ctx* ctx) {
     free_model(ctx->stat);
     free_model(ctx->dyn);
     free_model(ctx->aud);
+    free_model(ctx->face);
     for (auto& b : ctx->ws)
         if (b.p) (void)hipFree(b.p);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
@@ -466,6 +467,181 @@ extern "C" int avcer_static_forward_nchw(avcer_ctx* ctx, const float* x, int n, 
                                          float* feats, avcer_stream_t stream) {
     if (!x) return ctx ? set_err(ctx, AVCER_EINVAL, "static_forward_nchw: null input") : AVCER_EINVAL;
     return static_forward_impl(ctx, nullptr, x, n, 224, 224, mode, logits, probs, feats, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ RetinaFace-R50 (row f4)
+// ref: data/face_detection/ibug/face_detection/retina_face/retina_face.py:46-115 (RetinaFace, test phase),
+// retina_face_net.py:42-101 (SSH, FPN), torchvision ResNet-50 as the body (children conv1..layer4, return_layers
+// layer2/3/4), retina_face_predictor.py:59-65 (mean subtraction).  Inference BatchNorm (eps 1e-5) is folded by
+// avcer_amd/packing.py; the three 1x1 heads of a pyramid level are one GEMM with 32 (+32 padding) output channels.
+static int face_forward_impl(avcer_ctx* ctx, const uint8_t* frames, int n, int H, int W, int rgb, int mode, float* loc,
+                             float* conf, float* landms, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (!ctx->face.loaded) return set_err(ctx, AVCER_ESTATE, "face detector weights not loaded");
+    if (!frames || !loc || !conf || !landms || n <= 0 || H < 32 || W < 32)
+        return set_err(ctx, AVCER_EINVAL, "face_forward: bad arguments (frames of at least 32x32)");
+    if (mode < AVCER_MODE_FP32 || mode > AVCER_MODE_BF16X3) return set_err(ctx, AVCER_EINVAL, "face_forward: mode %d", mode);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int bf = mode == AVCER_MODE_BF16;
+    const int act = bf ? 1 : (mode == AVCER_MODE_BF16X3 ? 2 : 0);
+    if (bf) TRY(ensure_all_bf16(ctx, ctx->face, st));
+    if (mode == AVCER_MODE_BF16X3) TRY(ensure_all_x3(ctx, ctx->face, st));
+    const size_t es = bf ? 2 : 4;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;       // conv1 7x7/2, padding 3
+    const int PH = 2 * (OH - 1) + 8, PW = 2 * (OW - 1) + 8;      // zero-bordered image the 8x(8x4)-tap stem reads
+    const int MH = (OH - 1) / 2 + 1, MW = (OW - 1) / 2 + 1;      // max-pool 3x3/2, padding 1
+    int fh[5], fw[5];                                             // output extent of layer1..4 (index 1..4)
+    fh[1] = MH; fw[1] = MW;
+    for (int li = 2; li <= 4; ++li) { fh[li] = (fh[li - 1] - 1) / 2 + 1; fw[li] = (fw[li - 1] - 1) / 2 + 1; }
+    const int P = 2 * (fh[2] * fw[2] + fh[3] * fw[3] + fh[4] * fw[4]);
+    // frames per pass: every gathered operand must stay below the 4 GiB buffer-descriptor range
+    const size_t per_frame = std::max({(size_t)PH * PW * 4, (size_t)OH * OW * 64, (size_t)MH * MW * 256}) * 4;
+    const int NB = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, (size_t)0xF0000000u / per_frame));
+    // the largest activation: the stem output or layer1's output (equal for even extents, the latter larger for odd ones)
+    const size_t big = (size_t)NB * std::max((size_t)OH * OW * 64, (size_t)MH * MW * 256);
+    size_t feat_el[5] = {0, 0, 0, 0, 0};
+    for (int li = 2; li <= 4; ++li) feat_el[li] = (size_t)NB * fh[li] * fw[li] * kStages[li - 1][0] * 4;
+    const size_t lvl = (size_t)NB * fh[2] * fw[2];                // positions of the finest pyramid level
+    size_t total = (size_t)NB * PH * PW * 4 * es + 4 * (big * es + 256) + 4096;
+    for (int li = 2; li <= 4; ++li) total += feat_el[li] * es + 256;
+    total += 5 * (lvl * 256 * es + 256) + 2 * (lvl * 64 * es + 256) + lvl * 64 * 4 + 256;
+    void* wsp = nullptr;
+    TRY(ws_reserve(ctx, 3, total, &wsp));
+    Arena ar(wsp, ctx->ws[3].cap);
+    void* Pimg = ar.get((size_t)NB * PH * PW * 4 * es);
+    void* buf[4];
+    for (auto& b : buf) b = ar.get(big * es);
+    void* feat[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int li = 2; li <= 4; ++li) feat[li] = ar.get(feat_el[li] * es);
+    void* pyr[3];      // FPN lateral outputs, finest first
+    for (auto& b : pyr) b = ar.get(lvl * 256 * es);
+    void* mrg = ar.get(lvl * 256 * es);   // merged level (output of merge1 / merge2)
+    void* S = ar.get(lvl * 256 * es);     // SSH output
+    void* t51 = ar.get(lvl * 64 * es);
+    void* t72 = ar.get(lvl * 64 * es);
+    float* hd = (float*)ar.get(lvl * 64 * 4);
+    if (!hd) return set_err(ctx, AVCER_ENOMEM, "face workspace arithmetic");
+
+    Net net{ctx, ctx->face, bf, st, mode == AVCER_MODE_BF16X3};
+    for (int s0 = 0; s0 < n; s0 += NB) {
+        const int nb = std::min(NB, n - s0);
+        net.chk(k_face_pre(ctx, frames + (size_t)s0 * H * W * 3, nb, H, W, PH, PW, rgb, Pimg, bf, st));
+        {
+            avcer_conv_desc d;
+            memset(&d, 0, sizeof(d));
+            d.batch = nb; d.in_h = PH; d.in_w = PW; d.out_h = OH; d.out_w = OW;
+            d.cin = 32; d.kh = 8; d.kw = 1;
+            d.stride_h = 2; d.stride_w = 2; d.dil_h = d.dil_w = 1;
+            d.x_stride_b = (int64_t)PH * PW * 4; d.x_stride_h = (int64_t)PW * 4; d.x_stride_w = 4;
+            d.n = 64; d.y_ld = 64; d.r_ld = 64; d.act = 1;
+            net.gemm(d, "stem.w", net.F("stem.s"), net.F("stem.b"), Pimg, nullptr, buf[0], bf, act);
+        }
+        net.chk(k_maxpool3s2p1(ctx, buf[0], buf[1], nb, OH, OW, 64, MH, MW, act, st));
+        net.tap("face_pool", buf[1], (size_t)nb * MH * MW * 64 * es);
+        void *X = buf[1], *T1 = buf[2], *T2 = buf[3];
+        int h = MH, w = MW, cin = 64;
+        for (int li = 1; li <= 4; ++li) {
+            const int planes = kStages[li - 1][0], blocks = kStages[li - 1][1];
+            for (int b = 0; b < blocks; ++b) {
+                const int stride = b == 0 ? kStages[li - 1][2] : 1;   // torchvision: the stride sits on the 3x3 convolution
+                const std::string p = "l" + std::to_string(li) + "." + std::to_string(b) + ".";
+                const int oh = (h - 1) / stride + 1, ow = (w - 1) / stride + 1;
+                // block output: the ping-pong buffer the input does not occupy, or the kept feature map of the stage
+                void* dst = (b == blocks - 1 && li >= 2) ? feat[li] : (X == buf[0] ? buf[1] : buf[0]);
+                avcer_conv_desc d1 = conv2d_desc(nb, h, h, cin, 1, 1, 1, 0, planes, 1);
+                d1.in_w = w; d1.out_w = w; d1.x_stride_b = (int64_t)h * w * cin; d1.x_stride_h = (int64_t)w * cin;
+                net.gemm(d1, p + "c1.w", net.F(p + "c1.s"), net.F(p + "c1.b"), X, nullptr, T1, act, act);
+                avcer_conv_desc d2 = conv2d_desc(nb, h, h, planes, 3, 3, stride, 1, planes, 1);
+                d2.in_w = w; d2.out_w = ow; d2.x_stride_b = (int64_t)h * w * planes; d2.x_stride_h = (int64_t)w * planes;
+                net.gemm(d2, p + "c2.w", net.F(p + "c2.s"), net.F(p + "c2.b"), T1, nullptr, T2, act, act);
+                avcer_conv_desc d3 = conv2d_desc(nb, oh, oh, planes, 1, 1, 1, 0, planes * 4, 1);
+                d3.in_w = ow; d3.out_w = ow; d3.x_stride_b = (int64_t)oh * ow * planes; d3.x_stride_h = (int64_t)ow * planes;
+                if (b == 0) {
+                    d3.x2_cin = cin; d3.x2_stride = stride;
+                    d3.x2_stride_b = (int64_t)h * w * cin; d3.x2_stride_h = (int64_t)w * cin; d3.x2_stride_w = cin;
+                    net.gemm(d3, p + "c3d.w", nullptr, net.F(p + "c3d.b"), T2, nullptr, dst, act, act, X);
+                } else {
+                    net.gemm(d3, p + "c3.w", net.F(p + "c3.s"), net.F(p + "c3.b"), T2, X, dst, act, act);
+                }
+                X = dst;
+                net.tap(("face_blk" + std::to_string(li) + "_" + std::to_string(b)).c_str(), X, (size_t)nb * oh * ow * planes * 4 * es);
+                if (li == 1 && b == 0) {
+                    net.tap("face_l1b0_c1", T1, (size_t)nb * oh * ow * planes * es);
+                    net.tap("face_l1b0_c2", T2, (size_t)nb * oh * ow * planes * es);
+                    net.tap("face_l1b0", X, (size_t)nb * oh * ow * planes * 4 * es);
+                }
+                h = oh; w = ow; cin = planes * 4;
+            }
+            if (li >= 2) net.tap(("face_body" + std::to_string(li - 1)).c_str(), X, (size_t)nb * h * w * cin * es);
+            else net.tap("face_layer1", X, (size_t)nb * h * w * cin * es);
+        }
+        // FPN (retina_face_net.py:87-101): laterals, then top-down nearest-upsample + add + 3x3 merge
+        for (int i = 0; i < 3; ++i) {
+            const int li = i + 2, c = kStages[li - 1][0] * 4;
+            avcer_conv_desc d = conv2d_desc(nb, fh[li], fh[li], c, 1, 1, 1, 0, 256, 1);
+            d.in_w = fw[li]; d.out_w = fw[li]; d.x_stride_b = (int64_t)fh[li] * fw[li] * c; d.x_stride_h = (int64_t)fw[li] * c;
+            const std::string p = "fpn.o" + std::to_string(i + 1) + ".";
+            net.gemm(d, p + "w", net.F(p + "s"), net.F(p + "b"), feat[li], nullptr, pyr[i], act, act);
+        }
+        auto conv3 = [&](const std::string& p, const void* x, int hh, int ww, int c, void* y, int nout, int y_ld, int y_coff,
+                         int relu, int okind) {
+            avcer_conv_desc d = conv2d_desc(nb, hh, hh, c, 3, 3, 1, 1, nout, relu);
+            d.in_w = ww; d.out_w = ww; d.x_stride_b = (int64_t)hh * ww * c; d.x_stride_h = (int64_t)ww * c;
+            d.y_ld = y_ld; d.y_coff = y_coff;
+            net.gemm(d, p + "w", net.F(p + "s"), net.F(p + "b"), x, nullptr, y, act, okind);
+        };
+        void* lvl_in[3] = {nullptr, nullptr, pyr[2]};
+        net.tap("face_lat1", pyr[0], (size_t)nb * fh[2] * fw[2] * 256 * es);
+        net.tap("face_lat2", pyr[1], (size_t)nb * fh[3] * fw[3] * 256 * es);
+        net.tap("face_lat3", pyr[2], (size_t)nb * fh[4] * fw[4] * 256 * es);
+        net.chk(k_upsample_add(ctx, pyr[1], pyr[2], nb, fh[3], fw[3], fh[4], fw[4], 256, act, st));
+        void* m2 = T1;   // the ping-pong buffers of the body are free again
+        net.tap("face_sum2", pyr[1], (size_t)nb * fh[3] * fw[3] * 256 * es);
+        conv3("fpn.m2.", pyr[1], fh[3], fw[3], 256, m2, 256, 256, 0, 1, act);
+        net.tap("face_fpn2", m2, (size_t)nb * fh[3] * fw[3] * 256 * es);
+        net.chk(k_upsample_add(ctx, pyr[0], m2, nb, fh[2], fw[2], fh[3], fw[3], 256, act, st));
+        conv3("fpn.m1.", pyr[0], fh[2], fw[2], 256, mrg, 256, 256, 0, 1, act);
+        lvl_in[0] = mrg; lvl_in[1] = m2;
+        net.tap("face_fpn1", mrg, (size_t)nb * fh[2] * fw[2] * 256 * es);
+        // SSH + heads per level (retina_face_net.py:59-73, retina_face.py:101-113)
+        int row0 = 0;
+        for (int i = 0; i < 3; ++i) {
+            const int hh = fh[i + 2], ww = fw[i + 2];
+            const std::string p = "ssh" + std::to_string(i + 1) + ".";
+            conv3(p + "c3.", lvl_in[i], hh, ww, 256, S, 128, 256, 0, 1, act);       // relu(cat(...)) = per-branch relu
+            conv3(p + "c51.", lvl_in[i], hh, ww, 256, t51, 64, 64, 0, 1, act);
+            conv3(p + "c52.", t51, hh, ww, 64, S, 64, 256, 128, 1, act);
+            conv3(p + "c72.", t51, hh, ww, 64, t72, 64, 64, 0, 1, act);
+            conv3(p + "c73.", t72, hh, ww, 64, S, 64, 256, 192, 1, act);
+            if (i == 0) net.tap("face_ssh1", S, (size_t)nb * hh * ww * 256 * es);
+            const std::string hp = "head" + std::to_string(i) + ".";
+            net.gemm(linear_desc((long)nb * hh * ww, 256, 64, 0), hp + "w", nullptr, net.F(hp + "b"), S, nullptr, hd, act, 0);
+            net.chk(k_face_head(ctx, hd, 64, nb, hh * ww, row0, P, loc + (size_t)s0 * P * 4, conf + (size_t)s0 * P * 2,
+                                landms + (size_t)s0 * P * 10, st));
+            row0 += hh * ww * 2;
+        }
+        if (net.err != AVCER_OK) return net.err;
+    }
+    return net.err;
+}
+
+extern "C" int avcer_load_face(avcer_ctx* ctx, const void* blob, size_t nbytes) {
+    if (!ctx) return AVCER_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return load_blob(ctx, ctx->face, blob, nbytes);
+}
+
+extern "C" int avcer_face_num_priors(int h, int w) {
+    if (h < 1 || w < 1) return 0;
+    int fh = ((h - 1) / 2 + 1 - 1) / 2 + 1, fw = ((w - 1) / 2 + 1 - 1) / 2 + 1, p = 0;
+    for (int li = 2; li <= 4; ++li) { fh = (fh - 1) / 2 + 1; fw = (fw - 1) / 2 + 1; p += 2 * fh * fw; }
+    return p;
+}
+
+extern "C" int avcer_face_forward(avcer_ctx* ctx, const uint8_t* frames, int n, int h, int w, int rgb, int mode, float* loc,
+                                  float* conf, float* landms, avcer_stream_t stream) {
+    return face_forward_impl(ctx, frames, n, h, w, rgb ? 1 : 0, mode, loc, conf, landms, stream);
 }
 
 extern "C" int avcer_gather_windows(avcer_ctx* ctx, const float* feats, const int32_t* idx, int nwin, float* out,

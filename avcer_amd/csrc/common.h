@@ -39,7 +39,7 @@ struct Model {
 struct avcer_ctx {
     int device = 0;
     char err[512] = {0};
-    Model stat, dyn, aud;
+    Model stat, dyn, aud, face;
     int aud_classes = 0;
     int static_batch = 1024;  // frames per internal pass of the static CNN (4 GiB buffer-descriptor limit at f32)
     int static_chunk = 0;     // frames per depth-first chunk of the CNN front end (0 = layer by layer)
@@ -112,5 +112,10 @@ int k_audio_chunks(avcer_ctx*, const float* wav, const int32_t* starts, const in
 int k_split_weights(avcer_ctx*, const float* w, bf16_t* out, size_t n, hipStream_t);
 int k_face_decode(avcer_ctx*, const float* loc, const float* conf, const float* landms, const float* priors, int P, int im_h,
                   int im_w, float var0, float var1, float* dets, hipStream_t);
+int k_face_pre(avcer_ctx*, const uint8_t* frames, int n, int h, int w, int ph, int pw, int rgb, void* out, int bf16, hipStream_t);
+int k_maxpool3s2p1(avcer_ctx*, const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int kind, hipStream_t);
+int k_upsample_add(avcer_ctx*, void* y, const void* coarse, int n, int h, int w, int ch, int cw, int c, int kind, hipStream_t);
+int k_face_head(avcer_ctx*, const float* hd, int ld, int n, int hw, int row0, int P, float* loc, float* conf, float* landms,
+                hipStream_t);
 int k_crop_tiles(avcer_ctx*, const uint8_t* frames, int T, int H, int W, const int32_t* rects, int n, int swap_rb,
                  uint8_t* tiles, hipStream_t);

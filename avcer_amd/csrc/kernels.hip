@@ -201,6 +201,108 @@ __global__ void crop_tiles_kernel(const uint8_t* __restrict__ frames, int T, int
     o[2] = px[8] | (px[9] << 8) | (px[10] << 16) | ((uint32_t)px[11] << 24);
 }
 
+// ------------------------------------------------------------------------------------------------ RetinaFace network (row f4)
+// retina_face_predictor.py:59-65: BGR pixels minus (104, 117, 123) (an RGB frame is flipped first), written as a
+// zero-bordered NHWC4 image [n, ph, pw, 4] with the picture at offset (3, 3): the border is torchvision's conv1 padding
+// of 3 plus the extra rows/columns that let the 7x7/2 stem run as an un-padded 8x(8 pixels x 4 channels) contraction.
+template <typename T>
+__global__ void face_pre_kernel(const uint8_t* __restrict__ in, T* __restrict__ out, int n, int h, int w, int ph, int pw,
+                                int rgb) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n * ph * pw;
+    if (idx >= total) return;
+    const int x = idx % pw;
+    const int y = (idx / pw) % ph;
+    const int b = idx / ((long)ph * pw);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const int sy = y - 3, sx = x - 3;
+    if (sy >= 0 && sy < h && sx >= 0 && sx < w) {
+        const uint8_t* px = in + (((long)b * h + sy) * w + sx) * 3;
+        v[0] = (float)((int)px[rgb ? 2 : 0] - 104);
+        v[1] = (float)((int)px[1] - 117);
+        v[2] = (float)((int)px[rgb ? 0 : 2] - 123);
+    }
+    st4<T>(out, idx * 4, v);
+}
+
+// torchvision ResNet max-pool: 3x3, stride 2, padding 1 (padded taps never win); NHWC.
+template <typename T>
+__global__ void maxpool3s2p1_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h, int w, int c, int oh, int ow) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = c / 4;
+    const long total = (long)n * oh * ow * c4;
+    if (idx >= total) return;
+    const int cc = (idx % c4) * 4;
+    long t = idx / c4;
+    const int ox = t % ow; t /= ow;
+    const int oy = t % oh;
+    const int b = t / oh;
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    bool nan[4] = {false, false, false, false};
+    for (int dy = 0; dy < 3; ++dy) {
+        const int iy = oy * 2 - 1 + dy;
+        if (iy < 0 || iy >= h) continue;
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ix = ox * 2 - 1 + dx;
+            if (ix < 0 || ix >= w) continue;
+            float v[4];
+            ld4<T>(x, (((long)b * h + iy) * w + ix) * c + cc, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { m[j] = fmaxf(m[j], v[j]); nan[j] |= v[j] != v[j]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (nan[j]) m[j] = NAN;
+    st4<T>(y, (((long)b * oh + oy) * ow + ox) * c + cc, m);
+}
+
+// retina_face_net.py:92-98: y += nearest-upsampled coarser level (F.interpolate(mode="nearest"): src = floor(dst*in/out))
+template <typename T>
+__global__ void upsample_add_kernel(T* __restrict__ y, const T* __restrict__ coarse, int n, int h, int w, int ch, int cw, int c) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = c / 4;
+    const long total = (long)n * h * w * c4;
+    if (idx >= total) return;
+    const int cc = (idx % c4) * 4;
+    long t = idx / c4;
+    const int x = t % w; t /= w;
+    const int yy = t % h;
+    const int b = t / h;
+    const int sy = min((int)floorf((float)yy * ((float)ch / (float)h)), ch - 1);
+    const int sx = min((int)floorf((float)x * ((float)cw / (float)w)), cw - 1);
+    float a[4], u[4];
+    const long o = (((long)b * h + yy) * w + x) * c + cc;
+    ld4<T>(y, o, a);
+    ld4<T>(coarse, (((long)b * ch + sy) * cw + sx) * c + cc, u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] += u[j];
+    st4<T>(y, o, a);
+}
+
+// retina_face.py:9-43,104-113: per position the fused head GEMM produced 32 values = class [2 anchors x 2], bbox
+// [2 x 4], landmarks [2 x 10] (row stride ld); scatter them anchor-major into loc / conf (softmax over the 2 classes,
+// F.softmax(dim=-1)) / landms at `row0` of an image with P rows in all.
+__global__ void face_head_kernel(const float* __restrict__ hd, int ld, int n, int hw, int row0, int P, float* __restrict__ loc,
+                                 float* __restrict__ conf, float* __restrict__ landms) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)n * hw * 2) return;
+    const int a = idx & 1;
+    const long pos = idx >> 1;            // b * hw + cell
+    const int b = pos / hw;
+    const long cell = pos - (long)b * hw;
+    const float* v = hd + pos * ld;
+    const long r = (long)b * P + row0 + cell * 2 + a;
+    const float c0 = v[2 * a], c1 = v[2 * a + 1];
+    const float mx = fmaxf(c0, c1);
+    const float e0 = expf(c0 - mx), e1 = expf(c1 - mx);
+    conf[2 * r] = e0 / (e0 + e1);
+    conf[2 * r + 1] = e1 / (e0 + e1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) loc[4 * r + j] = v[4 + 4 * a + j];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) landms[10 * r + j] = v[12 + 10 * a + j];
+}
+
 // get_prob_video.py:115-123: window rows = relu(features) gathered by index into [nwin, 10, 512]
 __global__ void gather_windows_kernel(const float* __restrict__ feats, const int32_t* __restrict__ idx, float* __restrict__ out,
                                       long total4) {
@@ -1116,6 +1218,43 @@ int k_crop_tiles(avcer_ctx* ctx, const uint8_t* frames, int T, int H, int W, con
                  uint8_t* tiles, hipStream_t st) {
     crop_tiles_kernel<<<cdiv((long)n * 224 * 56, 256), 256, 0, st>>>(frames, T, H, W, rects, n, swap_rb, tiles);
     CHECK_LAUNCH(ctx, "crop_tiles");
+    return AVCER_OK;
+}
+
+int k_face_pre(avcer_ctx* ctx, const uint8_t* frames, int n, int h, int w, int ph, int pw, int rgb, void* out, int bf16,
+               hipStream_t st) {
+    const long total = (long)n * ph * pw;
+    if (bf16) face_pre_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>(frames, (bf16_t*)out, n, h, w, ph, pw, rgb);
+    else face_pre_kernel<float><<<cdiv(total, 256), 256, 0, st>>>(frames, (float*)out, n, h, w, ph, pw, rgb);
+    CHECK_LAUNCH(ctx, "face_pre");
+    return AVCER_OK;
+}
+
+int k_maxpool3s2p1(avcer_ctx* ctx, const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int kind, hipStream_t st) {
+    const long total = (long)n * oh * ow * (c / 4);
+    const int grid = cdiv(total, 256);
+    if (kind == 1) maxpool3s2p1_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, n, h, w, c, oh, ow);
+    else if (kind == 2) maxpool3s2p1_kernel<sp32_t><<<grid, 256, 0, st>>>((const sp32_t*)x, (sp32_t*)y, n, h, w, c, oh, ow);
+    else maxpool3s2p1_kernel<float><<<grid, 256, 0, st>>>((const float*)x, (float*)y, n, h, w, c, oh, ow);
+    CHECK_LAUNCH(ctx, "maxpool3s2p1");
+    return AVCER_OK;
+}
+
+int k_upsample_add(avcer_ctx* ctx, void* y, const void* coarse, int n, int h, int w, int ch, int cw, int c, int kind,
+                   hipStream_t st) {
+    const long total = (long)n * h * w * (c / 4);
+    const int grid = cdiv(total, 256);
+    if (kind == 1) upsample_add_kernel<bf16_t><<<grid, 256, 0, st>>>((bf16_t*)y, (const bf16_t*)coarse, n, h, w, ch, cw, c);
+    else if (kind == 2) upsample_add_kernel<sp32_t><<<grid, 256, 0, st>>>((sp32_t*)y, (const sp32_t*)coarse, n, h, w, ch, cw, c);
+    else upsample_add_kernel<float><<<grid, 256, 0, st>>>((float*)y, (const float*)coarse, n, h, w, ch, cw, c);
+    CHECK_LAUNCH(ctx, "upsample_add");
+    return AVCER_OK;
+}
+
+int k_face_head(avcer_ctx* ctx, const float* hd, int ld, int n, int hw, int row0, int P, float* loc, float* conf,
+                float* landms, hipStream_t st) {
+    face_head_kernel<<<cdiv((long)n * hw * 2, 256), 256, 0, st>>>(hd, ld, n, hw, row0, P, loc, conf, landms);
+    CHECK_LAUNCH(ctx, "face_head");
     return AVCER_OK;
 }
 

@@ -81,6 +81,21 @@ class Engine:
         self._load(self.lib.avcer_load_audio, packing.pack_audio(state_dict))
         self.audio_classes = self.lib.avcer_audio_num_classes(self.ctx)
 
+    def load_face(self, state_dict):
+        self._load(self.lib.avcer_load_face, packing.pack_face(state_dict))
+
+    def face_forward(self, frames_u8, mode: int = MODE_FP32, rgb: bool = False):
+        """frames u8 [N,H,W,3] (BGR unless rgb) -> (loc [N,P,4], conf [N,P,2] softmaxed, landms [N,P,10])."""
+        x = self._dev(frames_u8, torch.uint8)
+        if x.dim() != 4 or x.shape[-1] != 3:
+            raise ValueError(f"frames must be [N,H,W,3] uint8, got {tuple(x.shape)}")
+        n, h, w = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+        p = int(self.lib.avcer_face_num_priors(h, w))
+        loc, conf, lm = self._new(n, p, 4), self._new(n, p, 2), self._new(n, p, 10)
+        self._check(self.lib.avcer_face_forward(self.ctx, _ptr(x), n, h, w, 1 if rgb else 0, mode, _ptr(loc), _ptr(conf),
+                                                _ptr(lm), self._stream()))
+        return loc, conf, lm
+
     def set_static_batch(self, frames: int):
         self._check(self.lib.avcer_set_static_batch(self.ctx, int(frames)))
 

@@ -9,10 +9,10 @@ Mirrors, with the reference's names and argument meaning:
 
 What runs where: box / landmark decoding and the crop + NEAREST resize into the u8 tile buffer are HIP kernels
 (`avcer_face_decode`, `avcer_crop_tiles`); the confidence filter, NMS, top-k and the IoU/Hungarian tracker act on a few
-dozen boxes per frame and stay on the host, as in the reference (numpy / scipy there too).  The RetinaFace network
-itself is not part of this build (torchvision ResNet-50 + FPN + SSH, weights not shipped): `VideoTiler.process` takes
-the per-frame head outputs or detections as input.  Tiles go straight to `avcer_static_forward`; the reference's JPEG
-file round trip (cv2.imwrite -> PIL.Image.open) is gone, which is the only intended difference.
+dozen boxes per frame and stay on the host, as in the reference (numpy / scipy there too).  The RetinaFace-R50
+network runs on the same implicit-GEMM kernel as the recognition models (`avcer_face_forward`, mirror
+`RetinaFacePredictor` below).  Tiles go straight to `avcer_static_forward`; the reference's JPEG file round trip
+(cv2.imwrite -> PIL.Image.open) is gone, which is the only intended difference.  Video decoding is not part of this build.
 """
 from __future__ import annotations
 
@@ -96,6 +96,23 @@ class FaceDetections:
         dets = dets[keep][: self.top_k]
         sel = np.where(dets[:, 4] >= self.threshold)[0]
         return dets[sel] if len(sel) else np.empty((0, 15), dtype=np.float32)
+
+
+class RetinaFacePredictor:
+    """`RetinaFacePredictor(threshold, device, model)` (retina_face_predictor.py:17-108) on the HIP path: the network,
+    box decoding and the host-side filter / NMS / top-k.  `state_dict` = RetinaFace(cfg_re50).state_dict() (the file
+    `Resnet50_Final.pth`, with or without the `module.` prefix)."""
+
+    def __init__(self, engine, state_dict, threshold: float = 0.8, mode: int = 0):
+        self.engine, self.mode = engine, mode
+        engine.load_face(state_dict)
+        self.post = FaceDetections(engine, threshold=threshold)
+
+    def __call__(self, image, rgb: bool = True) -> np.ndarray:
+        """image u8 [H,W,3] -> detections [k,15] = x0, y0, x1, y1, score, 5 landmarks (float32)."""
+        img = image if torch.is_tensor(image) else torch.from_numpy(np.ascontiguousarray(image))
+        loc, conf, lm = self.engine.face_forward(img[None], self.mode, rgb=rgb)
+        return self.post(loc[0], conf[0], lm[0], (int(img.shape[0]), int(img.shape[1])))
 
 
 class SimpleFaceTracker:

@@ -81,6 +81,50 @@ def pack_static(sd) -> "OrderedDict[str, np.ndarray]":
     return out
 
 
+def pack_face(sd) -> "OrderedDict[str, np.ndarray]":
+    """RetinaFace(cfg_re50).state_dict() (retina_face/retina_face.py:46-76; `body.*` = torchvision ResNet-50 children)."""
+    eps = 1e-5  # torch.nn.BatchNorm2d default, used by torchvision's ResNet and by retina_face_net.py
+    sd = {(k.split("module.", 1)[-1] if k.startswith("module.") else k): v for k, v in sd.items()}  # predictor.py:28-33
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    w = _f32(sd["body.conv1.weight"])  # [64, 3, 7, 7] -> 8 tap rows x (8 pixels x 4 channels), zero-filled
+    stem = np.zeros((64, 8, 8, 4), np.float32)
+    stem[:, :7, :7, :3] = w.transpose(0, 2, 3, 1)
+    out["stem.w"] = stem.reshape(64, 256)
+    out["stem.s"], out["stem.b"] = _bn_fold(sd, "body.bn1", eps)
+    for li, (planes, blocks, _) in enumerate(RESNET_STAGES, start=1):
+        for b in range(blocks):
+            src, dst = f"body.layer{li}.{b}", f"l{li}.{b}"
+            for i in (1, 2, 3):
+                out[f"{dst}.c{i}.w"] = _conv_w(sd[f"{src}.conv{i}.weight"])
+                out[f"{dst}.c{i}.s"], out[f"{dst}.c{i}.b"] = _bn_fold(sd, f"{src}.bn{i}", eps)
+            if b == 0:  # conv3 + downsample as one contraction over K = [t2 | x strided], as in pack_static
+                wd = _conv_w(sd[f"{src}.downsample.0.weight"])
+                s_d, b_d = _bn_fold(sd, f"{src}.downsample.1", eps)
+                w3, s3, b3 = out.pop(f"{dst}.c3.w"), out.pop(f"{dst}.c3.s"), out.pop(f"{dst}.c3.b")
+                out[f"{dst}.c3d.w"] = np.ascontiguousarray(np.concatenate([w3 * s3[:, None], wd * s_d[:, None]], axis=1))
+                out[f"{dst}.c3d.b"] = (b3 + b_d).astype(np.float32)
+    for i in (1, 2, 3):
+        out[f"fpn.o{i}.w"] = _conv_w(sd[f"fpn.output{i}.0.weight"])
+        out[f"fpn.o{i}.s"], out[f"fpn.o{i}.b"] = _bn_fold(sd, f"fpn.output{i}.1", eps)
+    for i in (1, 2):
+        out[f"fpn.m{i}.w"] = _conv_w(sd[f"fpn.merge{i}.0.weight"])
+        out[f"fpn.m{i}.s"], out[f"fpn.m{i}.b"] = _bn_fold(sd, f"fpn.merge{i}.1", eps)
+    for i in (1, 2, 3):
+        for src, dst in (("conv3X3", "c3"), ("conv5X5_1", "c51"), ("conv5X5_2", "c52"), ("conv7X7_2", "c72"),
+                         ("conv7x7_3", "c73")):
+            out[f"ssh{i}.{dst}.w"] = _conv_w(sd[f"ssh{i}.{src}.0.weight"])
+            out[f"ssh{i}.{dst}.s"], out[f"ssh{i}.{dst}.b"] = _bn_fold(sd, f"ssh{i}.{src}.1", eps)
+    for i in range(3):  # the three 1x1 heads of a level as one [64, 256] GEMM: class 0-3, bbox 4-11, landmarks 12-31
+        wh, bh = np.zeros((64, 256), np.float32), np.zeros((64,), np.float32)
+        row = 0
+        for head, nrow in (("ClassHead", 4), ("BboxHead", 8), ("LandmarkHead", 20)):
+            wh[row:row + nrow] = _f32(sd[f"{head}.{i}.conv1x1.weight"]).reshape(nrow, 256)
+            bh[row:row + nrow] = _f32(sd[f"{head}.{i}.conv1x1.bias"])
+            row += nrow
+        out[f"head{i}.w"], out[f"head{i}.b"] = wh, bh
+    return out
+
+
 def pack_dynamic(sd) -> "OrderedDict[str, np.ndarray]":
     """LSTMPyTorch state_dict (architectures/video.py:169-185)."""
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()

@@ -114,6 +114,18 @@ int avcer_audio_chunks(avcer_ctx* ctx, const float* wav, const int32_t* starts, 
 int avcer_audio_frame_mean(avcer_ctx* ctx, const float* win_logits, const int32_t* frame_lo, const int32_t* frame_hi,
                            int n_win, int c, int n_frames, float* out, int32_t* count, avcer_stream_t stream);
 
+/* RetinaFace-R50 detector network (row f4).
+ *   ref: retina_face/retina_face.py:46-115 (RetinaFace, phase "test"), retina_face_net.py:42-101 (SSH, FPN), torchvision
+ *        ResNet-50 body (layer2/3/4 returned), retina_face_predictor.py:59-65 (pixels minus 104, 117, 123)
+ * avcer_load_face: packed weights (avcer_amd.packing.pack_face of RetinaFace(cfg_re50).state_dict()).
+ * avcer_face_forward: frames u8 [n,h,w,3] in cv2's BGR order (rgb != 0: RGB, flipped first, as the predictor does),
+ *   any h, w >= 32 -> loc f32 [n,P,4], conf f32 [n,P,2] (softmaxed), landms f32 [n,P,10] with
+ *   P = avcer_face_num_priors(h, w) rows in PriorBox order; feed them to avcer_face_decode. */
+int avcer_load_face(avcer_ctx* ctx, const void* packed, size_t nbytes);
+int avcer_face_num_priors(int h, int w);
+int avcer_face_forward(avcer_ctx* ctx, const uint8_t* frames, int n, int h, int w, int rgb, int mode, float* loc,
+                       float* conf, float* landms, avcer_stream_t stream);
+
 /* Face stage ("next" row f4): the arithmetic either side of the RetinaFace network.
  *   avcer_face_decode  ref: data/face_detection/ibug/face_detection/retina_face/retina_face_predictor.py:70-82,
  *                            box_utils.py:210-249 (decode, decode_landm), scaled to pixels

@@ -1,0 +1,76 @@
+"""RetinaFace-R50 detector on the GPU (row f4) against vectors produced by the reference's RetinaFace class
+(tests/golden/face_net.npz) and against the CPU oracle on other frame sizes."""
+import numpy as np
+import pytest
+import torch
+
+from avcer_amd import face_tiles as ft
+from avcer_amd import synth
+from avcer_amd.engine import MODE_BF16, MODE_BF16X3, MODE_FP32
+from oracle import face as of
+from oracle import retina as orf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sd_retina():
+    return synth.to_torch(synth.retina_state_dict(42))
+
+
+@pytest.fixture(scope="module")
+def engine_face(engine, sd_retina):
+    engine.load_face(sd_retina)
+    return engine
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+@pytest.mark.parametrize("mode,tol", [(MODE_FP32, 1e-4), (MODE_BF16X3, 1e-4)])
+def test_network_matches_reference_class(engine_face, golden, name, mode, tol):
+    g = golden("face_net")
+    h, w = (int(v) for v in g[f"{name}_size"])
+    frame = synth.video_frames(900, 1, h, w)
+    loc, conf, lm = (t[0].cpu().numpy() for t in engine_face.face_forward(frame, mode))
+    assert loc.shape == g[f"{name}_loc"].shape and conf.shape == g[f"{name}_conf"].shape
+    print(name, mode, "max|dloc|", np.abs(loc - g[f"{name}_loc"]).max(), "max|dconf|", np.abs(conf - g[f"{name}_conf"]).max(),
+          "max|dlandm|", np.abs(lm - g[f"{name}_landms"]).max())
+    assert np.abs(conf - g[f"{name}_conf"]).max() < tol            # probabilities: the 1e-4 gate in f32
+    assert np.abs(loc - g[f"{name}_loc"]).max() < 10 * tol         # raw regression outputs, |x| up to ~10
+    assert np.abs(lm - g[f"{name}_landms"]).max() < 10 * tol
+
+
+def test_bf16_mode_is_close_but_not_parity(engine_face, golden):
+    g = golden("face_net")
+    frame = synth.video_frames(900, 1, 96, 128)
+    _, conf, _ = engine_face.face_forward(frame, MODE_BF16)
+    d = np.abs(conf[0].cpu().numpy() - g["a_conf"]).max()
+    print("bf16 max|dconf|", d)
+    assert d < 0.1
+
+
+def test_batch_and_rgb_against_oracle(engine_face, sd_retina):
+    frames = synth.video_frames(77, 3, 150, 214)                    # odd sizes, three frames in one call
+    loc, conf, lm = engine_face.face_forward(frames, MODE_FP32)
+    for i in range(3):
+        rl, rc, rm = orf.retina_forward(sd_retina, orf.preprocess(frames[i]))
+        assert np.abs(conf[i].cpu().numpy() - rc[0].numpy()).max() < 1e-4
+        assert np.abs(loc[i].cpu().numpy() - rl[0].numpy()).max() < 1e-3
+        assert np.abs(lm[i].cpu().numpy() - rm[0].numpy()).max() < 1e-3
+    l2, c2, _ = engine_face.face_forward(np.ascontiguousarray(frames[:1, :, :, ::-1]), MODE_FP32, rgb=True)
+    np.testing.assert_array_equal(c2[0].cpu().numpy(), conf[0].cpu().numpy())
+    assert engine_face.lib.avcer_face_num_priors(150, 214) == len(of.prior_boxes((150, 214))) == loc.shape[1]
+
+
+def test_predictor_chain_matches_oracle_chain(engine_face, sd_retina):
+    frame = synth.video_frames(5, 1, 120, 160)[0]
+    pred = ft.RetinaFacePredictor(engine_face, sd_retina, threshold=0.5, mode=MODE_FP32)
+    got = pred(frame, rgb=False)
+    rl, rc, rm = orf.retina_forward(sd_retina, orf.preprocess(frame))
+    ref = of.detections(rl[0].numpy(), rc[0].numpy(), rm[0].numpy(), (120, 160), threshold=0.5)
+    assert got.shape == ref.shape and got.shape[0] > 0
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-2)      # pixels
+
+
+def test_rejects_bad_arguments(engine_face):
+    with pytest.raises(Exception):
+        engine_face.face_forward(np.zeros((1, 16, 16, 3), np.uint8), MODE_FP32)
