@@ -114,6 +114,14 @@ class RetinaFacePredictor:
         loc, conf, lm = self.engine.face_forward(img[None], self.mode, rgb=rgb)
         return self.post(loc[0], conf[0], lm[0], (int(img.shape[0]), int(img.shape[1])))
 
+    def batch(self, frames, rgb: bool = False) -> List[np.ndarray]:
+        """frames u8 [T,H,W,3] -> one detection array per frame; the network runs once over the whole batch (the
+        reference calls it frame by frame, get_face_images.py:49)."""
+        x = frames if torch.is_tensor(frames) else torch.from_numpy(np.ascontiguousarray(frames))
+        loc, conf, lm = self.engine.face_forward(x, self.mode, rgb=rgb)
+        size = (int(x.shape[1]), int(x.shape[2]))
+        return [self.post(loc[t], conf[t], lm[t], size) for t in range(int(x.shape[0]))]
+
 
 class SimpleFaceTracker:
     """IoU + Hungarian face tracker; ids start at 1, a frame without faces drops every tracklet."""

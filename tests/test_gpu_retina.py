@@ -71,6 +71,14 @@ def test_predictor_chain_matches_oracle_chain(engine_face, sd_retina):
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-2)      # pixels
 
 
+def test_batch_equals_frame_by_frame(engine_face, sd_retina):
+    frames = synth.video_frames(11, 4, 96, 128)
+    pred = ft.RetinaFacePredictor(engine_face, sd_retina, threshold=0.3, mode=MODE_BF16X3)
+    together = pred.batch(frames, rgb=False)
+    for t in range(4):
+        np.testing.assert_array_equal(together[t], pred(frames[t], rgb=False))
+
+
 def test_rejects_bad_arguments(engine_face):
     with pytest.raises(Exception):
         engine_face.face_forward(np.zeros((1, 16, 16, 3), np.uint8), MODE_FP32)
