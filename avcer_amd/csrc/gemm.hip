@@ -70,6 +70,7 @@ struct GemmParams {
     int ablate;  // test-only (env AVCER_GEMM_ABLATE): 1 = skip MFMA, 2 = skip DMA loads, 4 = skip the x3 operand split,
                  // 8 = skip the W-tile DMA (half the L2->LDS bytes; results are garbage, timing only)
     int KH;
+    int fast;  // pad-free gather with a scalar K / tap advance (see AVCER_ISSUE_TILES)
     int tap_inner;  // K-steps walk (channel chunk, ky, kx) instead of (ky, kx, channel chunk): see launch_conv_gemm
 };
 
@@ -78,9 +79,10 @@ constexpr unsigned OOB = 0xFFFFFF00u;  // voffset that always fails the buffer b
 
 // 16 bytes per lane, global -> LDS (wave-uniform LDS base + lane * 16); zeros when voff fails the bounds check
 template <typename Rsrc>
-__device__ __forceinline__ void dma16(Rsrc rs, char* lds_wave_base, unsigned voff) {
+__device__ __forceinline__ void dma16(Rsrc rs, char* lds_wave_base, unsigned voff, unsigned soff = 0u) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+    // soff: wave-uniform byte offset (SGPR operand of the instruction), added to the per-lane voff by the hardware
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 #endif
 }
 
@@ -430,6 +432,7 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
     unsigned a_off[A_ISS];                                                                                          \
     unsigned a_off2[A_ISS];                                                                                         \
     unsigned a_offk[A_ISS];                                                                                         \
+    unsigned a_off2k[A_ISS];                                                                                        \
     int a_iy[A_ISS], a_ix[A_ISS], a_kc[A_ISS];                                                                      \
     _Pragma("unroll") for (int j = 0; j < A_ISS; ++j) {                                                             \
         const int lrow = dw * (A_ISS * 8) + j * 8 + lrow8;                                                          \
@@ -448,6 +451,8 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
         a_kc[j] = (slot ^ swz_key(lrow)) * VEC;                                                                     \
         a_offk[j] = a_off[j] + (unsigned)(a_kc[j] * ES);                                                            \
         a_off2[j] = ok ? (unsigned)(((long)b * p.sB2 + (long)oy * p.st2 * p.sH2 + (long)ox * p.st2 * p.sW2 + p.coff2) * ES) : OOB;\
+        a_off2k[j] = ok ? a_off2[j] + (unsigned)(a_kc[j] * ES) : OOB;                                               \
+        if (!ok) a_offk[j] = OOB;                                                                                   \
     }                                                                                                               \
     unsigned w_off[B_ISS];                                                                                          \
     _Pragma("unroll") for (int j = 0; j < B_ISS; ++j) {                                                             \
@@ -462,7 +467,18 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
     do {                                                                                                            \
         char* sa_ = smem + (buf) * TILE_BYTES + dw * (A_ISS * 1024);                                                \
         char* sb_ = smem + (buf) * TILE_BYTES + BMT * ROWB + dw * (B_ISS * 1024);                                   \
-        if (kdone >= p.K1) {                                                                                        \
+        if (p.fast) {                                                                                               \
+            /* no padding anywhere and every tap of every valid row in range: the per-lane offsets never change, */ \
+            /* the K / tap advance is a scalar operand of the DMA instruction -> no vector arithmetic at all    */ \
+            if (kdone >= p.K1) {                                                                                    \
+                const unsigned so = (unsigned)((kdone - p.K1) * ES);                                                \
+                _Pragma("unroll") for (int j = 0; j < A_ISS; ++j) dma16(x2rs, sa_ + j * 1024, a_off2k[j], so);      \
+            } else {                                                                                                \
+                const unsigned so = (unsigned)(((long)ky * p.dh * p.sH + (long)kx * p.dw * p.sW + kc) * ES);        \
+                _Pragma("unroll") for (int j = 0; j < A_ISS; ++j) dma16(xrs, sa_ + j * 1024, a_offk[j], so);        \
+            }                                                                                                       \
+            _Pragma("unroll") for (int j = 0; j < B_ISS; ++j) dma16(wrs, sb_ + j * 1024, w_off[j], wk);             \
+        } else if (kdone >= p.K1) {                                                                                 \
             _Pragma("unroll") for (int j = 0; j < A_ISS; ++j) {                                                     \
                 const unsigned vo = a_off2[j] + (unsigned)((kdone - p.K1 + a_kc[j]) * ES);                          \
                 dma16(x2rs, sa_ + j * 1024, (a_off2[j] != OOB && p.ablate < 2) ? vo : OOB);                         \
@@ -487,7 +503,7 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
             }                                                                                                       \
         }                                                                                                           \
         kdone += BK;                                                                                                \
-        if (p.ablate != 8) {                                                                                        \
+        if (p.ablate != 8 && !p.fast) {                                                                             \
             _Pragma("unroll") for (int j = 0; j < B_ISS; ++j)                                                       \
                 dma16(wrs, sb_ + j * 1024, p.ablate < 2 ? w_off[j] + wk : OOB);                                    \
         }                                                                                                           \
@@ -702,6 +718,12 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
     p.ntn = 0; p.nwg = 0; p.groups = groups;
     static const int ablate = getenv("AVCER_GEMM_ABLATE") ? atoi(getenv("AVCER_GEMM_ABLATE")) : 0;
     p.ablate = ablate;
+    // Fast gather: Cin a multiple of the K-step, no padding, and the last tap of the last output position inside the
+    // input -- true for every Linear, 1x1 convolution and un-padded Conv1d of both models.
+    static const int fast_env = getenv("AVCER_GEMM_FAST") ? atoi(getenv("AVCER_GEMM_FAST")) : 1;
+    p.fast = fast_env && !ablate && d.cin % bk == 0 && d.pad_h == 0 && d.pad_w == 0 &&
+             (long)(d.out_h - 1) * d.stride_h + (long)(d.kh - 1) * d.dil_h < d.in_h &&
+             (long)(d.out_w - 1) * d.stride_w + (long)(d.kw - 1) * d.dil_w < d.in_w;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ctx->prof) {
         if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
