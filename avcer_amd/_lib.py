@@ -45,6 +45,7 @@ SIGNATURES = {
                                             c_stream]),
     "avcer_gather_windows": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, c_stream]),
     "avcer_dynamic_forward": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, c_stream]),
+    "avcer_dynamic_forward_mode": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),
     "avcer_audio_forward": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, c_stream]),
     "avcer_audio_num_classes": (C.c_int, [c_ctx]),
     "avcer_audio_chunks": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,

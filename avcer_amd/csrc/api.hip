@@ -664,12 +664,17 @@ extern "C" int avcer_audio_chunks(avcer_ctx* ctx, const float* wav, const int32_
 // ------------------------------------------------------------------------------------------------ dynamic LSTM
 // ref: architectures/video.py:169-185.  Input projections of all 10 steps are one GEMM per layer; the recurrent
 // part is one [n,H]x[H,4H] GEMM + one cell kernel per step (h_0 = c_0 = 0, so step 0 needs no GEMM).
-extern "C" int avcer_dynamic_forward(avcer_ctx* ctx, const float* windows, int n, float* logits, avcer_stream_t stream) {
+static int dynamic_forward_impl(avcer_ctx* ctx, const float* windows, int n, int mode, float* logits, avcer_stream_t stream) {
     if (!ctx) return AVCER_EINVAL;
     if (!ctx->dyn.loaded) return set_err(ctx, AVCER_ESTATE, "dynamic weights not loaded");
     if (!windows || !logits || n <= 0) return set_err(ctx, AVCER_EINVAL, "dynamic_forward: bad arguments");
+    if (mode < AVCER_MODE_FP32 || mode > AVCER_MODE_BF16X3) return set_err(ctx, AVCER_EINVAL, "dynamic_forward: mode %d", mode);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // the recurrence keeps f32 state in every mode; AVCER_MODE_BF16X3 runs its ten dependent GEMMs per layer on the
+    // split-bf16 MFMA (a 128-row tile of the f32 MFMA costs 5x the cycles, and these launches are pure latency)
+    const int x3 = mode == AVCER_MODE_BF16X3;
+    if (x3) TRY(ensure_all_x3(ctx, ctx->dyn, st));
     constexpr int T = 10, I = 512, H1 = 512, H2 = 256;
     const size_t total = ((size_t)n * T * 4 * H1 + (size_t)n * 4 * H1 + (size_t)n * T * H1 + (size_t)n * H1 +
                           (size_t)n * T * 4 * H2 + (size_t)n * H2 * 2) * 4 + 8 * 256;
@@ -684,7 +689,7 @@ extern "C" int avcer_dynamic_forward(avcer_ctx* ctx, const float* windows, int n
     float* h2 = (float*)ar.get((size_t)n * H2 * 4);
     float* c2 = (float*)ar.get((size_t)n * H2 * 4);
     if (!c2) return set_err(ctx, AVCER_ENOMEM, "dynamic workspace arithmetic");
-    Net net{ctx, ctx->dyn, 0, st};
+    Net net{ctx, ctx->dyn, 0, st, x3};
     net.gemm(linear_desc((long)n * T, I, 4 * H1, 0), "lstm1.wih.w", nullptr, net.F("lstm1.b"), windows, nullptr, xp1, 0, 0);
     for (int t = 0; t < T; ++t) {
         if (t > 0) {
@@ -702,6 +707,15 @@ extern "C" int avcer_dynamic_forward(avcer_ctx* ctx, const float* windows, int n
     }
     net.chk(k_small_linear(ctx, h2, net.F("fc.w"), net.F("fc.b"), logits, nullptr, n, H2, 7, 0, st));
     return net.err;
+}
+
+extern "C" int avcer_dynamic_forward(avcer_ctx* ctx, const float* windows, int n, float* logits, avcer_stream_t stream) {
+    return dynamic_forward_impl(ctx, windows, n, AVCER_MODE_FP32, logits, stream);
+}
+
+extern "C" int avcer_dynamic_forward_mode(avcer_ctx* ctx, const float* windows, int n, int mode, float* logits,
+                                          avcer_stream_t stream) {
+    return dynamic_forward_impl(ctx, windows, n, mode, logits, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ audio model

@@ -139,12 +139,13 @@ class Engine:
                                                   self._stream()))
         return out
 
-    def dynamic_forward(self, windows):
+    def dynamic_forward(self, windows, mode: int = MODE_FP32):
         x = self._dev(windows, torch.float32)
         if x.dim() != 3 or tuple(x.shape[1:]) != (10, 512):
             raise ValueError(f"windows must be [N,10,512], got {tuple(x.shape)}")
         out = self._new(x.shape[0], 7)
-        self._check(self.lib.avcer_dynamic_forward(self.ctx, _ptr(x), int(x.shape[0]), _ptr(out), self._stream()))
+        self._check(self.lib.avcer_dynamic_forward_mode(self.ctx, _ptr(x), int(x.shape[0]), int(mode), _ptr(out),
+                                                        self._stream()))
         return out
 
     def audio_forward(self, wav, normalize: bool = True, mode: int = MODE_FP32):

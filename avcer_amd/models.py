@@ -51,8 +51,9 @@ class StaticModel:
 class DynamicModel:
     """Drop-in for `pth_model_dynamic` (architectures/video.py LSTMPyTorch in eval mode)."""
 
-    def __init__(self, engine: Engine, state_dict):
+    def __init__(self, engine: Engine, state_dict, mode: int = 0):
         self.engine = engine
+        self.mode = mode
         engine.load_dynamic(state_dict)
 
     def load_state_dict(self, state_dict):
@@ -65,7 +66,7 @@ class DynamicModel:
         return self
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        return self.engine.dynamic_forward(x)
+        return self.engine.dynamic_forward(x, self.mode)
 
     forward = __call__
 

@@ -117,7 +117,7 @@ def visual_forward(engine: Engine, frames_u8: torch.Tensor, present, fps: float,
         _, probs, feats = engine.static_forward(frames_sel, mode)
         stat = torch.cat([probs, plan.zero_row]).index_select(0, plan.s_src)
         if plan.n_win:
-            dl = engine.dynamic_forward(engine.gather_windows(feats, plan.win, validated=True))
+            dl = engine.dynamic_forward(engine.gather_windows(feats, plan.win, validated=True), mode)
             dyn = torch.cat([dl, plan.zero_row]).index_select(0, plan.d_src)
         else:
             dyn = torch.zeros(n * t, 7, device=dev)

@@ -88,6 +88,10 @@ int avcer_gather_windows(avcer_ctx* ctx, const float* feats, const int32_t* idx,
  *   ref: architectures/video.py:169-185 (LSTMPyTorch.forward), get_prob_video.py:122-129
  * windows f32 [n,10,512] -> logits f32 [n,7] (raw logits, no softmax). Always f32 arithmetic. */
 int avcer_dynamic_forward(avcer_ctx* ctx, const float* windows, int n, float* logits, avcer_stream_t stream);
+/* Same with an arithmetic mode: AVCER_MODE_BF16X3 runs the projections on the split-bf16 MFMA (f32 state, f32-grade
+ * results); AVCER_MODE_BF16 keeps them in f32 (the recurrence is latency-bound, not worth a third weight copy). */
+int avcer_dynamic_forward_mode(avcer_ctx* ctx, const float* windows, int n, int mode, float* logits,
+                               avcer_stream_t stream);
 
 /* Audio model on padded waveform windows.
  *   ref: get_prob_audio_8_cl.py:87-92 (HF feature-extractor normalisation + audio_model(x))

@@ -129,3 +129,15 @@ def test_visual_harness_matches_reference_tables(engine_static, engine_dynamic, 
     st, dy = video_pipeline.visual_forward(engine_static, clips, present, 25)
     s0, d0 = video_pipeline.visual_forward(engine_static, clips[1], present[1], 25)
     assert torch.equal(st[1], s0) and torch.equal(dy[1], d0)
+
+
+def test_lstm_split_bf16_mode(engine, sd_dynamic, golden):
+    """x3 projections (f32 state): still f32-grade against the reference LSTM."""
+    from avcer_amd.engine import MODE_BF16X3
+    engine.load_dynamic(sd_dynamic)
+    w = np.maximum(synth.centered(5, "lstm_in", (4, 10, 512), 1.0), 0).astype(np.float32)
+    w[0] = w[0, 0]
+    out = engine.dynamic_forward(torch.from_numpy(w), MODE_BF16X3).cpu().numpy()
+    d = np.abs(out - golden("lstm")["logits"]).max()
+    print("lstm x3 max|dlogit|", d)
+    assert d < 2e-4
