@@ -2,7 +2,7 @@
 """Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, MI355X_MICROARCH.md 'HBM' section) into
 HBM bytes per launch of the dominant kernel.
 
-    python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE [--out profiles/r01_traffic_x3.json]
+    python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE [--out profiles/r01_traffic_x3.json] [--clips 128]
 
 Corrections applied exactly as the guide prescribes for gfx950: counter unit = KiB; FETCH_SIZE reports 1/2 of the bytes of
 a wide (16 B/lane) coalesced stream (global_load and buffer_load...lds alike) -> doubled; WRITE_SIZE is exact for
@@ -46,7 +46,10 @@ def main():
         print(f"{name[-70:]:70s} {n:8d} {rd/1e9:9.2f} {wb/1e9:9.2f} {tot/n:12.0f} {tot/secs/1e12 if secs else 0:6.2f}")
     gem = [r for r in rows if "conv_gemm_kernel" in r[1]]
     tot = sum(r[0] for r in gem); n = sum(r[2] for r in gem); secs = sum(r[5] for r in gem)
-    res = {"kernel": "conv_gemm_kernel (all instantiations)", "launches": n, "hbm_bytes_per_launch": tot / n,
+    clips = int(sys.argv[sys.argv.index("--clips") + 1]) if "--clips" in sys.argv else 128
+    res = {"kernel": "conv_gemm_kernel (all instantiations)", "clips_per_gpu": clips,
+           "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-secondary --no-cpu",
+           "launches": n, "hbm_bytes_per_launch": tot / n,
            "read_bytes_per_launch": sum(r[3] for r in gem) / n, "write_bytes_per_launch": sum(r[4] for r in gem) / n,
            "hbm_tb_per_s_during_kernel": tot / secs / 1e12,
            "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), KiB units, WRITE_SIZE as is"}
