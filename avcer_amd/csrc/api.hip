@@ -344,26 +344,13 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     if (mode == AVCER_MODE_BF16X3) TRY(ensure_all_x3(ctx, ctx->stat, st));
     const size_t es = bf ? 2 : 4;
     const int NB = std::min(n, ctx->static_batch);
-    // Depth-first front end: the stem and the first `front` stages run over chunks of CH frames so that every tensor
-    // a chunk touches between two uses (block input re-read as residual, T1/T2, the next block's input) stays in the
-    // 256 MiB memory-side cache instead of streaming through HBM; the later stages need the whole pass to fill the
-    // chip.  AVCER_STATIC_CHUNK=0 restores the layer-by-layer schedule.
-    static const int env_chunk = getenv("AVCER_STATIC_CHUNK") ? atoi(getenv("AVCER_STATIC_CHUNK")) : ctx->static_chunk;
-    static const int env_front = getenv("AVCER_STATIC_FRONT") ? atoi(getenv("AVCER_STATIC_FRONT")) : 2;
-    const int CH = env_chunk > 0 ? std::min(env_chunk, NB) : NB;
-    const int front = env_chunk > 0 && CH < NB ? std::max(0, std::min(env_front, 3)) : 0;
     const size_t act_elems = (size_t)NB * 112 * 112 * 64;  // largest activation (stem output)
-    const size_t cact_elems = (size_t)CH * 112 * 112 * 64;
-    const size_t pre_elems = (size_t)(front ? CH : NB) * 230 * 230 * 4;
-    const size_t total = pre_elems * es + 4 * (act_elems * es + 256) + (front ? 4 * (cact_elems * es + 256) : 0) +
-                         (size_t)NB * (2048 + 512) * 4 + 4096;
+    const size_t pre_elems = (size_t)NB * 230 * 230 * 4;
+    const size_t total = pre_elems * es + 4 * (act_elems * es + 256) + (size_t)NB * (2048 + 512) * 4 + 4096;
     void* wsp = nullptr;
     TRY(ws_reserve(ctx, 0, total, &wsp));
     Arena ar(wsp, ctx->ws[0].cap);
     void* P = ar.get(pre_elems * es);
-    void* cbuf[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (front)
-        for (auto& b : cbuf) b = ar.get(cact_elems * es);
     void* buf[4];
     for (auto& b : buf) b = ar.get(act_elems * es);
     float* pooled = (float*)ar.get((size_t)NB * 2048 * 4);
@@ -427,24 +414,9 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
         const int nb = std::min(NB, n - s0);
         void *X, *T1 = buf[2], *T2 = buf[3], *OUT = buf[0];
         int h = 55, cin = 64;
-        if (front) {
-            int fh = 55, fc = 64;  // geometry after the chunked stages
-            for (int li = 0; li < front; ++li) { fh = (fh - 1) / kStages[li][2] + 1; fc = kStages[li][0] * 4; }
-            for (int c0 = 0; c0 < nb; c0 += CH) {
-                const int cn = std::min(CH, nb - c0);
-                run_stem(s0 + c0, cn, cbuf);
-                void *cX = cbuf[1], *cT1 = cbuf[2], *cT2 = cbuf[3], *cOUT = cbuf[0];
-                h = 55; cin = 64;
-                for (int li = 0; li < front; ++li)
-                    run_stage(li, cn, cX, cT1, cT2, cOUT, h, cin,
-                              li == front - 1 ? (char*)buf[1] + (size_t)c0 * fh * fh * fc * es : nullptr);
-            }
-            X = buf[1];
-        } else {
-            run_stem(s0, nb, buf);
-            X = buf[1];
-        }
-        for (int li = front; li < 4; ++li) run_stage(li, nb, X, T1, T2, OUT, h, cin, nullptr);
+        run_stem(s0, nb, buf);
+        X = buf[1];
+        for (int li = 0; li < 4; ++li) run_stage(li, nb, X, T1, T2, OUT, h, cin, nullptr);
         net.chk(k_avgpool_hw(ctx, X, pooled, nb, h * h, 2048, act, st));
         net.tap("avgpool", pooled, (size_t)nb * 2048 * 4);
         float* fo = feats ? feats + (size_t)s0 * 512 : feat_ws;

@@ -42,7 +42,6 @@ struct avcer_ctx {
     Model stat, dyn, aud, face;
     int aud_classes = 0;
     int static_batch = 1024;  // frames per internal pass of the static CNN (4 GiB buffer-descriptor limit at f32)
-    int static_chunk = 0;     // frames per depth-first chunk of the CNN front end (0 = layer by layer)
     // grow-only workspace arenas (activations), one per pipeline
     DevBuf ws[8];
     int64_t gemm_launches = 0;

@@ -11,10 +11,9 @@
 //   LSTM input / recurrent projections           architectures/video.py:169-185
 //
 // Design (CDNA4):
-//   * 256 threads = 4 waves (2x2, wave tile BM/2 x BN/2); block tile BM(m) x BN(n) = 128x128, 128x64 or 192x128; one
-//     K-step = 128 bytes per row for every element type (32 f32 / sp32 or 64 bf16), so the DMA pattern is
-//     type-independent.  64 / 48 / 80 KiB of LDS per block: two / three / two blocks per CU cover each other's barrier
-//     stalls.  The 192-row tile moves 17 % fewer L2->LDS bytes per flop and keeps 80 instead of 64 KiB in flight per CU.
+//   * 256 threads = 4 waves (2x2, wave tile 64 x BN/2); block tile 128(m) x BN(n), BN = 128 or 64; one K-step =
+//     128 bytes per row for every element type (32 f32 / sp32 or 64 bf16), so the DMA pattern is type-independent.
+//     64 / 48 KiB of LDS per block: two / three blocks per CU cover each other's barrier stalls.
 //   * A and W tiles go global -> LDS by DMA (buffer_load_dwordx4 ... lds, no VGPR staging, no ds_write); the
 //     hardware bounds check of the buffer descriptor supplies the zeros of image borders and of rows past M.
 //     The double-buffered LDS image has 128-byte rows whose 16-byte chunks are XOR-swizzled with a searched key of
@@ -28,17 +27,11 @@
 //     16-byte stores in f32, bf16 or sp32.  Optional second A source (two fused 1x1 convolutions), grouped
 //     convolution via grid.y, bijective XCD-aware block remap + grouped tile order.
 #include "common.h"
+#include "gemm_dev.h"
 
-#include <cstdlib>
 #include <type_traits>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-
 namespace {
-
-constexpr int ROWB = 128;  // bytes per tile row per K-step
 
 struct GemmParams {
     const char* X;
@@ -67,37 +60,9 @@ struct GemmParams {
     int ntn, ntm, nwg;
     int gm;  // m-tiles per group of the grouped block order (0 = plain n-fastest order)
     int groups;  // grid.y: group g shifts coff / yoff / roff by g*Cin / g*N and the weight/scale/bias rows by g*N
-    int ablate;  // test-only (env AVCER_GEMM_ABLATE): 1 = skip MFMA, 2 = skip DMA loads, 4 = skip the x3 operand split,
-                 // 8 = skip the W-tile DMA (half the L2->LDS bytes; results are garbage, timing only)
     int KH;
     int fast;  // pad-free gather with a scalar K / tap advance (see AVCER_ISSUE_TILES)
-    int tap_inner;  // K-steps walk (channel chunk, ky, kx) instead of (ky, kx, channel chunk): see launch_conv_gemm
 };
-
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-constexpr unsigned OOB = 0xFFFFFF00u;  // voffset that always fails the buffer bounds check -> load returns 0
-
-// 16 bytes per lane, global -> LDS (wave-uniform LDS base + lane * 16); zeros when voff fails the bounds check
-template <typename Rsrc>
-__device__ __forceinline__ void dma16(Rsrc rs, char* lds_wave_base, unsigned voff, unsigned soff = 0u) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    // soff: wave-uniform byte offset (SGPR operand of the instruction), added to the per-lane voff by the hardware
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
-#endif
-}
-
-// XOR swizzle of the 16-byte chunks of a 128-byte tile row.  The key f((row>>1)&7) with f = (0,1,4,5,6,7,2,3) was
-// found by exhaustive search: it makes every ds_read_b128 fragment pattern used below (bf16 16x16x32, f32 32x32x2 and
-// the two-chunk f32 row read of the split-bf16 mode) conflict-free under the MI355X 16-lane-group banking.
-__device__ __forceinline__ int swz_key(int row) { return (int)((0x32765410u >> (((row >> 1) & 7) * 4)) & 7u); }
-__device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ swz_key(row)) << 4); }
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-
-__device__ __forceinline__ float relu_nan(float v) { return v > 0.f ? v : (v != v ? v : 0.f); }  // keeps NaN like torch
-
-__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
-__device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
 
 // Epilogue, staged through LDS so that HBM sees whole 128-byte lines: every wave first parks its scaled/biased
 // accumulators in an f32 [128][BN] image (16-byte chunks XOR-swizzled with row&7 against write conflicts), then the
@@ -106,8 +71,6 @@ __device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(floa
 // OUT: 0 = f32, 1 = bf16, 2 = split-bf16 pairs ("sp32": per aligned group of 32 channels, 32 hi bf16 then 32 lo bf16,
 // value = hi + lo; 4 bytes per element like f32, directly consumable as MODE 3 A operand).  The residual has the
 // same storage type as the output.
-__device__ __forceinline__ long sp32_byte(long e) { return ((e & ~31L) << 2) + ((e & 31L) << 1); }
-
 // Raw 16-byte words of the residual belonging to 8 consecutive channels of one position: {f32 x4, f32 x4},
 // {bf16 x8, -} or {sp32 hi x8, sp32 lo x8}.  They are fetched at kernel start (res_prefetch) so that the read overlaps
 // the DMA / MFMA phase instead of sitting in the epilogue.
@@ -227,7 +190,7 @@ __device__ __forceinline__ void stage_acc(const GemmParams& p, char* smem, AccT 
 }
 
 template <int BMT, int BN> struct DrainMap {
-    static constexpr int EP_ROWS = BMT == 192 ? 96 : BMT;  // rows per epilogue round: the f32 image must fit the tile buffers
+    static constexpr int EP_ROWS = BMT;
     static constexpr int TPR = BN / 8;          // threads per row (8 channels each)
     static constexpr int RPP = 256 / TPR;       // rows per pass
     static constexpr int NP = EP_ROWS / RPP;    // passes per round
@@ -289,9 +252,7 @@ __device__ __forceinline__ void mfma_step(const GemmParams& p, const char* smem,
     constexpr int WM = BMT / 2;
     const char* sa = smem + cur * TILE_BYTES;
     const char* sb = sa + BMT * ROWB;
-    if (p.ablate == 1) {
-        // ablation: no fragment reads / MFMA
-    } else if constexpr (IS_F32) {
+    if constexpr (IS_F32) {
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) {
             const int ch = kq * 2 + (lane >> 5);
@@ -325,12 +286,7 @@ __device__ __forceinline__ void mfma_step(const GemmParams& p, const char* smem,
             }
             const float4 x = *reinterpret_cast<const float4*>(sa + swz(row, 2 * g));
             const float4 y = *reinterpret_cast<const float4*>(sa + swz(row, 2 * g + 1));
-            if (p.ablate == 4) {  // timing only: reinterpret instead of splitting
-                ahi[fm] = __builtin_bit_cast(bf16x8_t, x);
-                alo[fm] = __builtin_bit_cast(bf16x8_t, y);
-            } else {
-                split8(x, y, ahi[fm], alo[fm]);
-            }
+            split8(x, y, ahi[fm], alo[fm]);
         }
 #pragma unroll
         for (int fn = 0; fn < NFN; ++fn) {
@@ -364,13 +320,9 @@ __device__ __forceinline__ void mfma_step(const GemmParams& p, const char* smem,
     }
 }
 
-// LW = number of dedicated loader waves (0, or 4 as an opt-in experiment).  With LW = 4 the block has 8 waves: waves 0-3
-// only read fragments and issue MFMAs, waves 4-7 only issue the LDS-DMA of the next K-step (an LDS-DMA instruction costs its issuing wave
-// ~100 cycles inside a busy phase -- MI355X_MICROARCH.md, 'LDS-DMA piece issue cost' -- and eight of them per K-step
-// rival the MFMA time of a 64x64 wave tile).
-template <int MODE, int OUT, int BN, int LW, int BMT>
-__global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kernel(const GemmParams p) {
-    static_assert(BMT == 128 || (BMT == 192 && BN == 128 && LW == 0), "tile shapes: 128x128, 128x64, 192x128");
+template <int MODE, int OUT, int BN>
+__global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
+    constexpr int BMT = 128;
     constexpr bool IS_F32 = MODE == 0;
     constexpr int ES = MODE == 1 ? 2 : 4;
     constexpr int VEC = 16 / ES;
@@ -384,9 +336,7 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave >> 1) & 1, wn = wave & 1;
-    constexpr int NDW = LW ? LW : 4;                  // waves that issue DMA
-    const bool is_loader = LW > 0 && wave >= 4;       // wave-uniform
-    const int dw = LW ? (wave - 4) & (NDW - 1) : wave;  // index among the DMA-issuing waves
+    const int dw = wave;  // every wave issues its share of the DMA
 
     // XCD-aware bijective remap: blocks b and b+8 share an XCD (speed only, never correctness)
     int bid = blockIdx.x;
@@ -424,8 +374,8 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
     // lane i landing at (row i>>3, 16-byte slot i&7).  The XOR swizzle of the LDS image is therefore applied to the
     // SOURCE: lane i fetches data chunk c = slot ^ ((row>>1)&7) of its row.  Padding taps / rows past M use an
     // out-of-range offset, for which the buffer load writes zeros.
-    constexpr int A_ISS = BMT / 8 / NDW;  // DMA instructions per issuing wave per K-step for the A tile
-    constexpr int B_ISS = BN / 8 / NDW;
+    constexpr int A_ISS = BMT / 8 / 4;  // DMA instructions per wave per K-step for the A tile
+    constexpr int B_ISS = BN / 8 / 4;
     const int lrow8 = lane >> 3;
     const int slot = lane & 7;
 #define AVCER_DMA_SETUP()                                                                                           \
@@ -481,14 +431,14 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
         } else if (kdone >= p.K1) {                                                                                 \
             _Pragma("unroll") for (int j = 0; j < A_ISS; ++j) {                                                     \
                 const unsigned vo = a_off2[j] + (unsigned)((kdone - p.K1 + a_kc[j]) * ES);                          \
-                dma16(x2rs, sa_ + j * 1024, (a_off2[j] != OOB && p.ablate < 2) ? vo : OOB);                         \
+                dma16(x2rs, sa_ + j * 1024, a_off2[j] != OOB ? vo : OOB);                         \
             }                                                                                                       \
         } else if (tap_uniform) {                                                                                   \
             const int dy = ky * p.dh, dx = kx * p.dw;                                                               \
             const unsigned tap = (unsigned)(((long)dy * p.sH + (long)dx * p.sW + kc) * ES);                         \
             _Pragma("unroll") for (int j = 0; j < A_ISS; ++j) {                                                     \
                 const int iy = a_iy[j] + dy, ix = a_ix[j] + dx;                                                     \
-                const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.Wd) & (p.ablate < 2);  \
+                const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.Wd);                   \
                 dma16(xrs, sa_ + j * 1024, ok ? a_offk[j] + tap : OOB);                                             \
             }                                                                                                       \
         } else {                                                                                                    \
@@ -497,35 +447,21 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
                 if (kk >= p.Cin) { kk -= p.Cin; if (++kxx == p.KW) { kxx = 0; ++kyy; } }                            \
                 const int dy = kyy * p.dh, dx = kxx * p.dw;                                                         \
                 const int iy = a_iy[j] + dy, ix = a_ix[j] + dx;                                                     \
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd && p.ablate < 2;      \
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;                      \
                 const unsigned vo = a_off[j] + (unsigned)(((long)dy * p.sH + (long)dx * p.sW + kk) * ES);           \
                 dma16(xrs, sa_ + j * 1024, ok ? vo : OOB);                                                          \
             }                                                                                                       \
         }                                                                                                           \
         kdone += BK;                                                                                                \
-        if (p.ablate != 8 && !p.fast) {                                                                             \
-            _Pragma("unroll") for (int j = 0; j < B_ISS; ++j)                                                       \
-                dma16(wrs, sb_ + j * 1024, p.ablate < 2 ? w_off[j] + wk : OOB);                                    \
+        if (!p.fast) {                                                                                              \
+            _Pragma("unroll") for (int j = 0; j < B_ISS; ++j) dma16(wrs, sb_ + j * 1024, w_off[j] + wk);            \
         }                                                                                                           \
-        if (p.tap_inner) {                                                                                          \
-            if (++kx == p.KW) { kx = 0; if (++ky == p.KH) { ky = 0; kc += BK; } }                                   \
-            wk = (unsigned)(((ky * p.KW + kx) * p.Cin + kc) * ES);                                                  \
-        } else {                                                                                                    \
-            wk += ROWB;                                                                                             \
-            kc += BK;                                                                                               \
-            while (kc >= p.Cin) {                                                                                   \
-                kc -= p.Cin;                                                                                        \
-                if (++kx == p.KW) { kx = 0; ++ky; }                                                                 \
-            }                                                                                                       \
+        wk += ROWB;                                                                                                 \
+        kc += BK;                                                                                                   \
+        while (kc >= p.Cin) {                                                                                       \
+            kc -= p.Cin;                                                                                            \
+            if (++kx == p.KW) { kx = 0; ++ky; }                                                                     \
         }                                                                                                           \
-    } while (0)
-
-// A raw workgroup barrier that the compiler may not move LDS accesses across
-#define AVCER_MEET()                                                                                                \
-    do {                                                                                                            \
-        asm volatile("" ::: "memory");                                                                              \
-        __builtin_amdgcn_s_barrier();                                                                               \
-        asm volatile("" ::: "memory");                                                                              \
     } while (0)
 
     const int nk = p.K / BK;
@@ -533,28 +469,11 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
     // and the per-lane gather address is two adds and a bounds test instead of a per-lane (ky, kx, c) decomposition
     const bool tap_uniform = p.Cin % BK == 0;
     int cur = 0;
-    if constexpr (LW > 0) {
-        if (is_loader) {
-            // loader role: nothing but DMA issue; one barrier per K-step, exactly like the MFMA waves below
-            AVCER_DMA_SETUP();
-            AVCER_ISSUE_TILES(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            AVCER_MEET();
-            for (int step = 0; step < nk; ++step) {
-                if (step + 1 < nk) AVCER_ISSUE_TILES(cur ^ 1);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                AVCER_MEET();
-                cur ^= 1;
-            }
-            return;  // the epilogue belongs to the four MFMA waves (barriers only count live waves)
-        }
-    }
 
     // residual tile of this thread's epilogue rows: requested now, consumed after the last MFMA
     using D = DrainMap<BMT, BN>;
-    constexpr int EPN = BMT / D::EP_ROWS;  // epilogue rounds (2 for the 192-row tile, whose f32 image exceeds the LDS)
     uint4 rres[D::NP][2];
-    if constexpr (EPN == 1) res_prefetch<OUT, BMT, BN>(p, m_base, n_base, tid, rres);
+    res_prefetch<OUT, BMT, BN>(p, m_base, n_base, tid, rres);
 
     constexpr int NFN = IS_F32 ? WN / 32 : WN / 16;
     constexpr int NFM = IS_F32 ? WM / 32 : WM / 16;
@@ -566,90 +485,37 @@ __global__ void __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 2) conv_gemm_kern
 #pragma unroll
         for (int b = 0; b < NFM; ++b) acc[a][b] = acc_t{0};
 
-#define AVCER_MFMA_LOOP(ISSUE_NEXT, STEP_SYNC)                                                                      \
-    for (int step = 0; step < nk; ++step) {                                                                         \
-        ISSUE_NEXT;                                                                                                 \
-        mfma_step<MODE, BMT, BN, TILE_BYTES>(p, smem, cur, acc, wm, wn, lane);                                           \
-        STEP_SYNC;                                                                                                  \
-        cur ^= 1;                                                                                                   \
+    AVCER_DMA_SETUP();
+    AVCER_ISSUE_TILES(0);
+    __syncthreads();  // hipcc puts the s_waitcnt vmcnt(0) of the in-flight DMA in front of the barrier
+    for (int step = 0; step < nk; ++step) {
+        if (step + 1 < nk) AVCER_ISSUE_TILES(cur ^ 1);
+        mfma_step<MODE, BMT, BN, TILE_BYTES>(p, smem, cur, acc, wm, wn, lane);
+        __syncthreads();
+        cur ^= 1;
     }
-
-    if constexpr (LW > 0) {
-        AVCER_MEET();  // K-step 0 has landed
-        AVCER_MFMA_LOOP((void)0, AVCER_MEET())
-    } else {
-        AVCER_DMA_SETUP();
-        AVCER_ISSUE_TILES(0);
-        __syncthreads();  // hipcc puts the s_waitcnt vmcnt(0) of the in-flight DMA in front of the barrier
-        AVCER_MFMA_LOOP(if (step + 1 < nk) AVCER_ISSUE_TILES(cur ^ 1), __syncthreads())
-    }
-#undef AVCER_MFMA_LOOP
 #undef AVCER_ISSUE_TILES
 #undef AVCER_DMA_SETUP
-#undef AVCER_MEET
 
     // epilogue through LDS (the tile buffers are free: the loop ended on a barrier)
-    if constexpr (EPN == 1) {
-        stage_acc<MODE, BN>(p, smem, acc, n_base, wm * WM, wn, lane);
-        __syncthreads();
-        if (p.act == 2) drain_stage<OUT, BMT, BN, 2>(p, smem, m_base, n_base, tid, rres);
-        else if (p.act == 1) drain_stage<OUT, BMT, BN, 1>(p, smem, m_base, n_base, tid, rres);
-        else drain_stage<OUT, BMT, BN, 0>(p, smem, m_base, n_base, tid, rres);
-    } else {
-        // two rounds of 96 rows: round e stages the accumulators of the waves with wm == e (wave tile = 96 rows);
-        // the residual of a round is requested before its staging barrier
-#pragma unroll
-        for (int e = 0; e < EPN; ++e) {
-            const int m0 = m_base + e * D::EP_ROWS;
-            res_prefetch<OUT, BMT, BN>(p, m0, n_base, tid, rres);
-            if (wm == e) stage_acc<MODE, BN>(p, smem, acc, n_base, 0, wn, lane);
-            __syncthreads();
-            if (p.act == 2) drain_stage<OUT, BMT, BN, 2>(p, smem, m0, n_base, tid, rres);
-            else if (p.act == 1) drain_stage<OUT, BMT, BN, 1>(p, smem, m0, n_base, tid, rres);
-            else drain_stage<OUT, BMT, BN, 0>(p, smem, m0, n_base, tid, rres);
-            if (e + 1 < EPN) __syncthreads();
-        }
-    }
+    stage_acc<MODE, BN>(p, smem, acc, n_base, wm * WM, wn, lane);
+    __syncthreads();
+    if (p.act == 2) drain_stage<OUT, BMT, BN, 2>(p, smem, m_base, n_base, tid, rres);
+    else if (p.act == 1) drain_stage<OUT, BMT, BN, 1>(p, smem, m_base, n_base, tid, rres);
+    else drain_stage<OUT, BMT, BN, 0>(p, smem, m_base, n_base, tid, rres);
 }
-
-template <int MODE, int OUT, int LW>
-void launch_lw(GemmParams& p, hipStream_t st, bool bn128, int bm) {
-    constexpr int threads = 256 + 64 * LW;
-    if constexpr (LW == 0) {
-        if (bm == 192) {
-            conv_gemm_kernel<MODE, OUT, 128, 0, 192><<<dim3(p.nwg, p.groups), dim3(threads), 0, st>>>(p);
-            return;
-        }
-    }
-    if (bn128) conv_gemm_kernel<MODE, OUT, 128, LW, 128><<<dim3(p.nwg, p.groups), dim3(threads), 0, st>>>(p);
-    else conv_gemm_kernel<MODE, OUT, 64, LW, 128><<<dim3(p.nwg, p.groups), dim3(threads), 0, st>>>(p);
-}
-
-// Tile-height choice (filled in from measurements; see profiles/experiments)
-inline bool prefer_bm192(long M, int N, int K) { return false; }
 
 template <int MODE, int OUT>
 void launch_t(const GemmParams& p0, hipStream_t st) {
     GemmParams p = p0;
-    // K <= bn64_max_k: bandwidth-bound 1x1 convolutions; the 48 KiB BN=64 tile lets three blocks share a CU
-    static const int bn64_max_k = getenv("AVCER_GEMM_BN64_MAXK") ? atoi(getenv("AVCER_GEMM_BN64_MAXK")) : 128;
-    static const int gm_env = getenv("AVCER_GEMM_GM") ? atoi(getenv("AVCER_GEMM_GM")) : 8;
-    // AVCER_GEMM_LW=4 (experiment, off by default): four dedicated loader waves per block.  Measured +3..9 % on
-    // MFMA-bound bf16 / sp32 layers, nothing for f32, and -1.4 % on the whole x3 pipeline (profiles/experiments).
-    static const int lw_env = getenv("AVCER_GEMM_LW") ? atoi(getenv("AVCER_GEMM_LW")) : 0;
-    const int lw = (lw_env == 4 && MODE != 2) ? 4 : 0;
-    // AVCER_GEMM_BM: 128, 192, or 0 = choose per shape
-    static const int bm_env = getenv("AVCER_GEMM_BM") ? atoi(getenv("AVCER_GEMM_BM")) : 128;
-    const bool bn128 = p.N % 128 == 0 && p.K > bn64_max_k;
-    int bm = 128;
-    if (bn128 && lw == 0 && (bm_env == 192 || (bm_env == 0 && prefer_bm192(p.M, p.N, p.K)))) bm = 192;
-    const int ntm = (p.M + bm - 1) / bm;
-    p.ntm = ntm;
-    p.gm = gm_env;
+    // K <= 128: bandwidth-bound 1x1 convolutions; the 48 KiB BN=64 tile lets three blocks share a CU
+    const bool bn128 = p.N % 128 == 0 && p.K > 128;
+    p.ntm = (p.M + 127) / 128;
+    p.gm = 8;  // grouped block order: 8 m-tiles x all n-tiles per group (0/4/8/16 measured within +-3 %)
     p.ntn = p.N / (bn128 ? 128 : 64);
-    p.nwg = ntm * p.ntn;
-    if (lw == 4) launch_lw<MODE, OUT, 4>(p, st, bn128, 128);
-    else launch_lw<MODE, OUT, 0>(p, st, bn128, bm);
+    p.nwg = p.ntm * p.ntn;
+    if (bn128) conv_gemm_kernel<MODE, OUT, 128><<<dim3(p.nwg, p.groups), dim3(256), 0, st>>>(p);
+    else conv_gemm_kernel<MODE, OUT, 64><<<dim3(p.nwg, p.groups), dim3(256), 0, st>>>(p);
 }
 
 }  // namespace
@@ -688,13 +554,6 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
     p.Y = (char*)y;
     p.M = (int)M; p.N = d.n; p.K = (int)K;
     p.OH = d.out_h; p.OW = d.out_w; p.H = d.in_h; p.Wd = d.in_w; p.Cin = d.cin; p.KW = d.kw; p.KH = d.kh;
-    // Multi-tap convolutions whose Cin is a multiple of the K-step walk K as (channel chunk, ky, kx): the taps of one
-    // chunk re-read the same or neighbouring pixels in consecutive K-steps, i.e. while they are still in the XCD's
-    // 4 MiB L2 (in (ky, kx, chunk) order a pixel comes back only after Cin/BK steps of every block on the XCD).
-    // The weight rows are addressed by the same (ky, kx, chunk) offset, so the [N][kh][kw][Cin] layout is unchanged;
-    // only the order of the f32 accumulation differs.
-    static const int tap_inner_env = getenv("AVCER_GEMM_TAP_INNER") ? atoi(getenv("AVCER_GEMM_TAP_INNER")) : 0;
-    p.tap_inner = tap_inner_env && !x2 && d.kh * d.kw > 1 && d.cin % bk == 0 && d.cin > bk;
     p.sh = d.stride_h; p.sw = d.stride_w; p.ph = d.pad_h; p.pw = d.pad_w; p.dh = d.dil_h; p.dw = d.dil_w;
     p.sB = d.x_stride_b; p.sH = d.x_stride_h; p.sW = d.x_stride_w; p.coff = d.x_coff;
     p.ldY = d.y_ld; p.yoff = d.y_coff; p.ldR = d.r_ld; p.roff = d.r_coff;
@@ -716,12 +575,9 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
         p.sB2 = d.x2_stride_b; p.sH2 = d.x2_stride_h; p.sW2 = d.x2_stride_w; p.coff2 = d.x2_coff; p.st2 = d.x2_stride;
     }
     p.ntn = 0; p.nwg = 0; p.groups = groups;
-    static const int ablate = getenv("AVCER_GEMM_ABLATE") ? atoi(getenv("AVCER_GEMM_ABLATE")) : 0;
-    p.ablate = ablate;
     // Fast gather: Cin a multiple of the K-step, no padding, and the last tap of the last output position inside the
     // input -- true for every Linear, 1x1 convolution and un-padded Conv1d of both models.
-    static const int fast_env = getenv("AVCER_GEMM_FAST") ? atoi(getenv("AVCER_GEMM_FAST")) : 1;
-    p.fast = fast_env && !ablate && d.cin % bk == 0 && d.pad_h == 0 && d.pad_w == 0 &&
+    p.fast = d.cin % bk == 0 && d.pad_h == 0 && d.pad_w == 0 &&
              (long)(d.out_h - 1) * d.stride_h + (long)(d.kh - 1) * d.dil_h < d.in_h &&
              (long)(d.out_w - 1) * d.stride_w + (long)(d.kw - 1) * d.dil_w < d.in_w;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

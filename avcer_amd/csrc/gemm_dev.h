@@ -1,0 +1,43 @@
+// Device-side helpers shared by the MFMA kernels of libavcer_hip.so (gemm.hip, bneck.hip): LDS-DMA, the searched
+// LDS swizzle, bf16 / sp32 conversions.  gfx950 only.
+#pragma once
+
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+namespace {
+
+constexpr int ROWB = 128;  // bytes per tile row per K-step
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+constexpr unsigned OOB = 0xFFFFFF00u;  // voffset that always fails the buffer bounds check -> load returns 0
+
+// 16 bytes per lane, global -> LDS (wave-uniform LDS base + lane * 16); zeros when voff fails the bounds check
+template <typename Rsrc>
+__device__ __forceinline__ void dma16(Rsrc rs, char* lds_wave_base, unsigned voff, unsigned soff = 0u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // soff: wave-uniform byte offset (SGPR operand of the instruction), added to the per-lane voff by the hardware
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+#endif
+}
+
+// XOR swizzle of the 16-byte chunks of a 128-byte tile row.  The key f((row>>1)&7) with f = (0,1,4,5,6,7,2,3) was
+// found by exhaustive search: it makes every ds_read_b128 fragment pattern used below (bf16 16x16x32, f32 32x32x2 and
+// the two-chunk f32 row read of the split-bf16 mode) conflict-free under the MI355X 16-lane-group banking.
+__device__ __forceinline__ int swz_key(int row) { return (int)((0x32765410u >> (((row >> 1) & 7) * 4)) & 7u); }
+__device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ swz_key(row)) << 4); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float relu_nan(float v) { return v > 0.f ? v : (v != v ? v : 0.f); }  // keeps NaN like torch
+
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+
+// sp32 storage: per aligned group of 32 channels, 32 hi bf16 then 32 lo bf16 (value = hi + lo; 4 bytes per element)
+__device__ __forceinline__ long sp32_byte(long e) { return ((e & ~31L) << 2) + ((e & 31L) << 1); }
+
+}  // namespace

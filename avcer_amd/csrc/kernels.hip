@@ -341,7 +341,7 @@ __global__ void audio_chunks_kernel(const float* __restrict__ wav, const int32_t
     for (int i = tid; i < window; i += blockDim.x) {
         float v;
         if (i < len) v = wav[s + i];
-        else if (mode == 2) v = wav[s + i % len];
+        else if (mode == 2) v = len > 0 ? wav[s + i % len] : NAN;  // empty chunk: the reference raises (i % 0); never index
         else v = fill;
         o[i] = v;
     }
@@ -1118,18 +1118,17 @@ int k_attention(avcer_ctx* ctx, const void* qkv, void* out, int n, int s, int he
         return set_err(ctx, AVCER_EINVAL, "attention: unsupported storage combination %d -> %d", in_kind, out_kind);
     const int grid = n * heads;
     // 64-wide heads in the bf16 / split-bf16 modes: QK^T and PV on the MFMA (the f32 mode keeps exact f32 arithmetic)
-    static const bool mfma_off = getenv("AVCER_ATTN_VALU") != nullptr;  // test knob: force the VALU kernel
-    if (d == 64 && !mfma_off && (in_kind == 1 || out_kind == 2)) {
+    if (d == 64 && (in_kind == 1 || out_kind == 2)) {
         const int nkt = s <= 128 ? 8 : 16;
         const int sp = nkt * 16, x3 = out_kind == 2;
         const size_t lds_m = (size_t)sp * 128 * (x3 ? 2 : 1) + (size_t)64 * (sp * 2 + 16) * (x3 ? 2 : 1);
 #define ATTM(T, TO, NKT, X3)                                                                                          \
     do {                                                                                                              \
-        static bool attr_set = false;                                                                                 \
-        if (!attr_set) {                                                                                              \
+        static uint64_t attr_dev = 0; /* the attribute is per device: one bit per device index */                    \
+        if (!((attr_dev >> (ctx->device & 63)) & 1)) {                                                                \
             HIP_TRY(ctx, hipFuncSetAttribute((const void*)attention_mfma_kernel<T, TO, NKT, X3>,                      \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));               \
-            attr_set = true;                                                                                          \
+            attr_dev |= 1ull << (ctx->device & 63);                                                                   \
         }                                                                                                             \
         attention_mfma_kernel<T, TO, NKT, X3><<<grid, 256, lds_m, st>>>((const T*)qkv, (TO*)out, s, heads, scale);    \
     } while (0)
@@ -1142,11 +1141,11 @@ int k_attention(avcer_ctx* ctx, const void* qkv, void* out, int n, int s, int he
     const size_t lds = ((size_t)s * (d + 4) + (size_t)s * d + ATT_WAVES * 256 + ATT_WAVES * d) * sizeof(float);
 #define ATT(T, TO, D)                                                                                                \
     do {                                                                                                             \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
+        static uint64_t attr_dev = 0;                                                                                \
+        if (!((attr_dev >> (ctx->device & 63)) & 1)) {                                                               \
             HIP_TRY(ctx, hipFuncSetAttribute((const void*)attention_kernel<T, TO, D>,                                \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
-            attr_set = true;                                                                                         \
+            attr_dev |= 1ull << (ctx->device & 63);                                                                  \
         }                                                                                                            \
         attention_kernel<T, TO, D><<<grid, ATT_THREADS, lds, st>>>((const T*)qkv, (TO*)out, s, heads, scale);        \
     } while (0)

@@ -87,16 +87,15 @@ class _DevicePlan:
         self.zero_row = torch.zeros(1, 7, device=dev)
 
 
-_PLAN_CACHE: dict = {}
-
-
 def _device_plan(engine: Engine, present: np.ndarray, fps: float) -> _DevicePlan:
-    key = (id(engine), present.shape, present.tobytes(), float(fps))
-    plan = _PLAN_CACHE.get(key)
+    """Index plans live ON the Engine object (they hold tensors of its device), so they die with it."""
+    cache = engine.__dict__.setdefault("_plan_cache", {})
+    key = (present.shape, present.tobytes(), float(fps))
+    plan = cache.get(key)
     if plan is None:
-        if len(_PLAN_CACHE) > 64:
-            _PLAN_CACHE.clear()
-        plan = _PLAN_CACHE[key] = _DevicePlan(engine, present, fps)
+        if len(cache) > 64:
+            cache.clear()
+        plan = cache[key] = _DevicePlan(engine, present, fps)
     return plan
 
 

@@ -5,7 +5,7 @@
  * of four callables and two numpy functions.  Each entry point below replaces one
  * of them; the reference location it stands in for is cited as  ref: <file>:<lines>  relative to the
  * reference's src/ directory.  The Python mirror with the reference's own call signatures lives in
- * avcer_amd/ (static_model.py, dynamic_model.py, audio_model.py, fusion.py) and binds these symbols
+ * avcer_amd/ (models.py, video_pipeline.py, audio_pipeline.py, fusion.py) and binds these symbols
  * with ctypes; INTEGRATION.md shows the stub a maintainer would add on the reference side.
  *
  * Conventions
@@ -106,7 +106,9 @@ int avcer_audio_num_classes(const avcer_ctx* ctx);
 /* Window slicing + padding of one waveform.
  *   ref: get_prob_audio_8_cl.py:78-86, data/utils.py:63-71 (pad_wav, "repeat"), :74-89 (pad_wav_zeros, "mean"/"constant")
  * wav f32 [len]; starts/ends i32 [n] (device) sample ranges; out f32 [n, window];
- * mode 0 = pad with the chunk mean (NaN for an empty chunk, as torch.mean does), 1 = zeros, 2 = repeat. */
+ * mode 0 = pad with the chunk mean (NaN for an empty chunk, as torch.mean does), 1 = zeros, 2 = repeat
+ * (an empty chunk makes the reference raise ZeroDivisionError, data/utils.py:66; the host mirror raises the same,
+ * and the kernel itself writes NaN for such a row instead of indexing with i % 0). */
 int avcer_audio_chunks(avcer_ctx* ctx, const float* wav, const int32_t* starts, const int32_t* ends, int n,
                        int window, int mode, float* out, avcer_stream_t stream);
 

@@ -20,4 +20,4 @@ if __name__ == "__main__":
         conv2d(256, 55, 256, 1, 1, 0, 64, "l1 c1 256->64"),
         conv2d(256, 28, 128, 3, 1, 1, 128, "l2 c2 3x3 128"),
     ]
-    run(eng, layers, {"f32": 0, "bf16": 1, "x3": 3, "x3s": 5}[which], 10, f"{which} ablate={os.environ.get('AVCER_GEMM_ABLATE', '0')}")
+    run(eng, layers, {"f32": 0, "bf16": 1, "x3": 3, "x3s": 5}[which], 10, which)
