@@ -35,11 +35,11 @@ def _worker(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
-def _run(n):
+def _run(n, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -53,6 +53,31 @@ def test_all_gather_records_even_and_uneven():
         res = _run(n)
         assert all(ok for _, ok, _ in res), res
         assert all(shape == (n, 16 * 7 * 2 + 8) for _, _, shape in res)
+
+
+def test_all_gather_records_world_4_and_8_with_1024_clips():
+    """BASELINE config 5's shape: 1024 clips over 4 and 8 ranks (128 per rank at 8), plus an uneven 1021."""
+    for world, n in ((4, 1024), (8, 1024), (8, 1021)):
+        res = _run(n, world)
+        assert len(res) == world and all(ok for _, ok, _ in res), res
+        assert all(shape == (n, 16 * 7 * 2 + 8) for _, _, shape in res)
+
+
+def test_bench_refuses_world_size_mismatch():
+    """bench.py must fail loudly (before any GPU call) when the launcher's world size is not --gpus."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    env.pop("WORLD_SIZE")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    if not torch.cuda.is_available():  # no GPU here: the self-spawn path refuses instead of printing n_gpus = 1
+        assert r.returncode != 0 and "exposes 0 GPU" in r.stderr
 
 
 def test_shard_range_partitions():
