@@ -143,8 +143,8 @@ int ensure_all_bf16(avcer_ctx* ctx, Model& m, hipStream_t st) {
 // split-bf16 copies (k_split_weights) of every GEMM weight whose K is a multiple of 32, made on the first x3 call
 int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
     auto wanted = [](const std::string& k, const Tensor& t) {
-        return !t.x3 && k.size() > 2 && k.compare(k.size() - 2, 2, ".w") == 0 && t.ndim == 2 && t.dims[1] % 32 == 0 &&
-               t.dims[0] % 64 == 0;
+        const bool is_w = k.size() > 3 && (k.compare(k.size() - 2, 2, ".w") == 0 || k.compare(k.size() - 3, 3, ".wp") == 0);
+        return !t.x3 && is_w && t.ndim == 2 && t.dims[1] % 32 == 0 && t.dims[0] % 64 == 0;
     };
     size_t total = 0;
     for (auto& kv : m.t)
@@ -360,6 +360,17 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     Net net{ctx, ctx->stat, bf, st, mode == AVCER_MODE_BF16X3};
     // stem + max-pool of `nb` frames starting at frame f0 of the call: -> B[1] (55x55x64), B[0] is scratch
     auto run_stem = [&](int f0, int nb, void** B) {
+        if (net.x3) {
+            // x3 mode: planar bf16 hi / lo image -> ONE kernel for conv 7x7/2 + BN + ReLU + max-pool 3x3/2 (fused.hip)
+            if (frames) net.chk(k_preprocess(ctx, frames + (size_t)f0 * in_h * in_w * 3, nb, in_h, in_w, P, 3, st));
+            else net.chk(k_pack_nchw(ctx, nchw + (size_t)f0 * 3 * 224 * 224, nb, P, 3, st));
+            const Tensor* w = net.T("stem7.w");
+            if (net.err != AVCER_OK) return;
+            if (!w->x3) { net.err = set_err(ctx, AVCER_ESTATE, "stem7.w: split weights not prepared"); return; }
+            net.chk(launch_stem_pool(ctx, P, (size_t)nb * 230 * 230 * 4 * 2, w->x3, net.F("stem.s"), net.F("stem.b"), B[1], nb, st));
+            net.tap("stem", B[1], (size_t)nb * 55 * 55 * 64 * es);
+            return;
+        }
         if (frames) net.chk(k_preprocess(ctx, frames + (size_t)f0 * in_h * in_w * 3, nb, in_h, in_w, P, bf, st));
         else net.chk(k_pack_nchw(ctx, nchw + (size_t)f0 * 3 * 224 * 224, nb, P, bf, st));
         // 8 tap rows x (8 pixels x 4 channels) over the zero-bordered 230x230x4 image, stride 2
@@ -379,11 +390,33 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     // one stage (li) of bottlenecks on nb frames; the last block writes to `last_out` when given
     auto run_stage = [&](int li, int nb, void*& X, void*& T1, void*& T2, void*& OUT, int& h, int& cin, void* last_out) {
         const int planes = kStages[li][0], blocks = kStages[li][1];
+        const bool chain = net.x3 && li < 2;  // stages 1-2 in x3 mode: non-first blocks run as the fused chain (fused.hip)
         for (int b = 0; b < blocks; ++b) {
             const int stride = b == 0 ? kStages[li][2] : 1;
             const std::string p = "l" + std::to_string(li + 1) + "." + std::to_string(b) + ".";
             const int oh = (h - 1) / stride + 1;
             void* dst = (b == blocks - 1 && last_out) ? last_out : OUT;
+            if (chain && b >= 1) {
+                // T1 of this block is in T1 (written by the standalone conv1 of block 1 or by the previous chain launch)
+                if (b == 1)
+                    net.gemm(conv2d_desc(nb, h, h, cin, 1, 1, 1, 0, planes, 1), p + "c1.w", net.F(p + "c1.s"), net.F(p + "c1.b"),
+                             X, nullptr, T1, act, act);
+                const bool next = b + 1 < blocks;
+                const std::string pn = "l" + std::to_string(li + 1) + "." + std::to_string(b + 1) + ".";
+                const Tensor *w2 = net.T(p + "c2.wp"), *w3 = net.T(p + "c3.wp"), *w1n = next ? net.T(pn + "c1.wp") : nullptr;
+                if (net.err != AVCER_OK) return;
+                if (!w2->x3 || !w3->x3 || (next && !w1n->x3)) {
+                    net.err = set_err(ctx, AVCER_ESTATE, "%s: split chain weights not prepared", p.c_str());
+                    return;
+                }
+                net.chk(launch_bneck(ctx, planes, nb, h, h, T1, X, dst, next ? T2 : nullptr, w2->x3, net.F(p + "c2.s"),
+                                     net.F(p + "c2.b"), w3->x3, net.F(p + "c3.s"), net.F(p + "c3.b"), next ? w1n->x3 : nullptr,
+                                     next ? net.F(pn + "c1.s") : nullptr, next ? net.F(pn + "c1.b") : nullptr, st));
+                std::swap(T1, T2);  // the next block's T1 was written into T2
+                if (dst == OUT) std::swap(X, OUT);
+                else X = dst;
+                continue;
+            }
             net.gemm(conv2d_desc(nb, h, h, cin, 1, 1, stride, 0, planes, 1), p + "c1.w", net.F(p + "c1.s"),
                      net.F(p + "c1.b"), X, nullptr, T1, act, act);
             net.gemm(conv2d_desc(nb, oh, oh, planes, 3, 3, 1, 1, planes, 1), p + "c2.w", net.F(p + "c2.s"),

@@ -80,8 +80,21 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
                      const float* scale, const float* bias, const void* residual, void* y, hipStream_t st,
                      const void* x2 = nullptr);
 
+int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1);
+
+// ---- fused.hip (split-bf16 mode only)
+// planes: bf16 hi plane [n][230][230][4] followed plane_bytes later by the lo plane; y: sp32 [n][55][55][64]
+int launch_stem_pool(avcer_ctx* ctx, const void* planes, size_t plane_bytes, const void* w_x3, const float* scale,
+                     const float* bias, void* y, int n, hipStream_t st);
+// conv2 + conv3 (+ residual) of one non-first bottleneck and conv1 of the next block (t1n / w1n null when there is none);
+// all activations sp32, weights split-bf16 with permuted rows (packing.py: *.wp)
+int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, void* out, void* t1n,
+                 const void* w2, const float* s2, const float* b2, const void* w3, const float* s3, const float* b3,
+                 const void* w1n, const float* s1n, const float* b1n, hipStream_t st);
+
 // ---- kernels.hip (element-wise / reduction kernels; T selects f32 (0) or bf16 (1) activations)
-int k_preprocess(avcer_ctx*, const uint8_t* frames, int n, int in_h, int in_w, void* out, int bf16, hipStream_t);
+// kind: 0 = f32 [n,230,230,4], 1 = bf16, 3 = planar bf16 hi / lo (two [n,230,230,4] planes, the stem_pool input)
+int k_preprocess(avcer_ctx*, const uint8_t* frames, int n, int in_h, int in_w, void* out, int kind, hipStream_t);
 int k_maxpool3s2(avcer_ctx*, const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int bf16, hipStream_t);
 int k_avgpool_hw(avcer_ctx*, const void* x, float* y, int n, int hw, int c, int bf16, hipStream_t);
 int k_small_linear(avcer_ctx*, const float* x, const float* w, const float* b, float* logits, float* probs, int m,
@@ -104,7 +117,7 @@ int k_frame_mean(avcer_ctx*, const float* win_logits, const int32_t* lo, const i
 int k_fuse(avcer_ctx*, const float* stat, const float* dyn, const float* aud, int n, int n_aud, int aud_c,
            const double* w /*[21] device-side by value*/, int has_w1, int cwt, int cmask, double* comp_prob,
            int32_t* comp_argmax, hipStream_t);
-int k_pack_nchw(avcer_ctx*, const float* x, int n, void* out, int bf16, hipStream_t);
+int k_pack_nchw(avcer_ctx*, const float* x, int n, void* out, int kind, hipStream_t);
 int k_gather_windows(avcer_ctx*, const float* feats, const int32_t* idx, int nwin, float* out, hipStream_t);
 int k_audio_chunks(avcer_ctx*, const float* wav, const int32_t* starts, const int32_t* ends, int n, int window, int mode,
                    float* out, hipStream_t);

@@ -1,0 +1,500 @@
+// Fused kernels of the static CNN in the split-bf16 ("x3") arithmetic (gfx950 only).
+//
+//   stem_pool_kernel   preprocessed image (planar bf16 hi / lo) -> 7x7/2 convolution + BN + ReLU + 3x3/2 max-pool
+//                      ref: architectures/video.py:63-90,98-103,116-117
+//   bneck_kernel       the tail of one bottleneck and the head of the next one in ONE launch:
+//                        T1 --3x3 conv2+BN+ReLU--> T2 --1x1 conv3+BN, +X, ReLU--> OUT --1x1 conv1'+BN+ReLU--> T1'
+//                      ref: architectures/video.py:43-60 (Bottleneck.forward), one call per non-first block of a stage
+//
+// Why: layer by layer, the sp32 activations (4 bytes per element) of the 55x55 and 28x28 stages make conv3 + residual
+// and the following conv1 pure HBM streams (4.4-5.5 TB/s measured, profiles/r01_layers_x3.txt), and the stem writes a
+// 3.3 GB tensor per 1024 frames that the max-pool immediately re-reads.  Here T2 and the conv1' operand never leave
+// the registers: with weights as the MFMA A operand, a lane's accumulator holds 4 consecutive output channels of one
+// position; two 16-row weight tiles whose rows are stored in the order  row 16t + 4g + r  <->  channel 8g + 4t + r
+// (t = 0,1; g = lane >> 4; r = 0..3) give every lane group g the 8 consecutive channels 8g..8g+7 of a 32-channel
+// group, which is exactly the B-operand fragment of the NEXT contraction's K-step in natural K order -- and 16
+// contiguous bytes of the sp32 output row, so the stores are whole 64-byte half-lines.  The row permutation is applied
+// to the weights once, on the host (avcer_amd/packing.py: *.wp tensors).
+#include "common.h"
+#include "gemm_dev.h"
+
+namespace {
+
+// a.w ~= ah.wh + ah.wl + al.wh on the bf16 MFMA with f32 accumulation (same product order as conv_gemm MODE 3)
+__device__ __forceinline__ void mfma3(f32x4_t& acc, const bf16x8_t wh, const bf16x8_t wl, const bf16x8_t ah, const bf16x8_t al) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8_t ldfrag(const char* tile, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8_t*>(tile + swz(row, chunk));
+}
+
+// 8 f32 values -> bf16 hi / lo fragments (value = hi + lo + O(2^-17))
+__device__ __forceinline__ void split8v(const float (&v)[8], bf16x8_t& hi, bf16x8_t& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(v[j] - (float)h);
+    }
+}
+
+__device__ __forceinline__ void unpack8(const uint4 h, const uint4 l, float (&r)[8]) {
+    const uint32_t wh[4] = {h.x, h.y, h.z, h.w}, wl[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[2 * j] = bf2f((bf16_t)(wh[j] & 0xffff)) + bf2f((bf16_t)(wl[j] & 0xffff));
+        r[2 * j + 1] = bf2f((bf16_t)(wh[j] >> 16)) + bf2f((bf16_t)(wl[j] >> 16));
+    }
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ------------------------------------------------------------------------------------------------ stem + max-pool
+struct StemParams {
+    const char* P;         // bf16 hi plane [n][230][230][4]; the lo plane starts plane_bytes later
+    unsigned p_bytes;      // extent of both planes (hardware bounds check)
+    unsigned plane_bytes;
+    const char* W;         // split weights [64][7 tap rows x 32] (sp32 groups of 32 K-elements)
+    const float* scale;
+    const float* bias;
+    char* Y;               // sp32 [n][55][55][64]
+    int n;
+};
+
+constexpr int ST_TH = 8, ST_TW = 7;                       // pooled tile
+constexpr int ST_RH = 2 * ST_TH + 1, ST_RW = 2 * ST_TW + 1;  // stem region 17 x 15 = 255 positions
+constexpr int ST_TY = 7, ST_TX = 8;                       // tiles per frame (7 x 8 >= 55 / 8 x 55 / 7)
+
+__device__ __forceinline__ int stage64(int row, int chunk) { return row * 256 + ((chunk ^ (row & 7)) << 4); }
+
+// One block = one 8 x 7 tile of pooled outputs of one frame: the 17 x 15 stem positions under it are one 256-row
+// implicit-GEMM tile (K = 7 tap rows x 8 pixels x 4 channels, N = 64), the pool runs on the f32 image in LDS.
+// Neighbouring tiles recompute one shared stem row / column (255 positions per 224 useful ones).
+__global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
+    constexpr int BM = 256, BN = 64, NK = 7;
+    constexpr int TILE = (BM + BN) * ROWB;  // 40 KiB
+    __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = blk / (ST_TY * ST_TX), t = blk % (ST_TY * ST_TX);
+    const int ty = t / ST_TX, tx = t % ST_TX;
+
+    const auto prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.P), (short)0, (int)p.p_bytes, 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W), (short)0, 64 * NK * ROWB, 0x00020000);
+    const int lrow8 = lane >> 3, slot = lane & 7;
+    unsigned a_off[8], w_off[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = wave * 64 + j * 8 + lrow8;
+        const int ry = row / ST_RW, rx = row - ry * ST_RW;
+        const int sy = 2 * ST_TH * ty + ry, sx = 2 * ST_TW * tx + rx;  // stem output position
+        const bool ok = row < ST_RH * ST_RW && sy <= 111 && sx <= 111;
+        const int c = slot ^ swz_key(row);  // data chunk: 0-3 = 8 pixels x 4 channels of the hi plane, 4-7 = lo plane
+        a_off[j] = ok ? (unsigned)((((long)b * 230 + 2 * sy) * 230 + 2 * sx) * 8 + (c & 3) * 16) + (c >> 2) * p.plane_bytes : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = wave * 16 + j * 8 + lrow8;
+        w_off[j] = (unsigned)(row * (NK * ROWB) + ((slot ^ swz_key(row)) << 4));
+    }
+    auto issue = [&](int buf, int ky) {
+        char* sa = smem + buf * TILE + wave * (8 * 1024);
+        char* sb = smem + buf * TILE + BM * ROWB + wave * (2 * 1024);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dma16(prs, sa + j * 1024, a_off[j], (unsigned)(ky * 230 * 8));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma16(wrs, sb + j * 1024, w_off[j], (unsigned)(ky * ROWB));
+    };
+
+    f32x4_t acc[4][4];  // [channel tile][position tile]: wave = 64 positions x 64 channels
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4_t{0};
+    const int g = lane >> 4, l15 = lane & 15;
+    issue(0, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int ky = 0; ky < NK; ++ky) {
+        if (ky + 1 < NK) issue(cur ^ 1, ky + 1);
+        const char* sa = smem + cur * TILE;
+        const char* sb = sa + BM * ROWB;
+        bf16x8_t ah[4], al[4];
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm) {
+            ah[fm] = ldfrag(sa, wave * 64 + fm * 16 + l15, g);
+            al[fm] = ldfrag(sa, wave * 64 + fm * 16 + l15, 4 + g);
+        }
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+            const bf16x8_t wh = ldfrag(sb, fn * 16 + l15, g), wl = ldfrag(sb, fn * 16 + l15, 4 + g);
+#pragma unroll
+            for (int fm = 0; fm < 4; ++fm) mfma3(acc[fn][fm], wh, wl, ah[fm], al[fm]);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // BN + ReLU, parked as an f32 [256 positions][64 channels] image (64 KiB of the 80 KiB tile buffers)
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+        const int ch = fn * 16 + 4 * g;
+        const float4 sc = *reinterpret_cast<const float4*>(p.scale + ch), bi = *reinterpret_cast<const float4*>(p.bias + ch);
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm) {
+            const int row = wave * 64 + fm * 16 + l15;
+            *reinterpret_cast<float4*>(smem + stage64(row, ch >> 2)) =
+                make_float4(relu_nan(acc[fn][fm][0] * sc.x + bi.x), relu_nan(acc[fn][fm][1] * sc.y + bi.y),
+                            relu_nan(acc[fn][fm][2] * sc.z + bi.z), relu_nan(acc[fn][fm][3] * sc.w + bi.w));
+        }
+    }
+    __syncthreads();
+    // 3x3/2 max-pool over the image (no padding: video.py:103), 8 channels per thread, whole-line sp32 stores
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int item = pass * 256 + tid;
+        const int pp = item >> 3, c8 = item & 7;
+        const int ppy = pp / ST_TW, ppx = pp - ppy * ST_TW;
+        const int py = ST_TH * ty + ppy, px = ST_TW * tx + ppx;
+        if (pp >= ST_TH * ST_TW || py >= 55 || px >= 55) continue;
+        float m[8];
+        bool nan = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = 0.f;  // post-ReLU values are >= 0
+        bool anynan[8] = {false, false, false, false, false, false, false, false};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int row = (2 * ppy + dy) * ST_RW + 2 * ppx + dx;
+                const float4 u = *reinterpret_cast<const float4*>(smem + stage64(row, 2 * c8));
+                const float4 v = *reinterpret_cast<const float4*>(smem + stage64(row, 2 * c8 + 1));
+                const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { m[j] = fmaxf(m[j], x[j]); anynan[j] |= x[j] != x[j]; }
+            }
+        (void)nan;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (anynan[j]) m[j] = NAN;  // like torch's max-pool
+        bf16x8_t hi, lo;
+        split8v(m, hi, lo);
+        const long e = (((long)b * 55 + py) * 55 + px) * 64 + c8 * 8;
+        char* yp = p.Y + sp32_byte(e);
+        *reinterpret_cast<bf16x8_t*>(yp) = hi;
+        *reinterpret_cast<bf16x8_t*>(yp + 64) = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bottleneck chain
+struct BneckParams {
+    const char* T1;     // sp32 [M][P]: conv1 output of THIS block (3x3 input)
+    const char* X;      // sp32 [M][4P]: block input (residual)
+    char* OUT;          // sp32 [M][4P]
+    char* T1N;          // sp32 [M][P]: conv1 output of the NEXT block (null when there is none)
+    const char* W2;     // [P][9P] split, rows permuted
+    const char* W3;     // [4P][P] split, rows permuted
+    const char* W1N;    // [P][4P] split, rows permuted (next block's conv1)
+    const float *s2, *b2, *s3, *b3, *s1n, *b1n;  // folded BN, natural channel order
+    unsigned t1_bytes;
+    int M, H, Wd;       // M = nb * H * Wd positions
+};
+
+// BM positions per block, 4 waves, each wave owns BM/4 positions and ALL channels (so that a position's whole T2 /
+// OUT row lives in one wave's registers).  LDS: phase A double-buffers [BM + P rows][128 B]; phases B/C double-buffer
+// the weights of one 32-channel output group: P/32 tiles of W3 [32 rows][128 B] + one tile of W1N [P rows][128 B].
+template <int P, int BM, bool NEXT>
+__global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
+    constexpr int NQ = P / 32;            // K-steps of a P-channel contraction
+    constexpr int NT = BM / 64;           // 16-position tiles per wave
+    constexpr int NG = 4 * P / 32;        // 32-channel groups of the block output
+    constexpr int TILE_A = (BM + P) * ROWB;
+    constexpr int TILE_B = (32 * NQ + P) * ROWB;
+    constexpr int SMEM = 2 * (TILE_A > TILE_B ? TILE_A : TILE_B);
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const int lrow8 = lane >> 3, slot = lane & 7;
+    const int m_base = xcd_remap(blockIdx.x, gridDim.x) * BM;
+
+    const auto t1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.T1), (short)0, (int)p.t1_bytes, 0x00020000);
+    const auto w2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W2), (short)0, P * 9 * P * 4, 0x00020000);
+    const auto w3rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W3), (short)0, 4 * P * P * 4, 0x00020000);
+    const auto w1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(NEXT ? p.W1N : p.W3), (short)0, 4 * P * P * 4, 0x00020000);
+
+    // ---------------- phase A: T2 = relu(bn2(conv3x3(T1))), K = 9 taps x P channels, accumulators [P][BM/4] per wave
+    constexpr int A_ISS = BM / 32;  // A-tile DMA instructions per wave per K-step (8 rows each)
+    constexpr int W_ISS = P / 32;
+    unsigned a_off[A_ISS], w_off[W_ISS];
+    int a_y[A_ISS], a_x[A_ISS];
+#pragma unroll
+    for (int j = 0; j < A_ISS; ++j) {
+        const int row = wave * (A_ISS * 8) + j * 8 + lrow8;
+        const int m = m_base + row;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int x = mm % p.Wd, y = (mm / p.Wd) % p.H;
+        a_y[j] = ok ? y : -(1 << 28);
+        a_x[j] = x;
+        a_off[j] = (unsigned)((long)mm * (P * 4) + ((slot ^ swz_key(row)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < W_ISS; ++j) {
+        const int row = wave * (W_ISS * 8) + j * 8 + lrow8;
+        w_off[j] = (unsigned)((long)row * (9 * P * 4) + ((slot ^ swz_key(row)) << 4));
+    }
+    f32x4_t acc2[P / 16][NT];
+#pragma unroll
+    for (int i = 0; i < P / 16; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc2[i][t] = f32x4_t{0};
+    {
+        int ky = 0, kx = 0, kq = 0;
+        unsigned wk = 0;
+        auto issue = [&](int buf) {
+            char* sa = smem + buf * TILE_A + wave * (A_ISS * 1024);
+            char* sb = smem + buf * TILE_A + BM * ROWB + wave * (W_ISS * 1024);
+            const int dy = ky - 1, dx = kx - 1;
+            const int tap = ((dy * p.Wd + dx) * P + kq * 32) * 4;  // byte offset of this tap / channel chunk (may be negative)
+#pragma unroll
+            for (int j = 0; j < A_ISS; ++j) {
+                const bool ok = ((unsigned)(a_y[j] + dy) < (unsigned)p.H) & ((unsigned)(a_x[j] + dx) < (unsigned)p.Wd);
+                dma16(t1rs, sa + j * 1024, ok ? a_off[j] + (unsigned)tap : OOB);
+            }
+#pragma unroll
+            for (int j = 0; j < W_ISS; ++j) dma16(w2rs, sb + j * 1024, w_off[j], wk);
+            wk += ROWB;
+            if (++kq == NQ) { kq = 0; if (++kx == 3) { kx = 0; ++ky; } }
+        };
+        issue(0);
+        __syncthreads();
+        int cur = 0;
+        constexpr int NK = 9 * NQ;
+        for (int step = 0; step < NK; ++step) {
+            if (step + 1 < NK) issue(cur ^ 1);
+            const char* sa = smem + cur * TILE_A;
+            const char* sb = sa + BM * ROWB;
+            bf16x8_t ah[NT], al[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int row = wave * (BM / 4) + t * 16 + l15;
+                ah[t] = ldfrag(sa, row, g);
+                al[t] = ldfrag(sa, row, 4 + g);
+            }
+#pragma unroll
+            for (int i = 0; i < P / 16; ++i) {
+                const bf16x8_t wh = ldfrag(sb, i * 16 + l15, g), wl = ldfrag(sb, i * 16 + l15, 4 + g);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) mfma3(acc2[i][t], wh, wl, ah[t], al[t]);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    // ---------------- weights of output group G -> LDS buffer (G & 1)
+    unsigned g3_off[NQ], g1_off[W_ISS];  // W3: NQ tiles of 32 rows = NQ*4 instr per block -> NQ per wave; W1N: P/8 instr -> P/32 per wave
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        // instruction j of this wave fills rows [8 wave, 8 wave + 8) of K-step tile j of W3's 32-row group
+        const int row = wave * 8 + lrow8;
+        g3_off[j] = (unsigned)((long)row * (P * 4) + j * ROWB + ((slot ^ swz_key(row)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < W_ISS; ++j) {
+        const int row = wave * (W_ISS * 8) + j * 8 + lrow8;
+        g1_off[j] = (unsigned)((long)row * (4 * P * 4) + ((slot ^ swz_key(row)) << 4));
+    }
+    auto issue_group = [&](int G) {
+        char* base = smem + (G & 1) * TILE_B;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) dma16(w3rs, base + j * (32 * ROWB) + wave * 1024, g3_off[j], (unsigned)(G * 32 * P * 4));
+        if constexpr (NEXT) {
+#pragma unroll
+            for (int j = 0; j < W_ISS; ++j)
+                dma16(w1rs, base + NQ * (32 * ROWB) + wave * (W_ISS * 1024) + j * 1024, g1_off[j], (unsigned)(G * ROWB));
+        }
+    };
+    issue_group(0);  // the tile buffers are free: phase A ended on a barrier
+
+    // residual rows of this lane: position m_t = m_base + wave*BM/4 + 16 t + (lane & 15); 16 bytes hi + 16 bytes lo per group
+    long x_row[NT];
+    bool m_ok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const long m = (long)m_base + wave * (BM / 4) + t * 16 + l15;
+        m_ok[t] = m < p.M;
+        x_row[t] = (m_ok[t] ? m : 0) * (4L * P * 4) + 16 * g;
+    }
+    uint4 rh[NT], rl[NT];
+    auto load_res = [&](int G) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const char* rp = p.X + x_row[t] + G * 128;
+            rh[t] = *reinterpret_cast<const uint4*>(rp);
+            rl[t] = *reinterpret_cast<const uint4*>(rp + 64);
+        }
+    };
+    load_res(0);
+
+    // T2 as B-operand fragments: K-step q = channels 32q..32q+31, lane group g holds 8g..8g+7 (weight rows were permuted)
+    bf16x8_t t2h[NQ][NT], t2l[NQ][NT];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int ch = 32 * q + 8 * g;
+        const float4 s0 = *reinterpret_cast<const float4*>(p.s2 + ch), s1 = *reinterpret_cast<const float4*>(p.s2 + ch + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(p.b2 + ch), b1 = *reinterpret_cast<const float4*>(p.b2 + ch + 4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4_t lo4 = acc2[2 * q][t], hi4 = acc2[2 * q + 1][t];
+            const float v[8] = {relu_nan(lo4[0] * s0.x + b0.x), relu_nan(lo4[1] * s0.y + b0.y), relu_nan(lo4[2] * s0.z + b0.z),
+                                relu_nan(lo4[3] * s0.w + b0.w), relu_nan(hi4[0] * s1.x + b1.x), relu_nan(hi4[1] * s1.y + b1.y),
+                                relu_nan(hi4[2] * s1.z + b1.z), relu_nan(hi4[3] * s1.w + b1.w)};
+            split8v(v, t2h[q][t], t2l[q][t]);
+        }
+    }
+    f32x4_t acc1[NEXT ? P / 16 : 1][NT];
+#pragma unroll
+    for (int i = 0; i < (NEXT ? P / 16 : 1); ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc1[i][t] = f32x4_t{0};
+    __syncthreads();  // group 0 has landed
+
+    // ---------------- phases B + C per 32-channel output group
+    for (int G = 0; G < NG; ++G) {
+        if (G + 1 < NG) issue_group(G + 1);
+        const char* w3t = smem + (G & 1) * TILE_B;
+        const char* w1t = w3t + NQ * (32 * ROWB);
+        f32x4_t acc3[2][NT];
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc3[tp][t] = f32x4_t{0};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                const bf16x8_t wh = ldfrag(w3t + q * (32 * ROWB), tp * 16 + l15, g), wl = ldfrag(w3t + q * (32 * ROWB), tp * 16 + l15, 4 + g);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) mfma3(acc3[tp][t], wh, wl, t2h[q][t], t2l[q][t]);
+            }
+        const int ch = 32 * G + 8 * g;
+        const float4 s0 = *reinterpret_cast<const float4*>(p.s3 + ch), s1 = *reinterpret_cast<const float4*>(p.s3 + ch + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(p.b3 + ch), b1 = *reinterpret_cast<const float4*>(p.b3 + ch + 4);
+        bf16x8_t oh[NT], ol[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float r[8];
+            unpack8(rh[t], rl[t], r);
+            const f32x4_t lo4 = acc3[0][t], hi4 = acc3[1][t];
+            const float v[8] = {relu_nan(lo4[0] * s0.x + b0.x + r[0]), relu_nan(lo4[1] * s0.y + b0.y + r[1]),
+                                relu_nan(lo4[2] * s0.z + b0.z + r[2]), relu_nan(lo4[3] * s0.w + b0.w + r[3]),
+                                relu_nan(hi4[0] * s1.x + b1.x + r[4]), relu_nan(hi4[1] * s1.y + b1.y + r[5]),
+                                relu_nan(hi4[2] * s1.z + b1.z + r[6]), relu_nan(hi4[3] * s1.w + b1.w + r[7])};
+            split8v(v, oh[t], ol[t]);
+            if (m_ok[t]) {
+                char* yp = p.OUT + x_row[t] + G * 128;
+                *reinterpret_cast<bf16x8_t*>(yp) = oh[t];
+                *reinterpret_cast<bf16x8_t*>(yp + 64) = ol[t];
+            }
+        }
+        if (G + 1 < NG) load_res(G + 1);
+        if constexpr (NEXT) {
+#pragma unroll
+            for (int i = 0; i < P / 16; ++i) {
+                const bf16x8_t wh = ldfrag(w1t, i * 16 + l15, g), wl = ldfrag(w1t, i * 16 + l15, 4 + g);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) mfma3(acc1[i][t], wh, wl, oh[t], ol[t]);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- T1' = relu(bn1'(conv1'(OUT)))
+    if constexpr (NEXT) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int ch = 32 * q + 8 * g;
+            const float4 s0 = *reinterpret_cast<const float4*>(p.s1n + ch), s1 = *reinterpret_cast<const float4*>(p.s1n + ch + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(p.b1n + ch), b1 = *reinterpret_cast<const float4*>(p.b1n + ch + 4);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4_t lo4 = acc1[2 * q][t], hi4 = acc1[2 * q + 1][t];
+                const float v[8] = {relu_nan(lo4[0] * s0.x + b0.x), relu_nan(lo4[1] * s0.y + b0.y), relu_nan(lo4[2] * s0.z + b0.z),
+                                    relu_nan(lo4[3] * s0.w + b0.w), relu_nan(hi4[0] * s1.x + b1.x), relu_nan(hi4[1] * s1.y + b1.y),
+                                    relu_nan(hi4[2] * s1.z + b1.z), relu_nan(hi4[3] * s1.w + b1.w)};
+                bf16x8_t hi, lo;
+                split8v(v, hi, lo);
+                if (m_ok[t]) {
+                    const long m = (long)m_base + wave * (BM / 4) + t * 16 + l15;
+                    char* yp = p.T1N + m * (P * 4) + q * 128 + 16 * g;
+                    *reinterpret_cast<bf16x8_t*>(yp) = hi;
+                    *reinterpret_cast<bf16x8_t*>(yp + 64) = lo;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ launchers
+int launch_stem_pool(avcer_ctx* ctx, const void* planes, size_t plane_bytes, const void* w_x3, const float* scale,
+                     const float* bias, void* y, int n, hipStream_t st) {
+    if (!planes || !w_x3 || !scale || !bias || !y || n <= 0) return set_err(ctx, AVCER_EINVAL, "stem_pool: bad arguments");
+    if (2 * plane_bytes >= (size_t)OOB) return set_err(ctx, AVCER_EINVAL, "stem_pool: %d frames exceed the 4 GiB descriptor", n);
+    StemParams p;
+    p.P = (const char*)planes; p.plane_bytes = (unsigned)plane_bytes; p.p_bytes = (unsigned)(2 * plane_bytes);
+    p.W = (const char*)w_x3; p.scale = scale; p.bias = bias; p.Y = (char*)y; p.n = n;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    TRY(prof_begin(ctx, st, &ev0, &ev1));
+    stem_pool_kernel<<<dim3(n * ST_TY * ST_TX), dim3(256), 0, st>>>(p);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "stem_pool launch: %s", hipGetErrorString(e));
+    ctx->gemm_launches += 1;
+    ctx->gemm_flops += 2.0 * n * 112.0 * 112.0 * 64 * 147;
+    return AVCER_OK;
+}
+
+int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, void* out, void* t1n,
+                 const void* w2, const float* s2, const float* b2, const void* w3, const float* s3, const float* b3,
+                 const void* w1n, const float* s1n, const float* b1n, hipStream_t st) {
+    const long M = (long)nb * h * w;
+    if (!t1 || !x || !out || !w2 || !w3 || !s2 || !b2 || !s3 || !b3 || M <= 0)
+        return set_err(ctx, AVCER_EINVAL, "bneck: bad arguments");
+    if ((t1n != nullptr) != (w1n != nullptr) || (t1n && (!s1n || !b1n)))
+        return set_err(ctx, AVCER_EINVAL, "bneck: next-block conv1 needs weights, scale, bias and an output");
+    if (planes != 64 && planes != 128) return set_err(ctx, AVCER_EINVAL, "bneck: planes %d (64 or 128)", planes);
+    if (M * planes * 4L >= (long)OOB) return set_err(ctx, AVCER_EINVAL, "bneck: M=%ld too large for one pass", M);
+    BneckParams p;
+    p.T1 = (const char*)t1; p.X = (const char*)x; p.OUT = (char*)out; p.T1N = (char*)t1n;
+    p.W2 = (const char*)w2; p.W3 = (const char*)w3; p.W1N = (const char*)w1n;
+    p.s2 = s2; p.b2 = b2; p.s3 = s3; p.b3 = b3; p.s1n = s1n; p.b1n = b1n;
+    p.t1_bytes = (unsigned)(M * planes * 4);
+    p.M = (int)M; p.H = h; p.Wd = w;
+    constexpr int BM = 128;
+    const int grid = (int)((M + BM - 1) / BM);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    TRY(prof_begin(ctx, st, &ev0, &ev1));
+    if (planes == 64) {
+        if (t1n) bneck_kernel<64, BM, true><<<dim3(grid), dim3(256), 0, st>>>(p);
+        else bneck_kernel<64, BM, false><<<dim3(grid), dim3(256), 0, st>>>(p);
+    } else {
+        if (t1n) bneck_kernel<128, BM, true><<<dim3(grid), dim3(256), 0, st>>>(p);
+        else bneck_kernel<128, BM, false><<<dim3(grid), dim3(256), 0, st>>>(p);
+    }
+    if (ev1) (void)hipEventRecord(ev1, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "bneck launch: %s", hipGetErrorString(e));
+    ctx->gemm_launches += 1;
+    ctx->gemm_flops += 2.0 * (double)M * planes * planes * (9.0 + 4.0 + (t1n ? 4.0 : 0.0));
+    return AVCER_OK;
+}

@@ -520,6 +520,24 @@ void launch_t(const GemmParams& p0, hipStream_t st) {
 
 }  // namespace
 
+// Live timing of the MFMA kernels (avcer_profile_enable): a pair of events around each launch, on the launch stream.
+// Records *ev0 now; the caller records *ev1 behind its launch.  Both stay null while profiling is off.
+int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1) {
+    *ev0 = *ev1 = nullptr;
+    if (!ctx->prof) return AVCER_OK;
+    if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
+        for (int i = 0; i < 512; ++i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return set_err(ctx, AVCER_EHIP, "hipEventCreate failed");
+            ctx->prof_ev.push_back(e);
+        }
+    }
+    *ev0 = ctx->prof_ev[ctx->prof_used++];
+    *ev1 = ctx->prof_ev[ctx->prof_used++];
+    (void)hipEventRecord(*ev0, st);
+    return AVCER_OK;
+}
+
 int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const void* x, const void* w,
                      const float* scale, const float* bias, const void* residual, void* y, hipStream_t st,
                      const void* x2) {
@@ -581,18 +599,7 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
              (long)(d.out_h - 1) * d.stride_h + (long)(d.kh - 1) * d.dil_h < d.in_h &&
              (long)(d.out_w - 1) * d.stride_w + (long)(d.kw - 1) * d.dil_w < d.in_w;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (ctx->prof) {
-        if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
-            for (int i = 0; i < 512; ++i) {
-                hipEvent_t e;
-                if (hipEventCreate(&e) != hipSuccess) return set_err(ctx, AVCER_EHIP, "hipEventCreate failed");
-                ctx->prof_ev.push_back(e);
-            }
-        }
-        ev0 = ctx->prof_ev[ctx->prof_used++];
-        ev1 = ctx->prof_ev[ctx->prof_used++];
-        (void)hipEventRecord(ev0, st);
-    }
+    TRY(prof_begin(ctx, st, &ev0, &ev1));
     switch (dtype) {
         case 0: launch_t<0, 0>(p, st); break;  // f32
         case 1: launch_t<1, 1>(p, st); break;  // bf16 -> bf16

@@ -117,6 +117,59 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ in, T* __restrict_
     st4<T>(out, idx * 4, v);
 }
 
+// Planar split-bf16 variant (input of stem_pool_kernel): the same zero-bordered image as two bf16 planes
+// [n,230,230,4], hi = bf16(v) and lo = bf16(v - hi), so that one 8-pixel tap row is 64 contiguous bytes per plane.
+__device__ __forceinline__ void st4_planar(bf16_t* hi, bf16_t* lo, long idx, const float* v) {
+    bf16_t h[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = f2bf(v[j]);
+    uint2 hh, ll;
+    hh.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+    hh.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+    ll.x = (uint32_t)f2bf(v[0] - bf2f(h[0])) | ((uint32_t)f2bf(v[1] - bf2f(h[1])) << 16);
+    ll.y = (uint32_t)f2bf(v[2] - bf2f(h[2])) | ((uint32_t)f2bf(v[3] - bf2f(h[3])) << 16);
+    *reinterpret_cast<uint2*>(hi + idx * 4) = hh;
+    *reinterpret_cast<uint2*>(lo + idx * 4) = ll;
+}
+
+__global__ void preprocess_planar_kernel(const uint8_t* __restrict__ in, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int n,
+                                         int in_h, int in_w) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n * PP * PP;
+    if (idx >= total) return;
+    const int x = idx % PP;
+    const int y = (idx / PP) % PP;
+    const int b = idx / ((long)PP * PP);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (y >= 2 && y < 226 && x >= 2 && x < 226) {
+        int sy = y - 2, sx = x - 2;
+        if (in_h != 224 || in_w != 224) {  // PIL NEAREST: src = floor((dst + 0.5) * in / out)
+            sy = min((int)(((double)sy + 0.5) * ((double)in_h / 224.0)), in_h - 1);
+            sx = min((int)(((double)sx + 0.5) * ((double)in_w / 224.0)), in_w - 1);
+        }
+        const uint8_t* px = in + (((long)b * in_h + sy) * in_w + sx) * 3;
+        v[0] = (float)px[2] - 91.4953f;
+        v[1] = (float)px[1] - 103.8827f;
+        v[2] = (float)px[0] - 131.0912f;
+    }
+    st4_planar(hi, lo, idx, v);
+}
+
+__global__ void pack_nchw_planar_kernel(const float* __restrict__ in, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int n) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n * PP * PP;
+    if (idx >= total) return;
+    const int x = idx % PP;
+    const int y = (idx / PP) % PP;
+    const int b = idx / ((long)PP * PP);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (y >= 2 && y < 226 && x >= 2 && x < 226) {
+        const long o = (long)b * 3 * 224 * 224 + (long)(y - 2) * 224 + (x - 2);
+        v[0] = in[o]; v[1] = in[o + 224 * 224]; v[2] = in[o + 2 * 224 * 224];
+    }
+    st4_planar(hi, lo, idx, v);
+}
+
 // Same zero-bordered image from an ALREADY preprocessed float tensor [n,3,224,224] (the tensor the reference's
 // pth_model_static is called with, get_prob_video.py:103-109).
 template <typename T>
@@ -1006,9 +1059,11 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
         if (_e != hipSuccess) return set_err((ctx), AVCER_EHIP, name " launch: %s", hipGetErrorString(_e)); \
     } while (0)
 
-int k_preprocess(avcer_ctx* ctx, const uint8_t* frames, int n, int in_h, int in_w, void* out, int bf16, hipStream_t st) {
+int k_preprocess(avcer_ctx* ctx, const uint8_t* frames, int n, int in_h, int in_w, void* out, int kind, hipStream_t st) {
     const long total = (long)n * PP * PP;
-    if (bf16) preprocess_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>(frames, (bf16_t*)out, n, in_h, in_w);
+    if (kind == 3)
+        preprocess_planar_kernel<<<cdiv(total, 256), 256, 0, st>>>(frames, (bf16_t*)out, (bf16_t*)out + total * 4, n, in_h, in_w);
+    else if (kind == 1) preprocess_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>(frames, (bf16_t*)out, n, in_h, in_w);
     else preprocess_kernel<float><<<cdiv(total, 256), 256, 0, st>>>(frames, (float*)out, n, in_h, in_w);
     CHECK_LAUNCH(ctx, "preprocess");
     return AVCER_OK;
@@ -1257,9 +1312,10 @@ int k_face_head(avcer_ctx* ctx, const float* hd, int ld, int n, int hw, int row0
     return AVCER_OK;
 }
 
-int k_pack_nchw(avcer_ctx* ctx, const float* x, int n, void* out, int bf16, hipStream_t st) {
+int k_pack_nchw(avcer_ctx* ctx, const float* x, int n, void* out, int kind, hipStream_t st) {
     const long total = (long)n * PP * PP;
-    if (bf16) pack_nchw_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>(x, (bf16_t*)out, n);
+    if (kind == 3) pack_nchw_planar_kernel<<<cdiv(total, 256), 256, 0, st>>>(x, (bf16_t*)out, (bf16_t*)out + total * 4, n);
+    else if (kind == 1) pack_nchw_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>(x, (bf16_t*)out, n);
     else pack_nchw_kernel<float><<<cdiv(total, 256), 256, 0, st>>>(x, (float*)out, n);
     CHECK_LAUNCH(ctx, "pack_nchw");
     return AVCER_OK;

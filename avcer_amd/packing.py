@@ -61,6 +61,7 @@ def pack_static(sd) -> "OrderedDict[str, np.ndarray]":
     stem = np.zeros((64, 8, 8, 4), np.float32)
     stem[:, :7, :7, :3] = w.transpose(0, 2, 3, 1)
     out["stem.w"] = stem.reshape(64, 256)
+    out["stem7.w"] = np.ascontiguousarray(stem[:, :7].reshape(64, 224))  # 7 tap rows only: stem_pool_kernel (x3 mode)
     out["stem.s"], out["stem.b"] = _bn_fold(sd, "batch_norm1", STATIC_BN_EPS)
     for li, (planes, blocks, _) in enumerate(RESNET_STAGES, start=1):
         for b in range(blocks):
@@ -76,9 +77,28 @@ def pack_static(sd) -> "OrderedDict[str, np.ndarray]":
                 w3, s3, b3 = out.pop(f"{dst}.c3.w"), out.pop(f"{dst}.c3.s"), out.pop(f"{dst}.c3.b")
                 out[f"{dst}.c3d.w"] = np.ascontiguousarray(np.concatenate([w3 * s3[:, None], wd * s_d[:, None]], axis=1))
                 out[f"{dst}.c3d.b"] = (b3 + b_d).astype(np.float32)
+        if li <= 2:  # stages whose non-first blocks run as the fused chain conv2 -> conv3 (+x) -> next conv1 (x3 mode)
+            for b in range(1, blocks):
+                out[f"l{li}.{b}.c2.wp"] = permute_rows_for_chain(out[f"l{li}.{b}.c2.w"])
+                out[f"l{li}.{b}.c3.wp"] = permute_rows_for_chain(out[f"l{li}.{b}.c3.w"])
+                if b >= 2:
+                    out[f"l{li}.{b}.c1.wp"] = permute_rows_for_chain(out[f"l{li}.{b}.c1.w"])
     out["fc1.w"], out["fc1.b"] = _f32(sd["fc1.weight"]), _f32(sd["fc1.bias"])
     out["fc2.w"], out["fc2.b"] = _f32(sd["fc2.weight"]), _f32(sd["fc2.bias"])
     return out
+
+
+def permute_rows_for_chain(w: np.ndarray) -> np.ndarray:
+    """Row order of the weights the fused bottleneck kernel (csrc/fused.hip) streams: inside every group of 32 output
+    channels, stored row 16t + 4g + r holds channel 8g + 4t + r (t = 0,1; g = 0..3; r = 0..3), so that the two
+    16-row MFMA tiles of a group leave every lane group g with the 8 consecutive channels 8g..8g+7."""
+    n = w.shape[0]
+    assert n % 32 == 0
+    i = np.arange(32)
+    t, g, r = i // 16, (i % 16) // 4, i % 4
+    src = 8 * g + 4 * t + r
+    idx = (np.arange(0, n, 32)[:, None] + src[None, :]).reshape(-1)
+    return np.ascontiguousarray(w[idx])
 
 
 def pack_face(sd) -> "OrderedDict[str, np.ndarray]":

@@ -44,6 +44,35 @@ def test_static_stage_taps_fp32(engine_static, sd_static):
         assert err < 2e-4 * max(mx, 1.0), report
 
 
+def _sp32_to_f32(raw_i16: torch.Tensor, shape):
+    """Decode an sp32 tensor (per 32 channels: 32 bf16 hi then 32 bf16 lo; value = hi + lo) tapped as raw int16."""
+    c = shape[-1]
+    v = raw_i16.view(-1, c // 32, 2, 32).to(torch.int32)
+    f = (v << 16).view(torch.float32)
+    return (f[:, :, 0] + f[:, :, 1]).reshape(shape)
+
+
+def test_static_stage_taps_x3(engine_static, sd_static):
+    """Split-bf16 mode, stage by stage: the fused stem + max-pool kernel and the fused bottleneck chains of stages 1-2
+    (csrc/fused.hip) against the oracle's taps (video.py:98-117, 43-60).  9 frames: 9*55*55 is not a multiple of 128."""
+    frames = synth.face_frames(4321, 9)
+    taps = {}
+    with torch.no_grad():
+        ov.resnet50_forward(sd_static, ov.pth_processing(frames), taps)
+    report = []
+    for name in ("stem", "layer1", "layer2", "layer3", "layer4"):
+        ref = _nhwc(taps[name])
+        dst = engine_static.debug_tap(name, ref.numel() * 2, dtype=torch.int16)
+        engine_static.static_forward(torch.from_numpy(frames), MODE_BF16X3)
+        torch.cuda.synchronize()
+        assert engine_static.debug_tap_copied() == ref.numel() * 4, name
+        got = _sp32_to_f32(dst.cpu(), ref.shape)
+        report.append((name, (got - ref).abs().max().item(), ref.abs().max().item()))
+    print("static x3 stage errors (name, max|err|, max|ref|):", report)
+    for name, err, mx in report:
+        assert err < 3e-4 * max(mx, 1.0), report
+
+
 def test_static_matches_golden_and_oracle_fp32(engine_static, sd_static, golden):
     g = golden("static")
     frames = synth.face_frames(1234, 8)
