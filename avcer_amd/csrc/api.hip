@@ -409,9 +409,8 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
                     net.err = set_err(ctx, AVCER_ESTATE, "%s: split chain weights not prepared", p.c_str());
                     return;
                 }
-                net.chk(launch_bneck(ctx, planes, nb, h, h, T1, X, dst, next ? T2 : nullptr, w2->x3, net.F(p + "c2.s"),
-                                     net.F(p + "c2.b"), w3->x3, net.F(p + "c3.s"), net.F(p + "c3.b"), next ? w1n->x3 : nullptr,
-                                     next ? net.F(pn + "c1.s") : nullptr, next ? net.F(pn + "c1.b") : nullptr, st));
+                net.chk(launch_bneck(ctx, planes, nb, h, h, T1, X, dst, next ? T2 : nullptr, w2->x3, net.F(p + "c2.b"), w3->x3,
+                                     net.F(p + "c3.b"), next ? w1n->x3 : nullptr, next ? net.F(pn + "c1.b") : nullptr, st));
                 std::swap(T1, T2);  // the next block's T1 was written into T2
                 if (dst == OUT) std::swap(X, OUT);
                 else X = dst;
@@ -991,6 +990,23 @@ extern "C" int avcer_conv_gemm_dual(avcer_ctx* ctx, const avcer_conv_desc* d, in
     if (!ctx || !d || !x2) return AVCER_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return launch_conv_gemm(ctx, *d, dtype, x, w, scale, bias, residual, y, (hipStream_t)stream, x2);
+}
+
+extern "C" int avcer_bneck_chain(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, void* out,
+                                 void* t1n, const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n,
+                                 const float* b1n, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (nb <= 0 || h <= 0 || w <= 0) return set_err(ctx, AVCER_EINVAL, "bneck_chain: bad geometry");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_bneck(ctx, planes, nb, h, w, t1, x, out, t1n, w2, b2, w3, b3, w1n, b1n, (hipStream_t)stream);
+}
+
+extern "C" int avcer_stem_pool(avcer_ctx* ctx, const void* planes_hi_lo, size_t plane_bytes, const void* w, const float* scale,
+                               const float* bias, void* y, int n, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (plane_bytes != (size_t)n * 230 * 230 * 4 * 2) return set_err(ctx, AVCER_EINVAL, "stem_pool: plane_bytes != n*230*230*4*2");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_stem_pool(ctx, planes_hi_lo, plane_bytes, w, scale, bias, y, n, (hipStream_t)stream);
 }
 
 extern "C" int avcer_split_weights(avcer_ctx* ctx, const float* w, void* out, size_t numel, avcer_stream_t stream) {

@@ -87,10 +87,10 @@ int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1)
 int launch_stem_pool(avcer_ctx* ctx, const void* planes, size_t plane_bytes, const void* w_x3, const float* scale,
                      const float* bias, void* y, int n, hipStream_t st);
 // conv2 + conv3 (+ residual) of one non-first bottleneck and conv1 of the next block (t1n / w1n null when there is none);
-// all activations sp32, weights split-bf16 with permuted rows (packing.py: *.wp)
+// all activations sp32, weights split-bf16 with permuted rows and the BN scale folded in (packing.py: *.wp)
 int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, void* out, void* t1n,
-                 const void* w2, const float* s2, const float* b2, const void* w3, const float* s3, const float* b3,
-                 const void* w1n, const float* s1n, const float* b1n, hipStream_t st);
+                 const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n, const float* b1n,
+                 hipStream_t st);
 
 // ---- kernels.hip (element-wise / reduction kernels; T selects f32 (0) or bf16 (1) activations)
 // kind: 0 = f32 [n,230,230,4], 1 = bf16, 3 = planar bf16 hi / lo (two [n,230,230,4] planes, the stem_pool input)

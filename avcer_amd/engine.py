@@ -261,6 +261,11 @@ class Engine:
         self._check(self.lib.avcer_conv_gemm_dual(self.ctx, C.byref(desc), dtype, _ptr(x), _ptr(x2), _ptr(w), _ptr(scale),
                                                   _ptr(bias), _ptr(residual), _ptr(y), self._stream()))
 
+    def bneck_chain(self, planes: int, nb: int, h: int, w: int, t1, x, out, t1n, w2, b2, w3, b3, w1n=None, b1n=None):
+        """Kernel-level entry of the fused bottleneck chain (csrc/fused.hip); all tensors already on the device."""
+        self._check(self.lib.avcer_bneck_chain(self.ctx, planes, nb, h, w, _ptr(t1), _ptr(x), _ptr(out), _ptr(t1n), _ptr(w2),
+                                               _ptr(b2), _ptr(w3), _ptr(b3), _ptr(w1n), _ptr(b1n), self._stream()))
+
     def gemm_stats(self, reset: bool = True):
         n, f = C.c_int64(0), C.c_double(0.0)
         self._check(self.lib.avcer_gemm_stats(self.ctx, C.byref(n), C.byref(f), int(reset)))

@@ -12,6 +12,23 @@ WEIGHTS_AV_1 = (
     (0.01223291, 0.21364307, 0.66688002, 0.93791526, 0.0398964, 0.48670648, 0.22089692),
     (0.08876611, 0.68273542, 0.24734363, 0.01780348, 0.06330495, 0.48672896, 0.14870002),
 )
+# The other two learned tables of get_weights_matrices.py (rows 0-6 transposed: one row per model, columns in audio
+# order; row 7 of each matrix = the level-2 "double" model weights that get_pred_*.py pass as weights_2):
+#   get_weights_matrices.py:5-16   video-only fusion (VS, VD), used by get_pred_video.get_c_expr_db_pred
+#   get_weights_matrices.py:28-39  7-class audio + video ("Acl7": ExprModelV2, padding "repeat", step 1; get_pred_av.py:362-365)
+#   get_weights_matrices.py:51-62  8-class audio + video ("Acl8"), level 1 == WEIGHTS_AV_1 above
+WEIGHTS_V_1 = (
+    (0.42633145, 0.57803352, 0.01878466, 0.86451425, 0.16464752, 0.03786653, 0.81048546),
+    (0.57366855, 0.42196648, 0.98121534, 0.13548575, 0.83535248, 0.96213347, 0.18951454),
+)
+WEIGHTS_V_2 = (0.36499999999999994, 0.22999999999999998)
+WEIGHTS_AV7_1 = (
+    (0.85806901, 0.2579578, 0.2579578, 0.72010502, 0.62082661, 0.06281922, 0.70875895),
+    (0.11491265, 0.46222294, 0.62411413, 0.16716238, 0.31962795, 0.16603196, 0.24433032),
+    (0.02701833, 0.27981925, 0.17148297, 0.1127326, 0.05954545, 0.77114883, 0.04691073),
+)
+WEIGHTS_AV7_2 = (0.060000000000000005, 0.21000000000000002, 0.01)
+WEIGHTS_AV_2 = (0.16000000000000003, 0.36000000000000004, 0.01)
 COMPOUND_NAMES = ("Fearfully Surprised", "Happily Surprised", "Sadly Surprised", "Disgustedly Surprised",
                   "Angrily Surprised", "Sadly Fearful", "Sadly Angry")  # run.py:66-74
 MODEL_ORDER = ("AV", "VS", "VD", "A")

@@ -65,6 +65,46 @@ def read_audio_csv(path: str):
     return df[cols].values, frames
 
 
+def dataset_fusion_video(engine, prediction_file_format: str, path_pred: str, name_videos, weights_1, weights_2=(1, 1),
+                         modality: str = "V", weight_type: str = "single", ce_weights_type: bool = False, ce_mask: bool = True,
+                         ce_mask_types=(True, False), save_path: str = "src/pred_results/DF_C_EXPR_DB/"):
+    """get_pred_video.get_c_expr_db_pred (get_pred_video.py:203-342): fusion of the two visual models only.
+    Writes the three submission files of the reference (fused, static-only, dynamic-only; the single-model files carry
+    the script's global `ce_mask_types` list in their name, get_pred_video.py:330,338 -- reproduced as is).
+    Returns (image_locations, (v_pred, s_pred, d_pred), (v_txt, s_txt, d_txt))."""
+    import torch
+
+    fmt = pd.read_csv(prediction_file_format)
+    listed = set(fmt.image_location)
+    stats, dyns, locations = [], [], []
+    for video in name_videos:
+        stat = read_visual_csv(os.path.join(path_pred, "static__" + video) + ".csv")
+        dyn = read_visual_csv(os.path.join(path_pred, "dynamic__" + video) + ".csv")
+        n = min(len(stat), len(dyn))  # the reference intersects the two tables' frame names with the listed ones
+        names = [f"{video}/{str(f + 1).zfill(5)}.jpg" for f in range(n)]
+        sel = np.array([f for f in range(n) if names[f] in listed], dtype=np.int64)
+        if not len(sel):
+            continue
+        stats.append(torch.from_numpy(stat[sel].astype(np.float32)))
+        dyns.append(torch.from_numpy(dyn[sel].astype(np.float32)))
+        locations.extend(sorted(names[f] for f in sel))  # `sorted(need_image_location)`: zero-padded names keep frame order
+    stat_all = torch.cat(stats).to(engine.device)
+    dyn_all = torch.cat(dyns).to(engine.device)
+    n = len(locations)
+    zeros = torch.zeros(n, 7, device=engine.device)  # a third model with weight 0 adds exactly 0.0 to every class
+    w1 = [list(weights_1[0]), list(weights_1[1]), [0.0] * 7]
+    _, am_w = engine.fuse(stat_all, dyn_all, zeros, n, w1, (float(weights_2[0]), float(weights_2[1]), 0.0), ce_weights_type, ce_mask)
+    _, am_raw = engine.fuse(stat_all, dyn_all, zeros, n, None, (1, 1, 1), ce_weights_type, ce_mask)  # un-weighted single models
+    preds = (am_w[0].cpu().numpy(), am_raw[1].cpu().numpy(), am_raw[2].cpu().numpy())
+    os.makedirs(save_path, exist_ok=True)
+    tails = (f"sd_{weight_type}_{ce_weights_type}_{ce_mask}", f"static_{weight_type}_{ce_weights_type}_{list(ce_mask_types)}",
+             f"dynamic_{weight_type}_{ce_weights_type}_{list(ce_mask_types)}")
+    paths = tuple(os.path.join(save_path, f"C_EXPR_DB_{modality}_{t}.txt") for t in tails)
+    for path, pred in zip(paths, preds):
+        save_txt(SUBMISSION_COLUMNS, locations, pred, path)
+    return locations, preds, paths
+
+
 def save_txt(column_names, file_names, labels, save_name: str):
     """data/utils.py:212-219."""
     with open(save_name, "w") as fh:

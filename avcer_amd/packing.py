@@ -79,10 +79,9 @@ def pack_static(sd) -> "OrderedDict[str, np.ndarray]":
                 out[f"{dst}.c3d.b"] = (b3 + b_d).astype(np.float32)
         if li <= 2:  # stages whose non-first blocks run as the fused chain conv2 -> conv3 (+x) -> next conv1 (x3 mode)
             for b in range(1, blocks):
-                out[f"l{li}.{b}.c2.wp"] = permute_rows_for_chain(out[f"l{li}.{b}.c2.w"])
-                out[f"l{li}.{b}.c3.wp"] = permute_rows_for_chain(out[f"l{li}.{b}.c3.w"])
-                if b >= 2:
-                    out[f"l{li}.{b}.c1.wp"] = permute_rows_for_chain(out[f"l{li}.{b}.c1.w"])
+                for i in (2, 3) if b < 2 else (1, 2, 3):  # BN scale folded into the rows: the chain's epilogues only add the shift
+                    k = f"l{li}.{b}.c{i}"
+                    out[k + ".wp"] = permute_rows_for_chain(out[k + ".w"] * out[k + ".s"][:, None])
     out["fc1.w"], out["fc1.b"] = _f32(sd["fc1.weight"]), _f32(sd["fc1.bias"])
     out["fc2.w"], out["fc2.b"] = _f32(sd["fc2.weight"]), _f32(sd["fc2.bias"])
     return out

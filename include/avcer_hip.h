@@ -195,6 +195,26 @@ int avcer_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, const v
 int avcer_conv_gemm_dual(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, const void* x, const void* x2, const void* w,
                          const float* scale, const float* bias, const void* residual, void* y, avcer_stream_t stream);
 
+/* Fused kernels of the static CNN in the split-bf16 arithmetic (csrc/fused.hip), exported for kernel-level parity tests.
+ *
+ * avcer_bneck_chain: the tail of one ResNet bottleneck and the head of the next in ONE launch,
+ *     T2 = relu(conv3x3(T1) + b2);  OUT = relu(conv1x1(T2) + b3 + X);  T1N = relu(conv1x1(OUT) + b1n)
+ *   ref: architectures/video.py:43-60 (Bottleneck.forward; stride 1, no downsample), BatchNorm folded.
+ *   t1 sp32 [nb,h,w,planes], x / out sp32 [nb,h,w,4*planes], t1n sp32 [nb,h,w,planes] or NULL (then w1n, b1n NULL);
+ *   w2 [planes][9*planes], w3 [4*planes][planes], w1n [planes][4*planes]: BN scale folded into the rows, rows permuted
+ *   inside every group of 32 (stored row 16t+4g+r = channel 8g+4t+r; avcer_amd/packing.py permute_rows_for_chain), then
+ *   split by avcer_split_weights; b2 / b3 / b1n f32 BN shifts in natural channel order.  planes = 64 or 128.
+ *
+ * avcer_stem_pool: conv 7x7/2 (TF-"same" padding) + BN + ReLU + max-pool 3x3/2 in one launch,
+ *   ref: architectures/video.py:63-90,98-103,116-117.  planes_hi_lo: two bf16 planes [n,230,230,4] (hi, then lo plane_bytes
+ *   later) of the zero-bordered preprocessed image as avcer_static_forward builds it; w split [64][7*32] (tap rows of
+ *   8 pixels x 4 channels); scale / bias f32 [64]; y sp32 [n,55,55,64]. */
+int avcer_bneck_chain(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, void* out, void* t1n,
+                      const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n, const float* b1n,
+                      avcer_stream_t stream);
+int avcer_stem_pool(avcer_ctx* ctx, const void* planes_hi_lo, size_t plane_bytes, const void* w, const float* scale,
+                    const float* bias, void* y, int n, avcer_stream_t stream);
+
 /* Weight layout of dtype 3: for every group of 32 K-elements, 32 bf16 "hi" values then 32 bf16 "lo" values with
  * w = hi + lo (+ O(2^-17 |w|)).  w f32 [n*k] (k a multiple of 32) -> out, same size in bytes. Both device pointers. */
 int avcer_split_weights(avcer_ctx* ctx, const float* w, void* out, size_t numel, avcer_stream_t stream);

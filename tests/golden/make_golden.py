@@ -380,6 +380,89 @@ def gen_dataset_fusion():
     print("dataset fusion: submission lines", len(txt.splitlines()))
 
 
+# ----------------------------------------------------------------------------- F11: 7-class ("Acl7") and video-only dataset fusion (row f3)
+def _weights_tables():
+    """The three learned weight matrices of get_weights_matrices.py:5-62, read from the source text (constants only)."""
+    out = {}
+    for node in ast.walk(ast.parse(open(os.path.join(REF, "get_weights_matrices.py")).read())):
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") in ("weights_1", "weights_2", "weights_3"):
+            out[node.targets[0].id] = np.array(ast.literal_eval(node.value.args[0]))
+    return out
+
+
+def gen_dataset_fusion7():
+    """get_pred_av.get_c_expr_db_pred with the Acl7 configuration (get_pred_av.py:362-365: audio_repeat_1 tables of the
+    7-class ExprModelV2, weights of get_weights_matrices.py:28-39) and get_pred_video.get_c_expr_db_pred (two visual
+    models, weights of get_weights_matrices.py:5-16), both on synthetic per-video CSVs; outputs = the submission txts."""
+    import shutil
+    import tempfile
+
+    import pandas as pd
+
+    import data.utils as du
+    import get_pred_av as gpa
+    import get_pred_video as gpv
+
+    gpv.ce_mask_types = [True, False]  # a global of the script's __main__ that its function body reads (get_pred_video.py:330,338)
+    vid_cols = ["Neutral", "Happiness", "Sadness", "Surprise", "Fear", "Disgust", "Anger"]
+    aud_cols = ["Neutral", "Anger", "Disgust", "Fear", "Happiness", "Sadness", "Surprise"]
+    model = "7cl-FLW-ExprModelV2-2024.03.04-11.52.11"
+    wt = _weights_tables()
+    out = {"weights_1": wt["weights_1"], "weights_2": wt["weights_2"], "weights_3": wt["weights_3"]}
+    tmp = tempfile.mkdtemp()
+    cwd = os.getcwd()
+    try:
+        os.chdir(tmp)
+        root = os.path.join(tmp, "preds")
+        os.makedirs(os.path.join(root, "video"))
+        os.makedirs(os.path.join(root, "audio_repeat_1", model))
+        videos = {"vidC": (30, 30), "vidD": (41, 26)}  # (video frames, frames covered by audio windows)
+        fmt_rows = []
+        for vi, (name, (n, cover)) in enumerate(videos.items()):
+            stat = du.softmax(synth.centered(900 + vi, "stat", (n, 7), 1.5)).astype(np.float32)
+            dyn = synth.centered(910 + vi, "dyn", (n, 7), 2.0).astype(np.float32)
+            pd.DataFrame(stat, columns=vid_cols).to_csv(os.path.join(root, "video", f"static__{name}.csv"), index=False)
+            pd.DataFrame(dyn, columns=vid_cols).to_csv(os.path.join(root, "video", f"dynamic__{name}.csv"), index=False)
+            rows, frames = [], []
+            for w, lo in enumerate(range(0, cover, 25)):  # step 1 s at 25 fps, windows of 4 s
+                lg = synth.centered(920 + vi, f"aud{w}", (7,), 2.0).astype(np.float32)
+                for f in range(lo, min(lo + 101, cover)):
+                    rows.append(lg)
+                    frames.append(f"{f:06d}.jpg")
+            df = pd.DataFrame(np.array(rows), columns=aud_cols)
+            df["frames"] = frames
+            df.to_csv(os.path.join(root, "audio_repeat_1", model, f"{name}.csv"), index=False)
+            fmt_rows += [f"{name}/{f + 1:05d}.jpg" for f in range(n) if f % 5 != 2]
+            out[f"{name}_stat"], out[f"{name}_dyn"] = stat, dyn
+            out[f"{name}_aud_rows"] = np.array(rows)
+            out[f"{name}_aud_frames"] = np.array([int(f[:6]) for f in frames])
+            for kind in ("static", "dynamic"):
+                out[f"{name}_{kind}_csv"] = np.frombuffer(open(os.path.join(root, "video", f"{kind}__{name}.csv"), "rb").read(), dtype=np.uint8)
+            out[f"{name}_audio_csv"] = np.frombuffer(open(os.path.join(root, "audio_repeat_1", model, f"{name}.csv"), "rb").read(), dtype=np.uint8)
+        fmt = os.path.join(tmp, "prediction_file_format.csv")
+        pd.DataFrame({"image_location": fmt_rows}).to_csv(fmt, index=False)
+        out["format_rows"] = np.array(fmt_rows)
+        res = os.path.join(tmp, "src/pred_results/DF_C_EXPR_DB")
+        w_av7, w_av7_2 = wt["weights_2"][:7].T, wt["weights_2"][7]   # rows VS, VD, A; level-2 ("double") weights
+        w_v, w_v_2 = wt["weights_1"][:7].T, wt["weights_1"][7]
+        for weight_type, w2a, w2v in (("single", np.array([1, 1, 1]), np.array([1, 1])), ("double", w_av7_2, w_v_2)):
+            for cwt in (False, True):
+                for cm in (True, False):
+                    gpa.get_c_expr_db_pred(fmt, root, ["video", "audio_repeat_1", model], list(videos), w_av7, w2a, "AV_Acl7",
+                                           weight_type, cwt, cm)
+                    out[f"av7_{weight_type}_{int(cwt)}{int(cm)}"] = np.frombuffer(
+                        open(os.path.join(res, f"C_EXPR_DB_AV_Acl7_sd_{weight_type}_{cwt}_{cm}.txt"), "rb").read(), dtype=np.uint8)
+                    gpv.get_c_expr_db_pred(fmt, os.path.join(root, "video"), list(videos), w_v, w2v, "V", weight_type, cwt, cm)
+                    for kind, tail in (("sd", f"{cwt}_{cm}"), ("static", f"{cwt}_[True, False]"), ("dynamic", f"{cwt}_[True, False]")):
+                        out[f"v_{kind}_{weight_type}_{int(cwt)}{int(cm)}"] = np.frombuffer(
+                            open(os.path.join(res, f"C_EXPR_DB_V_{kind}_{weight_type}_{tail}.txt"), "rb").read(), dtype=np.uint8)
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+    np.savez_compressed(os.path.join(HERE, "dataset_fusion7.npz"), **out)
+    print("dataset fusion (Acl7 + V):", len([k for k in out if k.startswith(("av7_", "v_"))]), "submission files")
+
+
 # ----------------------------------------------------------------------------- F7/F8 fusion
 def gen_fusion():
     import pandas as pd
@@ -702,7 +785,7 @@ if __name__ == "__main__":
     from transformers.models.wav2vec2 import modeling_wav2vec2  # noqa: F401
 
     install_stubs()
-    which = sys.argv[1:] or ["face", "facenet", "visual", "audio", "fusion", "audio7", "dataset"]
+    which = sys.argv[1:] or ["face", "facenet", "visual", "audio", "fusion", "audio7", "dataset", "dataset7"]
     if "face" in which:  # first: gen_fusion replaces data.get_face_images by a stand-in module
         gen_face()
     if "facenet" in which:
@@ -717,3 +800,5 @@ if __name__ == "__main__":
         gen_audio7()
     if "dataset" in which:
         gen_dataset_fusion()
+    if "dataset7" in which:
+        gen_dataset_fusion7()

@@ -252,3 +252,43 @@ def test_dual_source_fused_1x1(engine, dtype):
     ref = F.relu(_dec(td, ak).double() @ wdv.double().cpu()[:, :p_].t() + xs @ wdv.double().cpu()[:, p_:].t() + bias.double())
     got = _dec(yd, ok).double()
     assert (got - ref).abs().max() < _tol(dtype, ref)
+
+
+# ----------------------------------------------------------------------------- fused bottleneck chain (csrc/fused.hip)
+@pytest.mark.parametrize("planes,nb,hw,nxt", [(64, 3, 55, True), (64, 2, 9, False), (128, 5, 28, True), (128, 1, 7, False)])
+def test_bneck_chain_vs_float64(engine, planes, nb, hw, nxt):
+    """conv3x3+ReLU -> conv1x1 + residual + ReLU -> next conv1x1 + ReLU in one launch against float64 torch convolutions
+    (video.py:43-60 with folded BatchNorm).  M = nb*hw*hw is never a multiple of the 128-position tile here."""
+    from avcer_amd.packing import permute_rows_for_chain
+
+    g = torch.Generator().manual_seed(planes + hw)
+    p4 = 4 * planes
+    t1 = torch.rand(nb, hw, hw, planes, generator=g) * 2          # post-ReLU activations
+    x = torch.rand(nb, hw, hw, p4, generator=g) * 2
+    w2 = torch.randn(planes, 3, 3, planes, generator=g) / (3 * planes ** 0.5)   # [O][kh][kw][I]
+    w3 = torch.randn(p4, planes, generator=g) / planes ** 0.5
+    w1 = torch.randn(planes, p4, generator=g) / p4 ** 0.5
+    b2, b3, b1 = (torch.randn(n, generator=g) * 0.3 for n in (planes, p4, planes))
+    # float64 reference (NCHW convolutions)
+    t2 = F.relu(F.conv2d(t1.permute(0, 3, 1, 2).double(), w2.permute(0, 3, 1, 2).double(), b2.double(), padding=1))
+    out = F.relu(F.conv2d(t2, w3.double()[:, :, None, None], b3.double()) + x.permute(0, 3, 1, 2).double())
+    t1n = F.relu(F.conv2d(out, w1.double()[:, :, None, None], b1.double()))
+    dev = engine.device
+
+    def wsplit(w):
+        return engine.split_weights(torch.from_numpy(permute_rows_for_chain(w.reshape(w.shape[0], -1).numpy())))
+
+    d_out = torch.full((nb, hw, hw, 2 * p4), 0x7fc0, dtype=torch.int16, device=dev)   # NaN-filled sp32
+    d_t1n = torch.full((nb, hw, hw, 2 * planes), 0x7fc0, dtype=torch.int16, device=dev) if nxt else None
+    engine.bneck_chain(planes, nb, hw, hw, to_sp32(t1).to(dev), to_sp32(x).to(dev), d_out, d_t1n, wsplit(w2), b2.to(dev),
+                       wsplit(w3), b3.to(dev), wsplit(w1) if nxt else None, b1.to(dev) if nxt else None)
+    torch.cuda.synchronize()
+    got = from_sp32(d_out.cpu()).permute(0, 3, 1, 2).double()
+    err = (got - out).abs().max().item()
+    print(f"bneck planes={planes} {nb}x{hw}x{hw}: max|out err| {err:.2e} (max|out| {out.abs().max().item():.1f})")
+    assert err < 2e-5 * max(1.0, out.abs().max().item())
+    if nxt:
+        got1 = from_sp32(d_t1n.cpu()).permute(0, 3, 1, 2).double()
+        err1 = (got1 - t1n).abs().max().item()
+        print(f"   max|t1n err| {err1:.2e} (max {t1n.abs().max().item():.1f})")
+        assert err1 < 2e-5 * max(1.0, t1n.abs().max().item())

@@ -91,7 +91,7 @@ def test_pack_static_layouts(sd_static):
     assert len(t) == 1 * 3 + 16 * 9 - 4 * 3 + 4 * 2 + 4 + 1 + n_chain
     np.testing.assert_array_equal(t["stem7.w"].reshape(64, 7, 8, 4), stem[:, :7])
     # chain weights (csrc/fused.hip): stored row 16t + 4g + r of every 32-row group holds channel 8g + 4t + r
-    wp, w0 = t["l2.2.c3.wp"], t["l2.2.c3.w"]
+    wp, w0 = t["l2.2.c3.wp"], t["l2.2.c3.w"] * t["l2.2.c3.s"][:, None]  # BN scale folded into the rows
     for q in (0, 5):
         for tt in range(2):
             for g in range(4):
