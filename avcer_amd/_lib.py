@@ -67,6 +67,8 @@ SIGNATURES = {
     "avcer_split_weights": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_size_t, c_stream]),
     "avcer_conv_gemm_dual": (C.c_int, [c_ctx, C.POINTER(ConvDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
+    "avcer_face_nms": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float,
+                                 C.c_void_p, C.c_void_p, c_stream]),
     "avcer_bneck_chain": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 + [c_stream]),
     "avcer_stem_pool": (C.c_int, [c_ctx, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_stream]),
     "avcer_gemm_stats": (C.c_int, [c_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),

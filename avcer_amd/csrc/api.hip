@@ -908,6 +908,20 @@ extern "C" int avcer_face_decode(avcer_ctx* ctx, const float* loc, const float* 
     return k_face_decode(ctx, loc, conf, landms, priors, n_priors, im_h, im_w, var0, var1, dets, (hipStream_t)stream);
 }
 
+extern "C" int avcer_face_nms(avcer_ctx* ctx, const float* dets, int n_frames, int n_priors, float conf_thresh, float nms_thresh,
+                              int nms_top_k, int top_k, float threshold, float* out, int32_t* out_n, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (!dets || !out || !out_n || n_frames <= 0 || n_priors <= 0 || nms_top_k <= 0 || top_k <= 0 || top_k > 1024)
+        return set_err(ctx, AVCER_EINVAL, "face_nms: bad arguments (top_k <= 1024)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void* wsp = nullptr;
+    TRY(ws_reserve(ctx, 4, ((size_t)n_frames * nms_top_k + n_frames) * 4 + 256, &wsp));
+    int32_t* order = (int32_t*)wsp;
+    int32_t* count = order + (size_t)n_frames * nms_top_k;
+    return k_face_nms(ctx, dets, n_frames, n_priors, conf_thresh, nms_thresh, nms_top_k, top_k, threshold, order, count, out, out_n,
+                      (hipStream_t)stream);
+}
+
 extern "C" int avcer_crop_tiles(avcer_ctx* ctx, const uint8_t* frames, int n_frames, int h, int w, const int32_t* rects,
                                 int n, int swap_rb, uint8_t* tiles, avcer_stream_t stream) {
     if (!ctx) return AVCER_EINVAL;

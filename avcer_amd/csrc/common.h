@@ -124,6 +124,8 @@ int k_audio_chunks(avcer_ctx*, const float* wav, const int32_t* starts, const in
 int k_split_weights(avcer_ctx*, const float* w, bf16_t* out, size_t n, hipStream_t);
 int k_face_decode(avcer_ctx*, const float* loc, const float* conf, const float* landms, const float* priors, int P, int im_h,
                   int im_w, float var0, float var1, float* dets, hipStream_t);
+int k_face_nms(avcer_ctx*, const float* dets, int T, int P, float conf_thresh, float nms_thresh, int nms_top_k, int top_k,
+               float threshold, int32_t* order, int32_t* count, float* out, int32_t* out_n, hipStream_t);
 int k_face_pre(avcer_ctx*, const uint8_t* frames, int n, int h, int w, int ph, int pw, int rgb, void* out, int bf16, hipStream_t);
 int k_maxpool3s2p1(avcer_ctx*, const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int kind, hipStream_t);
 int k_upsample_add(avcer_ctx*, void* y, const void* coarse, int n, int h, int w, int ch, int cw, int c, int kind, hipStream_t);

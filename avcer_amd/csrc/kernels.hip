@@ -217,6 +217,99 @@ __global__ void face_decode_kernel(const float* __restrict__ loc, const float* _
     }
 }
 
+// retina_face_predictor.py:86-108 + py_cpu_nms.py:11-39 on the GPU: confidence floor, descending-score order, greedy
+// NMS with the "+1 pixel" areas, top-k, final threshold.  Two kernels per batch of frames:
+//   face_rank_kernel   position of every candidate (score > conf_thresh) in the descending order of py_cpu_nms
+//                      (`scores.argsort()[: -top_k - 1 : -1]`; equal scores: the lower prior index first, i.e. a stable
+//                      descending sort -- numpy's default argsort leaves the order of ties undefined) by counting,
+//                      written as order[rank] = prior index
+//   face_nms_kernel    one workgroup per frame: the top nms_top_k boxes sit in LDS, boxes are visited in order, a kept
+//                      box clears every later box whose IoU with it exceeds the threshold (one barrier per KEPT box)
+// f32 arithmetic in numpy's evaluation order, contraction off, so the keep decisions are the reference's.
+__global__ void face_rank_kernel(const float* __restrict__ dets, int P, float conf_thresh, int nms_top_k,
+                                 int32_t* __restrict__ order, int32_t* __restrict__ count) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float* d = dets + (long)f * P * 15;
+    __shared__ float sc[256];
+    const float si = i < P ? d[15L * i + 4] : 0.f;
+    const bool cand = i < P && si > conf_thresh;
+    int rank = 0;
+    for (int j0 = 0; j0 < P; j0 += 256) {
+        __syncthreads();
+        const int jj = j0 + threadIdx.x;
+        sc[threadIdx.x] = jj < P ? d[15L * jj + 4] : -1.f;
+        __syncthreads();
+        if (cand) {
+            const int lim = min(256, P - j0);
+            for (int k = 0; k < lim; ++k) {
+                const float sj = sc[k];
+                rank += (sj > conf_thresh) && (sj > si || (sj == si && j0 + k < i));
+            }
+        }
+    }
+    if (cand) {
+        atomicAdd(count + f, 1);
+        if (rank < nms_top_k) order[(long)f * nms_top_k + rank] = i;
+    }
+}
+
+constexpr int NMS_THREADS = 1024;
+constexpr int NMS_MAX = 6144;  // boxes held in LDS: 5 floats + 1 flag byte each (126 KiB)
+
+__global__ void __launch_bounds__(NMS_THREADS) face_nms_kernel(const float* __restrict__ dets, int P, const int32_t* __restrict__ order,
+                                                                const int32_t* __restrict__ count, int nms_top_k, float nms_thresh,
+                                                                int top_k, float threshold, float* __restrict__ out,
+                                                                int32_t* __restrict__ out_n) {
+#pragma clang fp contract(off)
+    extern __shared__ char nms_smem[];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int n = min(count[f], nms_top_k);
+    float* bx = reinterpret_cast<float*>(nms_smem);       // [5][n]: x1, y1, x2, y2, area
+    unsigned char* dead = reinterpret_cast<unsigned char*>(bx + 5 * (long)n);
+    __shared__ int kept_n;
+    __shared__ int kept[1024];                            // kept boxes beyond top_k are never reported
+    const float* d = dets + (long)f * P * 15;
+    const int32_t* ord = order + (long)f * nms_top_k;
+    for (int a = tid; a < n; a += NMS_THREADS) {
+        const float* r = d + 15L * ord[a];
+        const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
+        bx[a] = x1; bx[n + a] = y1; bx[2 * n + a] = x2; bx[3 * n + a] = y2;
+        bx[4 * n + a] = (x2 - x1 + 1.0f) * (y2 - y1 + 1.0f);
+        dead[a] = 0;
+    }
+    if (tid == 0) kept_n = 0;
+    __syncthreads();
+    for (int a = 0; a < n; ++a) {
+        if (dead[a]) continue;  // uniform: every thread reads the same flag after the previous barrier
+        if (tid == 0 && kept_n < 1024) kept[kept_n++] = a;
+        const float x1 = bx[a], y1 = bx[n + a], x2 = bx[2 * n + a], y2 = bx[3 * n + a], ar = bx[4 * n + a];
+        for (int b = a + 1 + tid; b < n; b += NMS_THREADS) {
+            if (dead[b]) continue;
+            const float w = fmaxf(0.0f, fminf(x2, bx[2 * n + b]) - fmaxf(x1, bx[b]) + 1.0f);
+            const float h = fmaxf(0.0f, fminf(y2, bx[3 * n + b]) - fmaxf(y1, bx[n + b]) + 1.0f);
+            const float inter = w * h;
+            const float ovr = inter / (ar + bx[4 * n + b] - inter);
+            if (!(ovr <= nms_thresh)) dead[b] = 1;
+        }
+        __syncthreads();
+    }
+    // dets[keep][:top_k], then the rows with score >= threshold (retina_face_predictor.py:96-108)
+    const int nk = min(kept_n, min(top_k, 1024));
+    __shared__ int out_rows;
+    if (tid == 0) {
+        int m = 0;
+        for (int k = 0; k < nk; ++k) {
+            const int idx = ord[kept[k]];
+            if (d[15L * idx + 4] >= threshold) kept[m++] = idx;  // compaction in place (m <= k)
+        }
+        out_rows = m;
+        out_n[f] = m;
+    }
+    __syncthreads();
+    for (int e = tid; e < out_rows * 15; e += NMS_THREADS) out[((long)f * top_k + e / 15) * 15 + e % 15] = d[15L * kept[e / 15] + e % 15];
+}
+
 // get_face_images.py:52-56 (crop of the decoded frame) + data/utils.py:34 (PIL NEAREST resize to 224x224) in one pass:
 // tile pixel (y, x) = frame[f][y0 + floor((y + .5) * ch / 224)][x0 + floor((x + .5) * cw / 224)], channels swapped
 // when the frames are BGR (cv2) so that the tile is RGB like the image PIL reads back.  One thread per 4 tile pixels.
@@ -1272,6 +1365,23 @@ int k_crop_tiles(avcer_ctx* ctx, const uint8_t* frames, int T, int H, int W, con
                  uint8_t* tiles, hipStream_t st) {
     crop_tiles_kernel<<<cdiv((long)n * 224 * 56, 256), 256, 0, st>>>(frames, T, H, W, rects, n, swap_rb, tiles);
     CHECK_LAUNCH(ctx, "crop_tiles");
+    return AVCER_OK;
+}
+
+int k_face_nms(avcer_ctx* ctx, const float* dets, int T, int P, float conf_thresh, float nms_thresh, int nms_top_k, int top_k,
+               float threshold, int32_t* order, int32_t* count, float* out, int32_t* out_n, hipStream_t st) {
+    if (nms_top_k > NMS_MAX) return set_err(ctx, AVCER_EINVAL, "face_nms: nms_top_k %d exceeds %d", nms_top_k, NMS_MAX);
+    if (hipMemsetAsync(count, 0, (size_t)T * 4, st) != hipSuccess) return set_err(ctx, AVCER_EHIP, "face_nms: memset failed");
+    face_rank_kernel<<<dim3(cdiv(P, 256), T), 256, 0, st>>>(dets, P, conf_thresh, nms_top_k, order, count);
+    CHECK_LAUNCH(ctx, "face_rank");
+    static uint64_t attr_dev = 0;
+    if (!((attr_dev >> (ctx->device & 63)) & 1)) {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)face_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_dev |= 1ull << (ctx->device & 63);
+    }
+    const size_t lds = (size_t)std::min(nms_top_k, P) * 21 + 16;
+    face_nms_kernel<<<T, NMS_THREADS, lds, st>>>(dets, P, order, count, nms_top_k, nms_thresh, top_k, threshold, out, out_n);
+    CHECK_LAUNCH(ctx, "face_nms");
     return AVCER_OK;
 }
 

@@ -196,6 +196,22 @@ class Engine:
                                                float(variance[1]), _ptr(dets), self._stream()))
         return dets
 
+    def face_nms(self, dets, conf_thresh: float = 0.02, nms_thresh: float = 0.4, nms_top_k: int = 5000, top_k: int = 750,
+                 threshold: float = 0.8):
+        """dets [T,P,15] (face_decode output per frame) -> (rows [T,top_k,15], counts [T]) after the reference's confidence
+        floor, NMS, top-k and final threshold; only counts[t] rows of frame t are meaningful."""
+        d = self._dev(dets, torch.float32)
+        if d.dim() == 2:
+            d = d[None]
+        if d.dim() != 3 or d.shape[2] != 15:
+            raise ValueError("face_nms: dets [T,P,15]")
+        t, p = int(d.shape[0]), int(d.shape[1])
+        out = self._new(t, top_k, 15)
+        cnt = self._new(t, dtype=torch.int32)
+        self._check(self.lib.avcer_face_nms(self.ctx, _ptr(d), t, p, float(conf_thresh), float(nms_thresh), int(nms_top_k),
+                                            int(top_k), float(threshold), _ptr(out), _ptr(cnt), self._stream()))
+        return out, cnt
+
     def crop_tiles(self, frames_u8, rects, bgr: bool = True):
         """frames u8 [T,H,W,3] + rects i32 [n,5] (frame, x0, y0, x1, y1; validated by the caller) -> RGB tiles [n,224,224,3]."""
         x = self._dev(frames_u8, torch.uint8)

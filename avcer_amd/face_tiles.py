@@ -50,26 +50,6 @@ def prior_boxes(image_size) -> np.ndarray:
     return _prior_boxes(int(image_size[0]), int(image_size[1]))
 
 
-def nms(dets: np.ndarray, thresh: float, top_k: int) -> List[int]:
-    """Greedy NMS over [n,5] = x1, y1, x2, y2, score with the +1 pixel area convention; returns kept row indices."""
-    x1, y1, x2, y2, scores = (dets[:, c] for c in range(5))
-    areas = (x2 - x1 + 1) * (y2 - y1 + 1)
-    order = scores.argsort()[: -top_k - 1: -1]
-    alive = np.ones(len(order), dtype=bool)
-    keep = []
-    for pos in range(len(order)):
-        if not alive[pos]:
-            continue
-        i = order[pos]
-        keep.append(int(i))
-        rest = order[pos + 1:]
-        w = np.maximum(0.0, np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]) + 1)
-        h = np.maximum(0.0, np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]) + 1)
-        inter = w * h
-        alive[pos + 1:] &= inter / (areas[i] + areas[rest] - inter) <= thresh
-    return keep
-
-
 class FaceDetections:
     """The post-network half of `RetinaFacePredictor`: same constructor thresholds, same [k,15] float32 result."""
 
@@ -87,15 +67,24 @@ class FaceDetections:
         if key not in self._priors_dev:
             self._priors_dev[key] = torch.from_numpy(np.array(prior_boxes(key))).to(self.engine.device)
         dets = self.engine.face_decode(loc, conf, landms, self._priors_dev[key], key, CFG_RE50["variance"])
-        dets = dets.cpu().numpy()
-        inds = np.where(dets[:, 4] > self.conf_thresh)[0]
-        if len(inds) == 0:
-            return np.empty((0, 15), dtype=np.float32)
-        dets = dets[inds]
-        keep = nms(dets[:, :5], self.nms_thresh, self.nms_top_k)
-        dets = dets[keep][: self.top_k]
-        sel = np.where(dets[:, 4] >= self.threshold)[0]
-        return dets[sel] if len(sel) else np.empty((0, 15), dtype=np.float32)
+        # confidence floor, NMS (py_cpu_nms order), top-k and the final threshold run on the device: only the kept rows
+        # and their count come back to the host
+        rows, cnt = self.engine.face_nms(dets[None], self.conf_thresh, self.nms_thresh, self.nms_top_k, self.top_k, self.threshold)
+        k = int(cnt[0])
+        return rows[0, :k].cpu().numpy() if k else np.empty((0, 15), dtype=np.float32)
+
+
+    def batch(self, loc, conf, landms, image_size) -> List[np.ndarray]:
+        """[T,P,*] network outputs of T frames -> one [k,15] array per frame: decode per frame, ONE NMS launch pair and
+        ONE device-to-host copy for the whole batch."""
+        key = (int(image_size[0]), int(image_size[1]))
+        if key not in self._priors_dev:
+            self._priors_dev[key] = torch.from_numpy(np.array(prior_boxes(key))).to(self.engine.device)
+        dets = torch.stack([self.engine.face_decode(loc[t], conf[t], landms[t], self._priors_dev[key], key, CFG_RE50["variance"])
+                            for t in range(int(loc.shape[0]))])
+        rows, cnt = self.engine.face_nms(dets, self.conf_thresh, self.nms_thresh, self.nms_top_k, self.top_k, self.threshold)
+        rows, cnt = rows.cpu().numpy(), cnt.cpu().numpy()
+        return [rows[t, :int(cnt[t])] if cnt[t] else np.empty((0, 15), dtype=np.float32) for t in range(len(cnt))]
 
 
 class RetinaFacePredictor:
@@ -120,7 +109,7 @@ class RetinaFacePredictor:
         x = frames if torch.is_tensor(frames) else torch.from_numpy(np.ascontiguousarray(frames))
         loc, conf, lm = self.engine.face_forward(x, self.mode, rgb=rgb)
         size = (int(x.shape[1]), int(x.shape[2]))
-        return [self.post(loc[t], conf[t], lm[t], size) for t in range(int(x.shape[0]))]
+        return self.post.batch(loc, conf, lm, size)
 
 
 class SimpleFaceTracker:

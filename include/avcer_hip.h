@@ -132,6 +132,16 @@ int avcer_face_num_priors(int h, int w);
 int avcer_face_forward(avcer_ctx* ctx, const uint8_t* frames, int n, int h, int w, int rgb, int mode, float* loc,
                        float* conf, float* landms, avcer_stream_t stream);
 
+/* The post-decode half of RetinaFacePredictor.__call__ for a batch of frames, on the device:
+ *   ref: retina_face/retina_face_predictor.py:86-108 (confidence floor, NMS, top-k, final threshold),
+ *        retina_face/py_cpu_nms.py:11-39 (greedy NMS, "+1 pixel" areas, visit order = descending score).
+ * dets f32 [n_frames, n_priors, 15] as avcer_face_decode writes them; out f32 [n_frames, top_k, 15] receives, per frame,
+ * the kept rows in the reference's order; out_n i32 [n_frames] their number.  nms_top_k <= 6144, top_k <= 1024.
+ * Equal scores are visited lower prior index first (a stable descending sort); numpy's default argsort does not define
+ * the order of ties, so for exactly tied scores a given numpy build may visit (and keep) a different member of the tie. */
+int avcer_face_nms(avcer_ctx* ctx, const float* dets, int n_frames, int n_priors, float conf_thresh, float nms_thresh,
+                   int nms_top_k, int top_k, float threshold, float* out, int32_t* out_n, avcer_stream_t stream);
+
 /* Face stage ("next" row f4): the arithmetic either side of the RetinaFace network.
  *   avcer_face_decode  ref: data/face_detection/ibug/face_detection/retina_face/retina_face_predictor.py:70-82,
  *                            box_utils.py:210-249 (decode, decode_landm), scaled to pixels

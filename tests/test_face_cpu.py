@@ -50,7 +50,7 @@ def test_oracle_detections_empty():
     assert got.shape == (0, 15) == G["pred_empty"].shape
 
 
-@pytest.mark.parametrize("fn", [of.nms, ft.nms])
+@pytest.mark.parametrize("fn", [of.nms])  # the product path runs NMS on the GPU: tests/test_gpu_face.py
 def test_nms(fn):
     assert list(fn(G["nms_dets"], 0.4, 5000)) == list(G["nms_keep_04"])
     assert list(fn(G["nms_dets"], 0.2, 50)) == list(G["nms_keep_02_top50"])
