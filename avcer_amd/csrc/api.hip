@@ -140,10 +140,11 @@ int ensure_all_bf16(avcer_ctx* ctx, Model& m, hipStream_t st) {
     return AVCER_OK;
 }
 
-// split-bf16 copies (k_split_weights) of every GEMM weight whose K is a multiple of 32, made on the first x3 call
+// split-bf16 copies (k_split_weight_rows: hi/lo per 32-element K group, rows permuted inside every group of 32 output
+// channels) of every GEMM weight whose K is a multiple of 32, made on the first x3 call
 int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
     auto wanted = [](const std::string& k, const Tensor& t) {
-        const bool is_w = k.size() > 3 && (k.compare(k.size() - 2, 2, ".w") == 0 || k.compare(k.size() - 3, 3, ".wp") == 0);
+        const bool is_w = k.size() > 3 && (k.compare(k.size() - 2, 2, ".w") == 0 || k.compare(k.size() - 3, 3, ".wf") == 0);
         return !t.x3 && is_w && t.ndim == 2 && t.dims[1] % 32 == 0 && t.dims[0] % 64 == 0;
     };
     size_t total = 0;
@@ -160,7 +161,8 @@ int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
     for (auto& kv : m.t)
         if (wanted(kv.first, kv.second)) {
             kv.second.x3 = (bf16_t*)((char*)dev + off);
-            TRY(k_split_weights(ctx, kv.second.f32, kv.second.x3, kv.second.numel, st));
+            // grouped weights ([groups*n][k], pos-conv) are stacked row blocks of multiples of 32 rows: same permutation
+            TRY(k_split_weight_rows(ctx, kv.second.f32, kv.second.x3, (int)kv.second.dims[0], (int)kv.second.dims[1], st));
             off += (kv.second.numel * 4 + 255) & ~(size_t)255;
         }
     return AVCER_OK;
@@ -403,7 +405,7 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
                              X, nullptr, T1, act, act);
                 const bool next = b + 1 < blocks;
                 const std::string pn = "l" + std::to_string(li + 1) + "." + std::to_string(b + 1) + ".";
-                const Tensor *w2 = net.T(p + "c2.wp"), *w3 = net.T(p + "c3.wp"), *w1n = next ? net.T(pn + "c1.wp") : nullptr;
+                const Tensor *w2 = net.T(p + "c2.wf"), *w3 = net.T(p + "c3.wf"), *w1n = next ? net.T(pn + "c1.wf") : nullptr;
                 if (net.err != AVCER_OK) return;
                 if (!w2->x3 || !w3->x3 || (next && !w1n->x3)) {
                     net.err = set_err(ctx, AVCER_ESTATE, "%s: split chain weights not prepared", p.c_str());
@@ -1028,6 +1030,13 @@ extern "C" int avcer_split_weights(avcer_ctx* ctx, const float* w, void* out, si
     if (!w || !out || numel % 32) return set_err(ctx, AVCER_EINVAL, "split_weights: numel must be a multiple of 32");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return k_split_weights(ctx, w, (bf16_t*)out, numel, (hipStream_t)stream);
+}
+
+extern "C" int avcer_split_weight_rows(avcer_ctx* ctx, const float* w, void* out, int n, int k, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (!w || !out || n <= 0 || k <= 0) return set_err(ctx, AVCER_EINVAL, "split_weight_rows: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return k_split_weight_rows(ctx, w, (bf16_t*)out, n, k, (hipStream_t)stream);
 }
 
 extern "C" int avcer_gemm_stats(avcer_ctx* ctx, int64_t* launches, double* flops, int reset) {

@@ -61,7 +61,7 @@ struct StemParams {
     const char* P;         // bf16 hi plane [n][230][230][4]; the lo plane starts plane_bytes later
     unsigned p_bytes;      // extent of both planes (hardware bounds check)
     unsigned plane_bytes;
-    const char* W;         // split weights [64][7 tap rows x 32] (sp32 groups of 32 K-elements)
+    const char* W;         // split weights [64][7 tap rows x 32] (sp32 groups of 32 K-elements, rows permuted)
     const float* scale;
     const float* bias;
     char* Y;               // sp32 [n][55][55][64]
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
     // BN + ReLU, parked as an f32 [256 positions][64 channels] image (64 KiB of the 80 KiB tile buffers)
 #pragma unroll
     for (int fn = 0; fn < 4; ++fn) {
-        const int ch = fn * 16 + 4 * g;
+        const int ch = 32 * (fn >> 1) + 8 * g + 4 * (fn & 1);  // weight rows are stored permuted (split_weight_rows_kernel)
         const float4 sc = *reinterpret_cast<const float4*>(p.scale + ch), bi = *reinterpret_cast<const float4*>(p.bias + ch);
 #pragma unroll
         for (int fm = 0; fm < 4; ++fm) {

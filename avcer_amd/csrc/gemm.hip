@@ -227,6 +227,45 @@ __device__ __forceinline__ void drain_stage(const GemmParams& p, const char* sme
     }
 }
 
+// ---- direct epilogue of the split-bf16 modes (MODE 2 / 3).  Their weight rows are stored permuted inside every group of
+// 32 output channels (kernels.hip split_weight_rows_kernel: stored row 16t + 4g + r = channel 8g + 4t + r), so the two
+// 16-row accumulator tiles of a group leave lane group g = lane >> 4 with the 8 CONSECUTIVE channels 8g..8g+7 of one
+// position: 16 contiguous bytes of an sp32 / bf16 row or 32 of an f32 row.  No LDS staging, no second barrier: residual
+// words are requested at kernel start in exactly this layout and the stores cover whole 64-byte half-lines.
+template <int OUT, int NFN, int NFM>
+__device__ __forceinline__ void res_prefetch_direct(const GemmParams& p, int m0, int c0, int lane, uint4 (&rr)[NFN / 2][NFM][2]) {
+#pragma unroll
+    for (int j = 0; j < NFN / 2; ++j)
+#pragma unroll
+        for (int fm = 0; fm < NFM; ++fm) {
+            rr[j][fm][0] = make_uint4(0u, 0u, 0u, 0u);
+            rr[j][fm][1] = make_uint4(0u, 0u, 0u, 0u);
+            const long m = (long)m0 + fm * 16 + (lane & 15);
+            if (p.R && m < p.M) res_load<OUT>(p, m, c0 + 32 * j + 8 * (lane >> 4), rr[j][fm][0], rr[j][fm][1]);
+        }
+}
+
+template <int OUT, int ACT, int NFN, int NFM>
+__device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4_t (&acc)[NFN][NFM], int m0, int c0, int lane,
+                                                const uint4 (&rr)[NFN / 2][NFM][2]) {
+#pragma unroll
+    for (int j = 0; j < NFN / 2; ++j) {
+        const int ch = c0 + 32 * j + 8 * (lane >> 4);  // first of this lane's 8 channels (index into scale / bias too)
+        float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+        if (p.scale) { s0 = *reinterpret_cast<const float4*>(p.scale + ch); s1 = *reinterpret_cast<const float4*>(p.scale + ch + 4); }
+        if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + ch); b1 = *reinterpret_cast<const float4*>(p.bias + ch + 4); }
+#pragma unroll
+        for (int fm = 0; fm < NFM; ++fm) {
+            const long m = (long)m0 + fm * 16 + (lane & 15);
+            if (m >= p.M) continue;
+            const f32x4_t lo = acc[2 * j][fm], hi = acc[2 * j + 1][fm];
+            finish8<OUT, ACT>(p, m, ch, make_float4(lo[0] * s0.x + b0.x, lo[1] * s0.y + b0.y, lo[2] * s0.z + b0.z, lo[3] * s0.w + b0.w),
+                              make_float4(hi[0] * s1.x + b1.x, hi[1] * s1.y + b1.y, hi[2] * s1.z + b1.z, hi[3] * s1.w + b1.w),
+                              rr[j][fm][0], rr[j][fm][1]);
+        }
+    }
+}
+
 // bf16 <-> f32 split used by MODE 2: x = hi + lo + O(2^-17 |x|) with hi, lo bf16 (round to nearest even)
 __device__ __forceinline__ void split8(const float4 x, const float4 y, bf16x8_t& hi, bf16x8_t& lo) {
     const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
@@ -471,12 +510,17 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
     int cur = 0;
 
     // residual tile of this thread's epilogue rows: requested now, consumed after the last MFMA
-    using D = DrainMap<BMT, BN>;
-    uint4 rres[D::NP][2];
-    res_prefetch<OUT, BMT, BN>(p, m_base, n_base, tid, rres);
-
+    constexpr bool DIRECT = MODE >= 2;  // split-bf16 modes: permuted weight rows, epilogue straight from the accumulators
     constexpr int NFN = IS_F32 ? WN / 32 : WN / 16;
     constexpr int NFM = IS_F32 ? WM / 32 : WM / 16;
+    using D = DrainMap<BMT, BN>;
+    uint4 rres[DIRECT ? 1 : D::NP][2];
+    uint4 rdir[DIRECT ? NFN / 2 : 1][DIRECT ? NFM : 1][2];
+    // channel index of this wave's first output column: n_base counts rows of W / entries of scale and bias, the
+    // epilogue helpers add p.yoff / p.roff themselves
+    if constexpr (DIRECT) res_prefetch_direct<OUT, NFN, NFM>(p, m_base + wm * WM, n_base + wn * WN, lane, rdir);
+    else res_prefetch<OUT, BMT, BN>(p, m_base, n_base, tid, rres);
+
     static_assert(MODE < 2 || OUT != 1, "split-bf16 modes write f32 or sp32");
     using acc_t = typename std::conditional<IS_F32, f32x16_t, f32x4_t>::type;
     acc_t acc[NFN][NFM];
@@ -497,12 +541,18 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
 #undef AVCER_ISSUE_TILES
 #undef AVCER_DMA_SETUP
 
-    // epilogue through LDS (the tile buffers are free: the loop ended on a barrier)
-    stage_acc<MODE, BN>(p, smem, acc, n_base, wm * WM, wn, lane);
-    __syncthreads();
-    if (p.act == 2) drain_stage<OUT, BMT, BN, 2>(p, smem, m_base, n_base, tid, rres);
-    else if (p.act == 1) drain_stage<OUT, BMT, BN, 1>(p, smem, m_base, n_base, tid, rres);
-    else drain_stage<OUT, BMT, BN, 0>(p, smem, m_base, n_base, tid, rres);
+    if constexpr (DIRECT) {
+        if (p.act == 2) epilogue_direct<OUT, 2, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir);
+        else if (p.act == 1) epilogue_direct<OUT, 1, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir);
+        else epilogue_direct<OUT, 0, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir);
+    } else {
+        // epilogue through LDS (the tile buffers are free: the loop ended on a barrier)
+        stage_acc<MODE, BN>(p, smem, acc, n_base, wm * WM, wn, lane);
+        __syncthreads();
+        if (p.act == 2) drain_stage<OUT, BMT, BN, 2>(p, smem, m_base, n_base, tid, rres);
+        else if (p.act == 1) drain_stage<OUT, BMT, BN, 1>(p, smem, m_base, n_base, tid, rres);
+        else drain_stage<OUT, BMT, BN, 0>(p, smem, m_base, n_base, tid, rres);
+    }
 }
 
 template <int MODE, int OUT>

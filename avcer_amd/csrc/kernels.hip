@@ -1028,6 +1028,24 @@ __global__ void split_weights_kernel(const float* __restrict__ w, bf16_t* __rest
     out[g * 64 + 32 + j] = f2bf(v - bf2f(h));
 }
 
+// The same split for WEIGHT matrices [n][k] of the split-bf16 contractions, with the rows of every group of 32 output
+// channels re-ordered: stored row 16t + 4g + r holds channel 8g + 4t + r (t = 0,1; g = 0..3; r = 0..3).  With weights as
+// the MFMA A operand a lane's accumulators are 4 consecutive ROWS of a 16-row tile, so this order leaves lane group g of
+// two adjacent tiles with the 8 consecutive channels 8g..8g+7: a 16-byte piece of the output row (direct whole-line
+// stores, no LDS staging) and, in fused.hip, the B fragment of the next contraction in natural K order.
+__global__ void split_weight_rows_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int n, int k) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * k) return;
+    const int row = i / k, col = i - (size_t)row * k;      // destination row / K index
+    const int j = row & 31, t = j >> 4, g = (j >> 2) & 3, r = j & 3;
+    const int src = (row & ~31) + 8 * g + 4 * t + r;
+    const float v = w[(size_t)src * k + col];
+    const bf16_t h = f2bf(v);
+    const size_t o = (size_t)row * k * 2 + (size_t)(col >> 5) * 64 + (col & 31);
+    out[o] = h;
+    out[o + 32] = f2bf(v - bf2f(h));
+}
+
 __global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = f2bf(x[i]);
@@ -1442,6 +1460,13 @@ int k_audio_chunks(avcer_ctx* ctx, const float* wav, const int32_t* starts, cons
                    int mode, float* out, hipStream_t st) {
     audio_chunks_kernel<<<n, 512, 0, st>>>(wav, starts, ends, window, mode, out);
     CHECK_LAUNCH(ctx, "audio_chunks");
+    return AVCER_OK;
+}
+
+int k_split_weight_rows(avcer_ctx* ctx, const float* w, bf16_t* out, int n, int k, hipStream_t st) {
+    if (n % 32 || k % 32) return set_err(ctx, AVCER_EINVAL, "split_weight_rows: n=%d and k=%d must be multiples of 32", n, k);
+    split_weight_rows_kernel<<<cdiv((long)n * k, 256), 256, 0, st>>>(w, out, n, k);
+    CHECK_LAUNCH(ctx, "split_weight_rows");
     return AVCER_OK;
 }
 

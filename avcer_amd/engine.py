@@ -273,6 +273,16 @@ class Engine:
         self._check(self.lib.avcer_split_weights(self.ctx, _ptr(w), _ptr(out), w.numel(), self._stream()))
         return out
 
+    def split_weight_rows(self, w):
+        """f32 [N,K] weight matrix -> the split-bf16, row-permuted layout of conv_gemm dtypes 3-6 and the fused kernels
+        (int16 tensor of 2*N*K entries)."""
+        w = self._dev(w, torch.float32)
+        if w.dim() != 2:
+            raise ValueError("split_weight_rows: w [N,K]")
+        out = torch.empty(w.numel() * 2, dtype=torch.int16, device=self.device)
+        self._check(self.lib.avcer_split_weight_rows(self.ctx, _ptr(w), _ptr(out), int(w.shape[0]), int(w.shape[1]), self._stream()))
+        return out
+
     def conv_gemm_dual(self, desc: ConvDesc, dtype: int, x, x2, w, scale, bias, residual, y):
         self._check(self.lib.avcer_conv_gemm_dual(self.ctx, C.byref(desc), dtype, _ptr(x), _ptr(x2), _ptr(w), _ptr(scale),
                                                   _ptr(bias), _ptr(residual), _ptr(y), self._stream()))

@@ -81,14 +81,15 @@ def pack_static(sd) -> "OrderedDict[str, np.ndarray]":
             for b in range(1, blocks):
                 for i in (2, 3) if b < 2 else (1, 2, 3):  # BN scale folded into the rows: the chain's epilogues only add the shift
                     k = f"l{li}.{b}.c{i}"
-                    out[k + ".wp"] = permute_rows_for_chain(out[k + ".w"] * out[k + ".s"][:, None])
+                    out[k + ".wf"] = np.ascontiguousarray(out[k + ".w"] * out[k + ".s"][:, None])
     out["fc1.w"], out["fc1.b"] = _f32(sd["fc1.weight"]), _f32(sd["fc1.bias"])
     out["fc2.w"], out["fc2.b"] = _f32(sd["fc2.weight"]), _f32(sd["fc2.bias"])
     return out
 
 
-def permute_rows_for_chain(w: np.ndarray) -> np.ndarray:
-    """Row order of the weights the fused bottleneck kernel (csrc/fused.hip) streams: inside every group of 32 output
+def permute_rows_for_mfma(w: np.ndarray) -> np.ndarray:
+    """Row order of every split-bf16 weight matrix on the device (the library applies it when it builds the split copies,
+    csrc/kernels.hip split_weight_rows_kernel; this numpy twin exists for tests): inside every group of 32 output
     channels, stored row 16t + 4g + r holds channel 8g + 4t + r (t = 0,1; g = 0..3; r = 0..3), so that the two
     16-row MFMA tiles of a group leave every lane group g with the 8 consecutive channels 8g..8g+7."""
     n = w.shape[0]

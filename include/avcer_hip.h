@@ -171,7 +171,7 @@ int avcer_fuse(avcer_ctx* ctx, const float* stat, const float* dyn_logits, const
 /* The contraction kernel itself (implicit-GEMM convolution with fused epilogue), exported for kernel-level
  * parity tests and micro-benchmarks:  Y[m, n] = act(scale[n] * sum_k A[m,k] * W[n,k] + bias[n] (+ R[m,n]))
  * where A is gathered from an NHWC tensor.  See avcer_conv_desc. dtype: 0 = f32 in/out, 1 = bf16 in/out,
- * 2 = bf16 in / f32 out; split-bf16 arithmetic with w pre-split by avcer_split_weights: 3 = f32 in / f32 out,
+ * 2 = bf16 in / f32 out; split-bf16 arithmetic with w pre-split by avcer_split_weight_rows: 3 = f32 in / f32 out,
  * 4 = f32 in / sp32 out, 5 = sp32 in / sp32 out (+ sp32 residual), 6 = sp32 in / f32 out (+ f32 residual).
  * "sp32" storage = per aligned group of 32 channels, 32 bf16 hi values then 32 bf16 lo values (x = hi + lo), i.e. the
  * layout avcer_split_weights produces; 4 bytes per element. */
@@ -211,9 +211,8 @@ int avcer_conv_gemm_dual(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, co
  *     T2 = relu(conv3x3(T1) + b2);  OUT = relu(conv1x1(T2) + b3 + X);  T1N = relu(conv1x1(OUT) + b1n)
  *   ref: architectures/video.py:43-60 (Bottleneck.forward; stride 1, no downsample), BatchNorm folded.
  *   t1 sp32 [nb,h,w,planes], x / out sp32 [nb,h,w,4*planes], t1n sp32 [nb,h,w,planes] or NULL (then w1n, b1n NULL);
- *   w2 [planes][9*planes], w3 [4*planes][planes], w1n [planes][4*planes]: BN scale folded into the rows, rows permuted
- *   inside every group of 32 (stored row 16t+4g+r = channel 8g+4t+r; avcer_amd/packing.py permute_rows_for_chain), then
- *   split by avcer_split_weights; b2 / b3 / b1n f32 BN shifts in natural channel order.  planes = 64 or 128.
+ *   w2 [planes][9*planes], w3 [4*planes][planes], w1n [planes][4*planes]: BN scale folded into the rows, then split
+ *   by avcer_split_weight_rows; b2 / b3 / b1n f32 BN shifts in natural channel order.  planes = 64 or 128.
  *
  * avcer_stem_pool: conv 7x7/2 (TF-"same" padding) + BN + ReLU + max-pool 3x3/2 in one launch,
  *   ref: architectures/video.py:63-90,98-103,116-117.  planes_hi_lo: two bf16 planes [n,230,230,4] (hi, then lo plane_bytes
@@ -228,6 +227,13 @@ int avcer_stem_pool(avcer_ctx* ctx, const void* planes_hi_lo, size_t plane_bytes
 /* Weight layout of dtype 3: for every group of 32 K-elements, 32 bf16 "hi" values then 32 bf16 "lo" values with
  * w = hi + lo (+ O(2^-17 |w|)).  w f32 [n*k] (k a multiple of 32) -> out, same size in bytes. Both device pointers. */
 int avcer_split_weights(avcer_ctx* ctx, const float* w, void* out, size_t numel, avcer_stream_t stream);
+
+/* The split of a WEIGHT matrix w f32 [n][k] (n, k multiples of 32) as the split-bf16 contractions (dtype 3-6 of
+ * avcer_conv_gemm, avcer_bneck_chain, avcer_stem_pool) expect it: the layout above along K, and the rows of every group of
+ * 32 output channels re-ordered so that stored row 16t + 4g + r holds channel 8g + 4t + r (t = 0,1; g = 0..3; r = 0..3).
+ * With weights as the MFMA A operand this leaves each lane with 8 consecutive output channels, i.e. 16-byte pieces of
+ * the output row (direct whole-line stores).  scale / bias / residual / output stay in natural channel order. */
+int avcer_split_weight_rows(avcer_ctx* ctx, const float* w, void* out, int n, int k, avcer_stream_t stream);
 
 /* Last launch statistics of the dominant kernel (for bench.py's roofline object): number of conv_gemm
  * launches and their summed algorithmic FLOPs since the previous call to this function. */

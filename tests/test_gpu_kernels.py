@@ -63,7 +63,8 @@ def _run(engine, d, dtype, x, w, scale, bias, res, y):
     ak, ok = A_KIND[dtype], O_KIND[dtype]
     xd = _enc(x, ak, dev)
     wd = w.to(dev, torch.bfloat16 if ak == "bf16" else torch.float32).contiguous()
-    w_arg = engine.split_weights(wd) if dtype >= 3 else wd  # split-bf16 arithmetic: bf16 hi/lo split of the f32 weights
+    # split-bf16 arithmetic: bf16 hi/lo split of the f32 weights, rows permuted inside groups of 32 output channels
+    w_arg = engine.split_weight_rows(wd.reshape(wd.shape[0], -1)) if dtype >= 3 else wd
     sd_ = None if scale is None else scale.to(dev, torch.float32)
     bd = None if bias is None else bias.to(dev, torch.float32)
     rd = None if res is None else _enc(res, ok, dev)
@@ -244,7 +245,7 @@ def test_dual_source_fused_1x1(engine, dtype):
     ak, ok = A_KIND[dtype], O_KIND[dtype]
     xd, td = _enc(x, ak, dev), _enc(t2, ak, dev)
     wdv = w.to(dev, torch.bfloat16 if ak == "bf16" else torch.float32).contiguous()
-    w_arg = engine.split_weights(wdv) if dtype >= 3 else wdv
+    w_arg = engine.split_weight_rows(wdv) if dtype >= 3 else wdv
     yd = _enc(torch.zeros(b, oh, oh, n), ok, dev)
     engine.conv_gemm_dual(d, dtype, td, xd, w_arg, None, bias.to(dev), None, yd)
     torch.cuda.synchronize()
@@ -259,8 +260,6 @@ def test_dual_source_fused_1x1(engine, dtype):
 def test_bneck_chain_vs_float64(engine, planes, nb, hw, nxt):
     """conv3x3+ReLU -> conv1x1 + residual + ReLU -> next conv1x1 + ReLU in one launch against float64 torch convolutions
     (video.py:43-60 with folded BatchNorm).  M = nb*hw*hw is never a multiple of the 128-position tile here."""
-    from avcer_amd.packing import permute_rows_for_chain
-
     g = torch.Generator().manual_seed(planes + hw)
     p4 = 4 * planes
     t1 = torch.rand(nb, hw, hw, planes, generator=g) * 2          # post-ReLU activations
@@ -276,7 +275,7 @@ def test_bneck_chain_vs_float64(engine, planes, nb, hw, nxt):
     dev = engine.device
 
     def wsplit(w):
-        return engine.split_weights(torch.from_numpy(permute_rows_for_chain(w.reshape(w.shape[0], -1).numpy())))
+        return engine.split_weight_rows(w.reshape(w.shape[0], -1))
 
     d_out = torch.full((nb, hw, hw, 2 * p4), 0x7fc0, dtype=torch.int16, device=dev)   # NaN-filled sp32
     d_t1n = torch.full((nb, hw, hw, 2 * planes), 0x7fc0, dtype=torch.int16, device=dev) if nxt else None
@@ -292,3 +291,14 @@ def test_bneck_chain_vs_float64(engine, planes, nb, hw, nxt):
         err1 = (got1 - t1n).abs().max().item()
         print(f"   max|t1n err| {err1:.2e} (max {t1n.abs().max().item():.1f})")
         assert err1 < 2e-5 * max(1.0, t1n.abs().max().item())
+
+
+def test_split_weight_rows_layout(engine):
+    """avcer_split_weight_rows: hi/lo per 32-element K group + the row order of packing.permute_rows_for_mfma."""
+    from avcer_amd.packing import permute_rows_for_mfma
+
+    w = torch.randn(96, 64, generator=torch.Generator().manual_seed(1))
+    got = from_sp32(engine.split_weight_rows(w).cpu().reshape(96, 128))
+    ref = torch.from_numpy(permute_rows_for_mfma(w.numpy()))
+    assert (got - ref).abs().max() < 2e-5 and (got - ref).abs().max() > 0      # hi + lo is not exactly f32
+    assert torch.equal(from_sp32(to_sp32(ref)), got)

@@ -90,14 +90,17 @@ def test_pack_static_layouts(sd_static):
     n_chain = (2 + 3) * 2 + (1 + 2)  # stages 1-2: c2.wp, c3.wp of blocks >= 1; c1.wp of blocks >= 2
     assert len(t) == 1 * 3 + 16 * 9 - 4 * 3 + 4 * 2 + 4 + 1 + n_chain
     np.testing.assert_array_equal(t["stem7.w"].reshape(64, 7, 8, 4), stem[:, :7])
-    # chain weights (csrc/fused.hip): stored row 16t + 4g + r of every 32-row group holds channel 8g + 4t + r
-    wp, w0 = t["l2.2.c3.wp"], t["l2.2.c3.w"] * t["l2.2.c3.s"][:, None]  # BN scale folded into the rows
+    # chain weights (csrc/fused.hip): the BN scale folded into the rows (the device applies the row permutation)
+    np.testing.assert_array_equal(t["l2.2.c3.wf"], t["l2.2.c3.w"] * t["l2.2.c3.s"][:, None])
+    assert "l1.1.c1.wf" not in t and "l1.2.c1.wf" in t and "l3.1.c2.wf" not in t
+    # numpy twin of the device-side row order: stored row 16t + 4g + r of every 32-row group holds channel 8g + 4t + r
+    w0 = t["l2.2.c3.w"]
+    wp = packing.permute_rows_for_mfma(w0)
     for q in (0, 5):
         for tt in range(2):
             for g in range(4):
                 for r in range(4):
                     np.testing.assert_array_equal(wp[32 * q + 16 * tt + 4 * g + r], w0[32 * q + 8 * g + 4 * tt + r])
-    assert "l1.1.c1.wp" not in t and "l1.2.c1.wp" in t and "l3.1.c2.wp" not in t
     w3 = sd_static["layer2.0.conv3.weight"].numpy()[:, :, 0, 0]
     assert t["l2.0.c3d.w"].shape == (512, 128 + 256)
     np.testing.assert_allclose(t["l2.0.c3d.w"][:, :128] / w3, np.broadcast_to((t["l2.0.c3d.w"][:, :1] / w3[:, :1]), w3.shape), rtol=1e-5)

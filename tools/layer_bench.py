@@ -103,7 +103,7 @@ def run(engine, layers, dtype, iters, title):
         g = L.get("groups", 1)
         w = (torch.randn(g * d.n * k, device=engine.device) / k ** 0.5).to(tin)
         if dtype >= 3:
-            w = engine.split_weights(w)
+            w = engine.split_weight_rows(w.reshape(g * d.n, k))
         if dtype in (4, 5) and d.y_ld % 32:
             continue
         ylen = m * max(d.y_ld, d.n) + 64
