@@ -26,6 +26,7 @@ class ConvDesc(C.Structure):
         ("act", C.c_int32), ("res_after_act", C.c_int32), ("groups", C.c_int32),
         ("x2_cin", C.c_int32), ("x2_coff", C.c_int32), ("x2_stride", C.c_int32),
         ("x2_stride_b", C.c_int64), ("x2_stride_h", C.c_int64), ("x2_stride_w", C.c_int64),
+        ("tile_n", C.c_int32),
     ]
 
 

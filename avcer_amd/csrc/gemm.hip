@@ -62,6 +62,7 @@ struct GemmParams {
     int groups;  // grid.y: group g shifts coff / yoff / roff by g*Cin / g*N and the weight/scale/bias rows by g*N
     int KH;
     int fast;  // pad-free gather with a scalar K / tap advance (see AVCER_ISSUE_TILES)
+    int tile_n;  // 0 = choose, 64, 128
 };
 
 // Epilogue, staged through LDS so that HBM sees whole 128-byte lines: every wave first parks its scaled/biased
@@ -555,11 +556,15 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
     }
 }
 
+// Tile width by shape.  K <= 128: bandwidth-bound 1x1 convolutions, the 48 KiB BN = 64 tile lets three blocks share a CU.
+inline bool choose_bn128(const GemmParams& p) { return p.K > 128; }
+
 template <int MODE, int OUT>
 void launch_t(const GemmParams& p0, hipStream_t st) {
     GemmParams p = p0;
-    // K <= 128: bandwidth-bound 1x1 convolutions; the 48 KiB BN=64 tile lets three blocks share a CU
-    const bool bn128 = p.N % 128 == 0 && p.K > 128;
+    bool bn128 = p.N % 128 == 0 && choose_bn128(p);
+    if (p.tile_n == 64) bn128 = false;
+    if (p.tile_n == 128 && p.N % 128 == 0) bn128 = true;
     p.ntm = (p.M + 127) / 128;
     p.gm = 8;  // grouped block order: 8 m-tiles x all n-tiles per group (0/4/8/16 measured within +-3 %)
     p.ntn = p.N / (bn128 ? 128 : 64);
@@ -643,6 +648,8 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
         p.sB2 = d.x2_stride_b; p.sH2 = d.x2_stride_h; p.sW2 = d.x2_stride_w; p.coff2 = d.x2_coff; p.st2 = d.x2_stride;
     }
     p.ntn = 0; p.nwg = 0; p.groups = groups;
+    if (d.tile_n != 0 && d.tile_n != 64 && d.tile_n != 128) return set_err(ctx, AVCER_EINVAL, "conv_gemm: tile_n %d (0, 64 or 128)", d.tile_n);
+    p.tile_n = d.tile_n;
     // Fast gather: Cin a multiple of the K-step, no padding, and the last tap of the last output position inside the
     // input -- true for every Linear, 1x1 convolution and un-padded Conv1d of both models.
     p.fast = d.cin % bk == 0 && d.pad_h == 0 && d.pad_w == 0 &&

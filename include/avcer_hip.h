@@ -195,6 +195,8 @@ typedef struct avcer_conv_desc {
      * K elements [kh*kw*cin, kh*kw*cin + x2_cin) of every row come from x2 at position (oy*x2_stride, ox*x2_stride). */
     int32_t x2_cin, x2_coff, x2_stride;
     int64_t x2_stride_b, x2_stride_h, x2_stride_w;
+    int32_t tile_n;                  /* output-channel width of the block tile: 0 = chosen by the library, 64 or 128 (128 needs
+                                        n % 128 == 0).  A tuning knob: results do not depend on it. */
 } avcer_conv_desc;
 
 int avcer_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, const void* x, const void* w,

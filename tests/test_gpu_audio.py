@@ -49,8 +49,8 @@ def test_expr_model_stage_taps_fp32(engine_audio, sd_audio):
     dl = (out.cpu() - ref_logits).abs().max().item()
     print("audio fp32 max|dlogit|", dl)
     for name, err, mx in report:
-        assert err < 5e-4 * max(mx, 1.0), report
-    assert dl < 2e-3
+        assert err < 5e-5 * max(mx, 1.0), report  # measured <= 6e-6 relative
+    assert dl < 1e-4  # measured 1.0e-5
 
 
 @pytest.mark.parametrize("tag,seed,b,t", [("t32000", 5678, 2, 32000), ("t64000", 5679, 1, 64000)])
@@ -110,7 +110,8 @@ def test_chunked_video_audio_matches_oracle_including_nan_tail(engine_audio, sd_
             assert frames[-1] == 25 and np.isnan(ref_rows[-1]).all() and np.isnan(rows[-1]).all()
         ok = ~np.isnan(ref_rows).any(axis=1)
         assert np.array_equal(ok, ~np.isnan(rows).any(axis=1))
-        assert np.abs(rows[ok] - ref_rows[ok]).max() < 2e-3
+        print("chunked audio max|dlogit|", np.abs(rows[ok] - ref_rows[ok]).max())
+        assert np.abs(rows[ok] - ref_rows[ok]).max() < 2e-4  # measured 2.2e-5
 
 
 def test_audio_batch_invariance_128(engine_audio):
@@ -131,11 +132,12 @@ def test_seven_class_variant(engine, golden):
     assert eng.audio_classes == 7
     wav = torch.from_numpy(synth.waveforms(777, 2, 32000))
     ref = golden("audio_model7")["logits"]
-    for mode, tol in ((MODE_FP32, 2e-3), (MODE_BF16X3, 2e-3)):
+    for mode, tol in ((MODE_FP32, 1e-4), (MODE_BF16X3, 8e-4)):  # measured 9e-6 / 7.7e-5
         out = eng.audio_forward(wav, normalize=True, mode=mode).cpu().numpy()
         assert out.shape == (2, 7)
         p_got = torch.softmax(torch.from_numpy(out), 1).numpy()
         p_ref = torch.softmax(torch.from_numpy(ref), 1).numpy()
+        print("7-class mode", mode, "max|dlogit|", np.abs(out - ref).max(), "max|dprob|", np.abs(p_got - p_ref).max())
         assert np.abs(out - ref).max() < tol and np.abs(p_got - p_ref).max() < 1e-4
     eng.close()
 

@@ -131,4 +131,5 @@ def test_track_feeds_visual_path(engine_static, sd_static, sd_dynamic):
     ref_frames[G["track_records"][rows, 0]] = G["track_tiles"][rows]
     rs, rd = ov.visual_forward(sd_static, sd_dynamic, ref_frames, present, 25, batched=True)
     np.testing.assert_allclose(stat.cpu().numpy(), rs, rtol=0, atol=1e-4)
-    np.testing.assert_allclose(dyn.cpu().numpy(), rd, rtol=0, atol=2e-3)
+    print("track -> visual path: max|dprob|", np.abs(stat.cpu().numpy() - rs).max(), "max|d dynamic logit|", np.abs(dyn.cpu().numpy() - rd).max())
+    np.testing.assert_allclose(dyn.cpu().numpy(), rd, rtol=0, atol=1e-5)  # measured 6.6e-7

@@ -78,7 +78,8 @@ def test_full_av_clips_match_oracle(engine, sd_static, sd_dynamic, sd_audio):
         rows, fr = oa.replicate_per_frame(lg, [(0, 32000, 0, t)])
         prob, am = of.fuse(st.astype(np.float32), dy.astype(np.float32), rows, fr)
         assert np.abs(out["static_probs"][c].cpu().numpy() - st).max() < 1e-4
-        assert np.abs(out["dynamic_logits"][c].cpu().numpy() - dy).max() < 1e-3
+        print("clip", c, "max|d dynamic logit|", np.abs(out["dynamic_logits"][c].cpu().numpy() - dy).max())
+        assert np.abs(out["dynamic_logits"][c].cpu().numpy() - dy).max() < 1e-5  # measured 1.1e-6
         assert np.abs(out["compound_prob"][:, c].cpu().numpy() - prob).max() < 1e-4
         got_am = out["compound_argmax"][:, c].cpu().numpy()
         if not np.array_equal(got_am, am):

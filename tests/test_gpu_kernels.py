@@ -14,7 +14,7 @@ def _desc(**kw):
     base = dict(batch=1, in_h=1, in_w=1, out_h=1, out_w=1, cin=32, kh=1, kw=1, stride_h=1, stride_w=1, pad_h=0, pad_w=0,
                 dil_h=1, dil_w=1, x_stride_b=0, x_stride_h=0, x_stride_w=0, x_coff=0, n=64, y_ld=64, y_coff=0, r_ld=64,
                 r_coff=0, act=0, res_after_act=0, groups=0, x2_cin=0, x2_coff=0, x2_stride=0, x2_stride_b=0, x2_stride_h=0,
-                x2_stride_w=0)
+                x2_stride_w=0, tile_n=0)
     base.update(kw)
     for k, v in base.items():
         setattr(d, k, int(v))

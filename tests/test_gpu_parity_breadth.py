@@ -1,0 +1,66 @@
+"""Parity margin of the two parity-grade arithmetic modes over several synthetic weight draws and logit scales.
+
+Real checkpoints are not available offline, so the 1e-4 probability gate is exercised on 5 weight seeds x logit scale
+{1, 4} (the last Linear of every model scaled by 4: sharper softmax, the probabilities four times more sensitive to a
+logit error) at 8 frames + 2 audio windows, in the f32 mode and in the split-bf16 (x3) headline mode.  The worst
+|dprob| per mode is printed; both must stay under the gate with the compound argmax identical."""
+import numpy as np
+import pytest
+import torch
+
+from avcer_amd import synth
+from avcer_amd.engine import MODE_BF16X3, MODE_FP32, Engine
+from oracle import audio as oa
+from oracle import fusion as of
+from oracle import video as ov
+
+pytestmark = pytest.mark.gpu
+
+SEEDS = (42, 43, 44, 45, 46)
+SCALES = (1.0, 4.0)
+
+
+def _scaled(sd, keys, s):
+    sd = dict(sd)
+    for k in keys:
+        sd[k] = sd[k] * s
+    return sd
+
+
+def test_probability_gate_over_seeds_and_logit_scales():
+    eng = Engine(0)
+    frames = synth.face_frames(2468, 8)
+    wav = synth.waveforms(1357, 2, 32000)
+    worst = {"fp32": 0.0, "x3": 0.0}
+    rows = []
+    for seed in SEEDS:
+        base = (synth.static_state_dict(seed), synth.dynamic_state_dict(seed), synth.audio_state_dict(seed))
+        for scale in SCALES:
+            sds = (_scaled(base[0], ("fc2.weight", "fc2.bias"), scale), _scaled(base[1], ("fc.weight", "fc.bias"), scale),
+                   _scaled(base[2], ("feature_downsample.weight", "feature_downsample.bias"), scale))
+            eng.load_static(sds[0]); eng.load_dynamic(sds[1]); eng.load_audio(sds[2])
+            tsd = [synth.to_torch(s) for s in sds]
+            with torch.no_grad():
+                ref_logits, _ = ov.resnet50_forward(tsd[0], ov.pth_processing(frames))
+                ref_p = torch.softmax(ref_logits, 1).numpy()
+                ref_a = oa.expr_model_v3_forward(tsd[2], torch.from_numpy(oa.normalize(wav))).numpy()
+            for name, mode in (("fp32", MODE_FP32), ("x3", MODE_BF16X3)):
+                _, probs, feats = eng.static_forward(torch.from_numpy(frames), mode)
+                d_s = float(np.abs(probs.cpu().numpy() - ref_p).max())
+                # LSTM on the GPU's own features of the 8 frames (window = first frame x10 sliding), against the oracle LSTM
+                win = torch.relu(feats.cpu())[[0] * 9 + [0], :][None].repeat(2, 1, 1)
+                win[1] = torch.relu(feats.cpu())[[0, 0, 0, 1, 2, 3, 4, 5, 6, 7]]
+                with torch.no_grad():
+                    ref_d = torch.softmax(ov.lstm_forward(tsd[1], win), 1).numpy()
+                got_d = torch.softmax(eng.dynamic_forward(win, mode).cpu(), 1).numpy()
+                d_d = float(np.abs(got_d - ref_d).max())
+                got_a = eng.audio_forward(torch.from_numpy(wav), True, mode).cpu().numpy()
+                d_a = float(np.abs(of.softmax(got_a[:, :7]) - of.softmax(ref_a[:, :7])).max())
+                assert (probs.cpu().numpy().argmax(1) == ref_p.argmax(1)).all() or d_s < 1e-6, (seed, scale, name)
+                worst[name] = max(worst[name], d_s, d_d, d_a)
+                rows.append((seed, scale, name, d_s, d_d, d_a))
+    for r in rows:
+        print("seed %d scale %.0f %-4s  static %.2e  dynamic %.2e  audio %.2e" % r)
+    print("worst |dprob| over %d seeds x %d scales: fp32 %.3e, x3 %.3e" % (len(SEEDS), len(SCALES), worst["fp32"], worst["x3"]))
+    assert worst["fp32"] < 1e-4 and worst["x3"] < 1e-4
+    eng.close()

@@ -78,8 +78,8 @@ def test_static_matches_golden_and_oracle_fp32(engine_static, sd_static, golden)
     frames = synth.face_frames(1234, 8)
     logits, probs, feats = [t.cpu().numpy() for t in engine_static.static_forward(torch.from_numpy(frames), MODE_FP32)]
     assert np.abs(probs - g["probs"]).max() < PROB_TOL
-    assert np.abs(logits - g["logits"]).max() < 1e-3
-    assert np.abs(feats - g["feats"]).max() < 1e-3
+    assert np.abs(logits - g["logits"]).max() < 1e-4  # measured 9e-6
+    assert np.abs(feats - g["feats"]).max() < 1e-4
     assert (probs.argmax(1) == g["probs"].argmax(1)).all()
     print("static fp32 max|dprob|", np.abs(probs - g["probs"]).max(), "max|dlogit|", np.abs(logits - g["logits"]).max())
     # the preprocessed-tensor entry point (exact argument of pth_model_static) gives the same numbers
@@ -142,7 +142,7 @@ def test_lstm_matches_golden_and_oracle(engine_dynamic, sd_dynamic, golden):
         ref = ov.lstm_forward(sd_dynamic, torch.from_numpy(big)).numpy()
     out = engine_dynamic.dynamic_forward(torch.from_numpy(big)).cpu().numpy()
     print("lstm max|dlogit|", np.abs(out - ref).max())
-    assert np.abs(out - ref).max() < 5e-5
+    assert np.abs(out - ref).max() < 3e-6  # measured 2.7e-7
 
 
 def test_visual_harness_matches_reference_tables(engine_static, engine_dynamic, golden):
@@ -151,7 +151,8 @@ def test_visual_harness_matches_reference_tables(engine_static, engine_dynamic, 
     for name in ("gap25", "gap30", "lead25", "full25"):
         st, dy = video_pipeline.visual_forward(engine_static, clip, g[f"{name}_present"], float(g[f"{name}_fps"]))
         assert np.abs(st.cpu().numpy() - g[f"{name}_static"]).max() < PROB_TOL, name
-        assert np.abs(dy.cpu().numpy() - g[f"{name}_dynamic"]).max() < 5e-4, name
+        print("harness", name, "max|d dynamic logit|", np.abs(dy.cpu().numpy() - g[f"{name}_dynamic"]).max())
+        assert np.abs(dy.cpu().numpy() - g[f"{name}_dynamic"]).max() < 1e-5, name  # measured 9e-7
     # batched over clips == clip by clip
     clips = torch.stack([clip, torch.from_numpy(synth.face_frames(4322, 16))])
     present = np.stack([g["gap25_present"], g["lead25_present"]])
@@ -169,4 +170,4 @@ def test_lstm_split_bf16_mode(engine, sd_dynamic, golden):
     out = engine.dynamic_forward(torch.from_numpy(w), MODE_BF16X3).cpu().numpy()
     d = np.abs(out - golden("lstm")["logits"]).max()
     print("lstm x3 max|dlogit|", d)
-    assert d < 2e-4
+    assert d < 2e-5  # measured 1.8e-6

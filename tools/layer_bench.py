@@ -23,7 +23,7 @@ def desc(**kw):
     base = dict(batch=1, in_h=1, in_w=1, out_h=1, out_w=1, cin=32, kh=1, kw=1, stride_h=1, stride_w=1, pad_h=0, pad_w=0,
                 dil_h=1, dil_w=1, x_stride_b=0, x_stride_h=0, x_stride_w=0, x_coff=0, n=64, y_ld=64, y_coff=0, r_ld=64,
                 r_coff=0, act=0, res_after_act=0, groups=0, x2_cin=0, x2_coff=0, x2_stride=0, x2_stride_b=0, x2_stride_h=0,
-                x2_stride_w=0)
+                x2_stride_w=0, tile_n=0)
     base.update(kw)
     for k, v in base.items():
         setattr(d, k, int(v))
@@ -87,13 +87,14 @@ def audio_layers(nb, t):
     return L
 
 
-def run(engine, layers, dtype, iters, title):
+def run(engine, layers, dtype, iters, title, tile_n=0):
     tin = torch.bfloat16 if dtype in (1, 2) else torch.float32
     es = 2 if dtype in (1, 2) else 4
     tot_ms = tot_fl = 0.0
     print(f"--- {title}")
     for L in layers:
         d = L["d"]
+        d.tile_n = tile_n if (tile_n != 128 or d.n % 128 == 0) else 0
         ldt = dtype
         if dtype == 5 and (d.x_stride_w % 32 or d.cin % 32):
             ldt = 4  # stem: f32 image in, sp32 out
@@ -135,9 +136,12 @@ if __name__ == "__main__":
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--chunks", type=int, default=128)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--tile-n", type=int, default=0, help="force the block tile width (64 / 128) on every layer: a tuning sweep")
+    ap.add_argument("--no-audio", action="store_true")
     a = ap.parse_args()
     eng = Engine(0)
     for name, dt in (("f32", 0), ("bf16", 1), ("x3", 3), ("x3s", 5)):
         if a.dtype in ("both", name):
-            run(eng, static_layers(a.frames), dt, a.iters, f"static CNN, {a.frames} frames, {name}")
-            run(eng, audio_layers(a.chunks, 32000), dt, a.iters, f"audio model, {a.chunks} x 2 s, {name}")
+            run(eng, static_layers(a.frames), dt, a.iters, f"static CNN, {a.frames} frames, {name}, tile_n={a.tile_n}", a.tile_n)
+            if not a.no_audio:
+                run(eng, audio_layers(a.chunks, 32000), dt, a.iters, f"audio model, {a.chunks} x 2 s, {name}, tile_n={a.tile_n}", a.tile_n)
