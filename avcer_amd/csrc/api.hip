@@ -398,24 +398,33 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
             const std::string p = "l" + std::to_string(li + 1) + "." + std::to_string(b) + ".";
             const int oh = (h - 1) / stride + 1;
             void* dst = (b == blocks - 1 && last_out) ? last_out : OUT;
-            if (chain && b >= 1) {
-                // T1 of this block is in T1 (written by the standalone conv1 of block 1 or by the previous chain launch)
-                if (b == 1)
+            // li == 0: the first block too (stride 1, 64 input channels: the downsample operand rides in registers)
+            if (chain && (b >= 1 || li == 0)) {
+                const bool first = b == 0;
+                // T1 of this block: written by the previous chain launch, or by a standalone conv1 at the head of a chain
+                if (first || (b == 1 && li != 0))
                     net.gemm(conv2d_desc(nb, h, h, cin, 1, 1, 1, 0, planes, 1), p + "c1.w", net.F(p + "c1.s"), net.F(p + "c1.b"),
                              X, nullptr, T1, act, act);
                 const bool next = b + 1 < blocks;
                 const std::string pn = "l" + std::to_string(li + 1) + "." + std::to_string(b + 1) + ".";
-                const Tensor *w2 = net.T(p + "c2.wf"), *w3 = net.T(p + "c3.wf"), *w1n = next ? net.T(pn + "c1.wf") : nullptr;
+                const Tensor *w2 = net.T(p + "c2.wf"), *w3 = net.T(first ? p + "c3d.w" : p + "c3.wf"),
+                             *w1n = next ? net.T(pn + "c1.wf") : nullptr;
                 if (net.err != AVCER_OK) return;
                 if (!w2->x3 || !w3->x3 || (next && !w1n->x3)) {
                     net.err = set_err(ctx, AVCER_ESTATE, "%s: split chain weights not prepared", p.c_str());
                     return;
                 }
-                net.chk(launch_bneck(ctx, planes, nb, h, h, T1, X, dst, next ? T2 : nullptr, w2->x3, net.F(p + "c2.b"), w3->x3,
-                                     net.F(p + "c3.b"), next ? w1n->x3 : nullptr, next ? net.F(pn + "c1.b") : nullptr, st));
+                net.chk(launch_bneck(ctx, planes, nb, h, h, T1, X, first ? cin : 0, dst, next ? T2 : nullptr, w2->x3, net.F(p + "c2.b"),
+                                     w3->x3, net.F(first ? p + "c3d.b" : p + "c3.b"), next ? w1n->x3 : nullptr,
+                                     next ? net.F(pn + "c1.b") : nullptr, st));
                 std::swap(T1, T2);  // the next block's T1 was written into T2
                 if (dst == OUT) std::swap(X, OUT);
                 else X = dst;
+                cin = planes * 4;
+                if (first) {
+                    net.tap("l1b0_c1", T2, (size_t)nb * h * h * planes * es);  // after the swap T2 holds this block's conv1 output
+                    net.tap("l1b0", X, (size_t)nb * h * h * cin * es);
+                }
                 continue;
             }
             net.gemm(conv2d_desc(nb, h, h, cin, 1, 1, stride, 0, planes, 1), p + "c1.w", net.F(p + "c1.s"),
@@ -1008,13 +1017,13 @@ extern "C" int avcer_conv_gemm_dual(avcer_ctx* ctx, const avcer_conv_desc* d, in
     return launch_conv_gemm(ctx, *d, dtype, x, w, scale, bias, residual, y, (hipStream_t)stream, x2);
 }
 
-extern "C" int avcer_bneck_chain(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, void* out,
-                                 void* t1n, const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n,
+extern "C" int avcer_bneck_chain(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin,
+                                 void* out, void* t1n, const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n,
                                  const float* b1n, avcer_stream_t stream) {
     if (!ctx) return AVCER_EINVAL;
     if (nb <= 0 || h <= 0 || w <= 0) return set_err(ctx, AVCER_EINVAL, "bneck_chain: bad geometry");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return launch_bneck(ctx, planes, nb, h, w, t1, x, out, t1n, w2, b2, w3, b3, w1n, b1n, (hipStream_t)stream);
+    return launch_bneck(ctx, planes, nb, h, w, t1, x, ds_cin, out, t1n, w2, b2, w3, b3, w1n, b1n, (hipStream_t)stream);
 }
 
 extern "C" int avcer_stem_pool(avcer_ctx* ctx, const void* planes_hi_lo, size_t plane_bytes, const void* w, const float* scale,

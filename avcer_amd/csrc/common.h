@@ -86,9 +86,10 @@ int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1)
 // planes: bf16 hi plane [n][230][230][4] followed plane_bytes later by the lo plane; y: sp32 [n][55][55][64]
 int launch_stem_pool(avcer_ctx* ctx, const void* planes, size_t plane_bytes, const void* w_x3, const float* scale,
                      const float* bias, void* y, int n, hipStream_t st);
-// conv2 + conv3 (+ residual) of one non-first bottleneck and conv1 of the next block (t1n / w1n null when there is none);
-// all activations sp32, weights split-bf16 with permuted rows and the BN scale folded in (packing.py: *.wp)
-int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, void* out, void* t1n,
+// conv2 + conv3 (+ residual) of one bottleneck and conv1 of the next block (t1n / w1n null when there is none);
+// ds_cin = 0: x [M][4 planes] is the residual; ds_cin = 64: x [M][64] is the downsample operand and w3 is [4 planes][planes + 64];
+// all activations sp32, weights split-bf16 (row-permuted) with the BN scale folded in (packing.py: *.wf, c3d.w)
+int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, void* out, void* t1n,
                  const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n, const float* b1n,
                  hipStream_t st);
 

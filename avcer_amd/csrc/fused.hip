@@ -209,13 +209,18 @@ struct BneckParams {
 // BM positions per block, 4 waves, each wave owns BM/4 positions and ALL channels (so that a position's whole T2 /
 // OUT row lives in one wave's registers).  LDS: phase A double-buffers [BM + P rows][128 B]; phases B/C double-buffer
 // the weights of one 32-channel output group: P/32 tiles of W3 [32 rows][128 B] + one tile of W1N [P rows][128 B].
-template <int P, int BM, bool NEXT>
+// NQX = 0: X is the block input [M][4P], added as the residual.  NQX > 0 (first block of a stage without spatial stride):
+// X is the block input [M][32 NQX], the operand of the downsample convolution, whose weights are the K tail of W3
+// ([4P][P + 32 NQX], both BN scales folded, packing.py c3d): its rows are loaded straight into B-operand fragments
+// (an sp32 row IS the fragment layout: 16 bytes hi + 16 bytes lo per lane group and K-step) and there is no residual.
+template <int P, int BM, bool NEXT, int NQX>
 __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
     constexpr int NQ = P / 32;            // K-steps of a P-channel contraction
+    constexpr int NQT = NQ + NQX;         // K-steps of conv3 (+ downsample)
     constexpr int NT = BM / 64;           // 16-position tiles per wave
     constexpr int NG = 4 * P / 32;        // 32-channel groups of the block output
     constexpr int TILE_A = (BM + P) * ROWB;
-    constexpr int TILE_B = (32 * NQ + P) * ROWB;
+    constexpr int TILE_B = (32 * NQT + P) * ROWB;
     constexpr int TILES = 2 * (TILE_A > TILE_B ? TILE_A : TILE_B);
     constexpr int NBIAS = 6 * P;  // b2 [P], b1n [P], b3 [4P]: read back as broadcast float4 pairs in the epilogues
     __shared__ __attribute__((aligned(16))) char smem[TILES + NBIAS * 4];
@@ -230,7 +235,7 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
 
     const auto t1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.T1), (short)0, (int)p.t1_bytes, 0x00020000);
     const auto w2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W2), (short)0, P * 9 * P * 4, 0x00020000);
-    const auto w3rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W3), (short)0, 4 * P * P * 4, 0x00020000);
+    const auto w3rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W3), (short)0, 4 * P * (P + 32 * NQX) * 4, 0x00020000);
     const auto w1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(NEXT ? p.W1N : p.W3), (short)0, 4 * P * P * 4, 0x00020000);
 
     // ---------------- phase A: T2 = relu(bn2(conv3x3(T1))), K = 9 taps x P channels, accumulators [P][BM/4] per wave
@@ -304,12 +309,12 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
     }
 
     // ---------------- weights of output group G -> LDS buffer (G & 1)
-    unsigned g3_off[NQ], g1_off[W_ISS];  // W3: NQ tiles of 32 rows = NQ*4 instr per block -> NQ per wave; W1N: P/8 instr -> P/32 per wave
+    unsigned g3_off[NQT], g1_off[W_ISS];  // W3: NQT tiles of 32 rows = NQT*4 instr per block -> NQT per wave; W1N: P/8 instr -> P/32 per wave
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) {
+    for (int j = 0; j < NQT; ++j) {
         // instruction j of this wave fills rows [8 wave, 8 wave + 8) of K-step tile j of W3's 32-row group
         const int row = wave * 8 + lrow8;
-        g3_off[j] = (unsigned)((long)row * (P * 4) + j * ROWB + ((slot ^ swz_key(row)) << 4));
+        g3_off[j] = (unsigned)((long)row * (NQT * ROWB) + j * ROWB + ((slot ^ swz_key(row)) << 4));
     }
 #pragma unroll
     for (int j = 0; j < W_ISS; ++j) {
@@ -319,32 +324,52 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
     auto issue_group = [&](int G) {
         char* base = smem + (G & 1) * TILE_B;
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) dma16(w3rs, base + j * (32 * ROWB) + wave * 1024, g3_off[j], (unsigned)(G * 32 * P * 4));
+        for (int j = 0; j < NQT; ++j) dma16(w3rs, base + j * (32 * ROWB) + wave * 1024, g3_off[j], (unsigned)(G * 32 * NQT * ROWB));
         if constexpr (NEXT) {
 #pragma unroll
             for (int j = 0; j < W_ISS; ++j)
-                dma16(w1rs, base + NQ * (32 * ROWB) + wave * (W_ISS * 1024) + j * 1024, g1_off[j], (unsigned)(G * ROWB));
+                dma16(w1rs, base + NQT * (32 * ROWB) + wave * (W_ISS * 1024) + j * 1024, g1_off[j], (unsigned)(G * ROWB));
         }
     };
     issue_group(0);  // the tile buffers are free: phase A ended on a barrier
 
     // residual rows of this lane: position m_t = m_base + wave*BM/4 + 16 t + (lane & 15); 16 bytes hi + 16 bytes lo per group
-    long x_row[NT];
+    long x_row[NT];  // byte offset of this lane's piece of the block-output row (and of the residual row: same shape)
+    long m_row[NT];  // position (clamped to 0 past M: loads stay in bounds, stores are predicated)
     bool m_ok[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const long m = (long)m_base + wave * (BM / 4) + t * 16 + l15;
         m_ok[t] = m < p.M;
-        x_row[t] = (m_ok[t] ? m : 0) * (4L * P * 4) + 16 * g;
+        m_row[t] = m_ok[t] ? m : 0;
+        x_row[t] = m_row[t] * (4L * P * 4) + 16 * g;
+    }
+    // downsample operand: the NQX K-steps of this lane's positions as B fragments, straight from global memory
+    bf16x8_t xh[NQX > 0 ? NQX : 1][NT], xl[NQX > 0 ? NQX : 1][NT];
+    if constexpr (NQX > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const char* xp = p.X + m_row[t] * (NQX * 128L) + 16 * g;
+#pragma unroll
+            for (int q = 0; q < NQX; ++q) {
+                xh[q][t] = *reinterpret_cast<const bf16x8_t*>(xp + q * 128);
+                xl[q][t] = *reinterpret_cast<const bf16x8_t*>(xp + q * 128 + 64);
+            }
+        }
     }
     // residual of group G sits in ring slot G & 1 and is requested two groups ahead of its use
     uint4 rh[2][NT], rl[2][NT];
     auto load_res = [&](int G, uint4 (&h)[NT], uint4 (&l)[NT]) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const char* rp = p.X + x_row[t] + G * 128;
-            h[t] = *reinterpret_cast<const uint4*>(rp);
-            l[t] = *reinterpret_cast<const uint4*>(rp + 64);
+            if constexpr (NQX > 0) {
+                h[t] = make_uint4(0u, 0u, 0u, 0u);  // no residual: the downsample branch is part of the contraction
+                l[t] = make_uint4(0u, 0u, 0u, 0u);
+            } else {
+                const char* rp = p.X + x_row[t] + G * 128;
+                h[t] = *reinterpret_cast<const uint4*>(rp);
+                l[t] = *reinterpret_cast<const uint4*>(rp + 64);
+            }
         }
     };
     load_res(0, rh[0], rl[0]);
@@ -374,7 +399,7 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
     auto group = [&](int G, uint4 (&h)[NT], uint4 (&l)[NT]) {
         if (G + 1 < NG) issue_group(G + 1);
         const char* w3t = smem + (G & 1) * TILE_B;
-        const char* w1t = w3t + NQ * (32 * ROWB);
+        const char* w1t = w3t + NQT * (32 * ROWB);
         f32x4_t acc3[2][NT];
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp)
@@ -388,6 +413,17 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) mfma3(acc3[tp][t], wh, wl, t2h[q][t], t2l[q][t]);
             }
+        if constexpr (NQX > 0) {
+#pragma unroll
+            for (int q = 0; q < NQX; ++q)
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp) {
+                    const char* wt = w3t + (NQ + q) * (32 * ROWB);
+                    const bf16x8_t wh = ldfrag(wt, tp * 16 + l15, g), wl = ldfrag(wt, tp * 16 + l15, 4 + g);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) mfma3(acc3[tp][t], wh, wl, xh[q][t], xl[q][t]);
+                }
+        }
         const float* bp = sbias + 2 * P + 32 * G + 8 * g;
         const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
         bf16x8_t oh[NT], ol[NT];
@@ -466,7 +502,7 @@ int launch_stem_pool(avcer_ctx* ctx, const void* planes, size_t plane_bytes, con
     return AVCER_OK;
 }
 
-int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, void* out, void* t1n,
+int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, void* out, void* t1n,
                  const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n, const float* b1n,
                  hipStream_t st) {
     const long M = (long)nb * h * w;
@@ -475,6 +511,8 @@ int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t
     if ((t1n != nullptr) != (w1n != nullptr) || (t1n && !b1n))
         return set_err(ctx, AVCER_EINVAL, "bneck: next-block conv1 needs weights, bias and an output");
     if (planes != 64 && planes != 128) return set_err(ctx, AVCER_EINVAL, "bneck: planes %d (64 or 128)", planes);
+    if (ds_cin != 0 && !(ds_cin == 64 && planes == 64 && t1n))
+        return set_err(ctx, AVCER_EINVAL, "bneck: the downsample form exists for planes 64 with a 64-channel input and a next conv1");
     if (M * planes * 4L >= (long)OOB) return set_err(ctx, AVCER_EINVAL, "bneck: M=%ld too large for one pass", M);
     BneckParams p;
     p.T1 = (const char*)t1; p.X = (const char*)x; p.OUT = (char*)out; p.T1N = (char*)t1n;
@@ -486,17 +524,19 @@ int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t
     const int grid = (int)((M + BM - 1) / BM);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     TRY(prof_begin(ctx, st, &ev0, &ev1));
-    if (planes == 64) {
-        if (t1n) bneck_kernel<64, BM, true><<<dim3(grid), dim3(256), 0, st>>>(p);
-        else bneck_kernel<64, BM, false><<<dim3(grid), dim3(256), 0, st>>>(p);
+    if (ds_cin) {
+        bneck_kernel<64, BM, true, 2><<<dim3(grid), dim3(256), 0, st>>>(p);
+    } else if (planes == 64) {
+        if (t1n) bneck_kernel<64, BM, true, 0><<<dim3(grid), dim3(256), 0, st>>>(p);
+        else bneck_kernel<64, BM, false, 0><<<dim3(grid), dim3(256), 0, st>>>(p);
     } else {
-        if (t1n) bneck_kernel<128, BM, true><<<dim3(grid), dim3(256), 0, st>>>(p);
-        else bneck_kernel<128, BM, false><<<dim3(grid), dim3(256), 0, st>>>(p);
+        if (t1n) bneck_kernel<128, BM, true, 0><<<dim3(grid), dim3(256), 0, st>>>(p);
+        else bneck_kernel<128, BM, false, 0><<<dim3(grid), dim3(256), 0, st>>>(p);
     }
     if (ev1) (void)hipEventRecord(ev1, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "bneck launch: %s", hipGetErrorString(e));
     ctx->gemm_launches += 1;
-    ctx->gemm_flops += 2.0 * (double)M * planes * planes * (9.0 + 4.0 + (t1n ? 4.0 : 0.0));
+    ctx->gemm_flops += 2.0 * (double)M * planes * (planes * (9.0 + 4.0 + (t1n ? 4.0 : 0.0)) + 4.0 * ds_cin);
     return AVCER_OK;
 }

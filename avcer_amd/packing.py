@@ -77,9 +77,14 @@ def pack_static(sd) -> "OrderedDict[str, np.ndarray]":
                 w3, s3, b3 = out.pop(f"{dst}.c3.w"), out.pop(f"{dst}.c3.s"), out.pop(f"{dst}.c3.b")
                 out[f"{dst}.c3d.w"] = np.ascontiguousarray(np.concatenate([w3 * s3[:, None], wd * s_d[:, None]], axis=1))
                 out[f"{dst}.c3d.b"] = (b3 + b_d).astype(np.float32)
-        if li <= 2:  # stages whose non-first blocks run as the fused chain conv2 -> conv3 (+x) -> next conv1 (x3 mode)
-            for b in range(1, blocks):
-                for i in (2, 3) if b < 2 else (1, 2, 3):  # BN scale folded into the rows: the chain's epilogues only add the shift
+        if li <= 2:  # stages that run as fused chains conv2 -> conv3 (+x) -> next conv1 in the x3 mode (csrc/fused.hip):
+            # stage 1 from its first block (stride 1; conv3 + downsample = c3d), stage 2 from its second block.
+            # BN scale folded into the rows: the chain's epilogues only add the shift.
+            for b in range(0 if li == 1 else 1, blocks):
+                head = b == (0 if li == 1 else 1)  # conv1 of the chain's first block runs on its own (plain conv_gemm)
+                for i in (1, 2, 3):
+                    if (i == 1 and head) or (i == 3 and b == 0):
+                        continue
                     k = f"l{li}.{b}.c{i}"
                     out[k + ".wf"] = np.ascontiguousarray(out[k + ".w"] * out[k + ".s"][:, None])
     out["fc1.w"], out["fc1.b"] = _f32(sd["fc1.weight"]), _f32(sd["fc1.bias"])

@@ -215,12 +215,15 @@ int avcer_conv_gemm_dual(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, co
  *   t1 sp32 [nb,h,w,planes], x / out sp32 [nb,h,w,4*planes], t1n sp32 [nb,h,w,planes] or NULL (then w1n, b1n NULL);
  *   w2 [planes][9*planes], w3 [4*planes][planes], w1n [planes][4*planes]: BN scale folded into the rows, then split
  *   by avcer_split_weight_rows; b2 / b3 / b1n f32 BN shifts in natural channel order.  planes = 64 or 128.
+ *   ds_cin = 64 (planes 64 only, t1n required): the FIRST block of a stage without spatial stride (video.py:43-60 with
+ *   i_downsample): x is the 64-channel block input sp32 [nb,h,w,64], w3 is [4*planes][planes + 64] = conv3 and the
+ *   downsample convolution concatenated along K (both BN scales folded, shifts summed into b3), and nothing is added.
  *
  * avcer_stem_pool: conv 7x7/2 (TF-"same" padding) + BN + ReLU + max-pool 3x3/2 in one launch,
  *   ref: architectures/video.py:63-90,98-103,116-117.  planes_hi_lo: two bf16 planes [n,230,230,4] (hi, then lo plane_bytes
  *   later) of the zero-bordered preprocessed image as avcer_static_forward builds it; w split [64][7*32] (tap rows of
  *   8 pixels x 4 channels); scale / bias f32 [64]; y sp32 [n,55,55,64]. */
-int avcer_bneck_chain(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, void* out, void* t1n,
+int avcer_bneck_chain(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, void* out, void* t1n,
                       const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n, const float* b1n,
                       avcer_stream_t stream);
 int avcer_stem_pool(avcer_ctx* ctx, const void* planes_hi_lo, size_t plane_bytes, const void* w, const float* scale,

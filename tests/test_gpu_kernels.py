@@ -302,3 +302,34 @@ def test_split_weight_rows_layout(engine):
     ref = torch.from_numpy(permute_rows_for_mfma(w.numpy()))
     assert (got - ref).abs().max() < 2e-5 and (got - ref).abs().max() > 0      # hi + lo is not exactly f32
     assert torch.equal(from_sp32(to_sp32(ref)), got)
+
+
+def test_bneck_chain_first_block_with_downsample(engine):
+    """The first block of stage 1 (video.py:43-60 with i_downsample, stride 1): conv3 and the downsample convolution as one
+    contraction over K = [T2 | x], no residual, then the next block's conv1 -- against float64 convolutions."""
+    g = torch.Generator().manual_seed(7)
+    planes, nb, hw = 64, 3, 55
+    p4 = 4 * planes
+    t1 = torch.rand(nb, hw, hw, planes, generator=g) * 2
+    x = torch.rand(nb, hw, hw, 64, generator=g) * 2
+    w2 = torch.randn(planes, 3, 3, planes, generator=g) / (3 * planes ** 0.5)
+    w3 = torch.randn(p4, planes, generator=g) / planes ** 0.5
+    wd = torch.randn(p4, 64, generator=g) / 8.0
+    w1 = torch.randn(planes, p4, generator=g) / p4 ** 0.5
+    b2, b3, b1 = (torch.randn(n, generator=g) * 0.3 for n in (planes, p4, planes))
+    t2 = F.relu(F.conv2d(t1.permute(0, 3, 1, 2).double(), w2.permute(0, 3, 1, 2).double(), b2.double(), padding=1))
+    out = F.relu(F.conv2d(t2, w3.double()[:, :, None, None], b3.double()) +
+                 F.conv2d(x.permute(0, 3, 1, 2).double(), wd.double()[:, :, None, None]))
+    t1n = F.relu(F.conv2d(out, w1.double()[:, :, None, None], b1.double()))
+    dev = engine.device
+    d_out = torch.full((nb, hw, hw, 2 * p4), 0x7fc0, dtype=torch.int16, device=dev)
+    d_t1n = torch.full((nb, hw, hw, 2 * planes), 0x7fc0, dtype=torch.int16, device=dev)
+    engine.bneck_chain(planes, nb, hw, hw, to_sp32(t1).to(dev), to_sp32(x).to(dev), d_out, d_t1n,
+                       engine.split_weight_rows(w2.reshape(planes, -1)), b2.to(dev),
+                       engine.split_weight_rows(torch.cat([w3, wd], dim=1)), b3.to(dev), engine.split_weight_rows(w1), b1.to(dev),
+                       ds_cin=64)
+    torch.cuda.synchronize()
+    e0 = (from_sp32(d_out.cpu()).permute(0, 3, 1, 2).double() - out).abs().max().item()
+    e1 = (from_sp32(d_t1n.cpu()).permute(0, 3, 1, 2).double() - t1n).abs().max().item()
+    print(f"bneck first block: max|out err| {e0:.2e} (max {out.abs().max().item():.1f}), max|t1n err| {e1:.2e}")
+    assert e0 < 2e-5 * max(1.0, out.abs().max().item()) and e1 < 2e-5 * max(1.0, t1n.abs().max().item())
