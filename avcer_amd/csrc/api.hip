@@ -398,6 +398,31 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
             const std::string p = "l" + std::to_string(li + 1) + "." + std::to_string(b) + ".";
             const int oh = (h - 1) / stride + 1;
             void* dst = (b == blocks - 1 && last_out) ? last_out : OUT;
+            if (net.x3 && li == 2 && b >= 1) {
+                // stage 3: conv2 stays a conv_gemm launch; conv3 + residual and the next block's conv1 share one (fused.hip)
+                if (b == 1)
+                    net.gemm(conv2d_desc(nb, h, h, cin, 1, 1, 1, 0, planes, 1), p + "c1.w", net.F(p + "c1.s"), net.F(p + "c1.b"),
+                             X, nullptr, T1, act, act);
+                net.gemm(conv2d_desc(nb, h, h, planes, 3, 3, 1, 1, planes, 1), p + "c2.w", net.F(p + "c2.s"), net.F(p + "c2.b"), T1,
+                         nullptr, T2, act, act);
+                if (b + 1 < blocks) {
+                    const std::string pn = "l" + std::to_string(li + 1) + "." + std::to_string(b + 1) + ".";
+                    const Tensor *w3 = net.T(p + "c3.wf"), *w1n = net.T(pn + "c1.wf");
+                    if (net.err != AVCER_OK) return;
+                    if (!w3->x3 || !w1n->x3) {
+                        net.err = set_err(ctx, AVCER_ESTATE, "%s: split tail weights not prepared", p.c_str());
+                        return;
+                    }
+                    net.chk(launch_bneck_tail(ctx, planes, (long)nb * h * h, T2, X, dst, T1, w3->x3, net.F(p + "c3.b"), w1n->x3,
+                                              net.F(pn + "c1.b"), st));
+                } else {
+                    net.gemm(conv2d_desc(nb, h, h, planes, 1, 1, 1, 0, planes * 4, 1), p + "c3.w", net.F(p + "c3.s"), net.F(p + "c3.b"),
+                             T2, X, dst, act, act);
+                }
+                if (dst == OUT) std::swap(X, OUT);
+                else X = dst;
+                continue;
+            }
             // li == 0: the first block too (stride 1, 64 input channels: the downsample operand rides in registers)
             if (chain && (b >= 1 || li == 0)) {
                 const bool first = b == 0;

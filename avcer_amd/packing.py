@@ -87,6 +87,10 @@ def pack_static(sd) -> "OrderedDict[str, np.ndarray]":
                         continue
                     k = f"l{li}.{b}.c{i}"
                     out[k + ".wf"] = np.ascontiguousarray(out[k + ".w"] * out[k + ".s"][:, None])
+        if li == 3:  # stage 3: conv3 (+x) of block b and conv1 of block b+1 share a launch (bneck_tail_kernel), b = 1..blocks-2
+            for b in range(1, blocks - 1):
+                for k in (f"l{li}.{b}.c3", f"l{li}.{b + 1}.c1"):
+                    out[k + ".wf"] = np.ascontiguousarray(out[k + ".w"] * out[k + ".s"][:, None])
     out["fc1.w"], out["fc1.b"] = _f32(sd["fc1.weight"]), _f32(sd["fc1.bias"])
     out["fc2.w"], out["fc2.b"] = _f32(sd["fc2.weight"]), _f32(sd["fc2.bias"])
     return out

@@ -87,12 +87,14 @@ def test_pack_static_layouts(sd_static):
     got = x * torch.from_numpy(t["l1.1.c3.s"])[None, :, None, None] + torch.from_numpy(t["l1.1.c3.b"])[None, :, None, None]
     assert (ref - got).abs().max() < 1e-5
     # block 0 of each stage: c3 + downsample fused into c3d.{w,b}; + stem7.w and the row-permuted chain weights
-    n_chain = (1 + 3 + 3) + (2 + 3 + 3)  # .wf of the chain blocks: stage 1 from block 0 (its conv3 is c3d.w), stage 2 from block 1
+    # .wf of the chain blocks: stage 1 from block 0 (its conv3 is c3d.w), stage 2 from block 1; stage 3 tails: c3 of blocks
+    # 1..4 with c1 of blocks 2..5
+    n_chain = (1 + 3 + 3) + (2 + 3 + 3) + 2 * 4
     assert len(t) == 1 * 3 + 16 * 9 - 4 * 3 + 4 * 2 + 4 + 1 + n_chain
     np.testing.assert_array_equal(t["stem7.w"].reshape(64, 7, 8, 4), stem[:, :7])
     # chain weights (csrc/fused.hip): the BN scale folded into the rows (the device applies the row permutation)
     np.testing.assert_array_equal(t["l2.2.c3.wf"], t["l2.2.c3.w"] * t["l2.2.c3.s"][:, None])
-    assert "l1.0.c1.wf" not in t and "l1.1.c1.wf" in t and "l2.1.c1.wf" not in t and "l2.2.c1.wf" in t and "l3.1.c2.wf" not in t
+    assert "l1.0.c1.wf" not in t and "l1.1.c1.wf" in t and "l2.1.c1.wf" not in t and "l2.2.c1.wf" in t and "l3.1.c2.wf" not in t and "l3.1.c3.wf" in t and "l3.5.c1.wf" in t and "l3.5.c3.wf" not in t
     # numpy twin of the device-side row order: stored row 16t + 4g + r of every 32-row group holds channel 8g + 4t + r
     w0 = t["l2.2.c3.w"]
     wp = packing.permute_rows_for_mfma(w0)
