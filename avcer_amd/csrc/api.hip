@@ -345,18 +345,28 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     if (bf) TRY(ensure_all_bf16(ctx, ctx->stat, st));
     if (mode == AVCER_MODE_BF16X3) TRY(ensure_all_x3(ctx, ctx->stat, st));
     const size_t es = bf ? 2 : 4;
+    // Two granularities.  The FRONT (stem, stage 1, first block of stage 2: the 55x55 tensors) runs in passes of NB <= 1024
+    // frames, the 4 GiB range of a buffer descriptor at 4 bytes per element.  The BACK (rest of stage 2, stages 3-4, tail)
+    // runs once over NS = up to two front passes: its grids are small (stage 4: 1568 tiles per 1024 frames on 512 block
+    // slots), and twice the rows per launch means a smaller last partial round (a tail of 0.06 rounds costs a whole one).
     const int NB = std::min(n, ctx->static_batch);
-    const size_t act_elems = (size_t)NB * 112 * 112 * 64;  // largest activation (stem output)
+    const int NS = std::min(n, 2 * NB);
+    const size_t act_elems = (size_t)NB * 112 * 112 * 64;  // largest activation of the front (stem output)
+    const size_t back_elems = (size_t)NS * 28 * 28 * 512;  // largest activation of the back (stage 2)
     const size_t pre_elems = (size_t)NB * 230 * 230 * 4;
-    const size_t total = pre_elems * es + 4 * (act_elems * es + 256) + (size_t)NB * (2048 + 512) * 4 + 4096;
+    if (back_elems * es >= 0xF0000000ull) return set_err(ctx, AVCER_EINVAL, "static_forward: %d frames per back pass", NS);
+    const size_t total = pre_elems * es + 4 * (act_elems * es + 256) + 4 * (back_elems * es + 256) +
+                         (size_t)NS * (2048 + 512) * 4 + 4096;
     void* wsp = nullptr;
     TRY(ws_reserve(ctx, 0, total, &wsp));
     Arena ar(wsp, ctx->ws[0].cap);
     void* P = ar.get(pre_elems * es);
     void* buf[4];
     for (auto& b : buf) b = ar.get(act_elems * es);
-    float* pooled = (float*)ar.get((size_t)NB * 2048 * 4);
-    float* feat_ws = (float*)ar.get((size_t)NB * 512 * 4);
+    void* bbuf[4];
+    for (auto& b : bbuf) b = ar.get(back_elems * es);
+    float* pooled = (float*)ar.get((size_t)NS * 2048 * 4);
+    float* feat_ws = (float*)ar.get((size_t)NS * 512 * 4);
     if (!feat_ws) return set_err(ctx, AVCER_ENOMEM, "static workspace arithmetic");
 
     Net net{ctx, ctx->stat, bf, st, mode == AVCER_MODE_BF16X3};
@@ -389,15 +399,16 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
         net.chk(k_maxpool3s2(ctx, B[0], B[1], nb, 112, 112, 64, 55, 55, act, st));
         net.tap("stem", B[1], (size_t)nb * 55 * 55 * 64 * es);
     };
-    // one stage (li) of bottlenecks on nb frames; the last block writes to `last_out` when given
-    auto run_stage = [&](int li, int nb, void*& X, void*& T1, void*& T2, void*& OUT, int& h, int& cin, void* last_out) {
+    // blocks [b_begin, b_end) of stage li on nb frames; the last of them writes to `last_out` when given
+    auto run_stage = [&](int li, int nb, void*& X, void*& T1, void*& T2, void*& OUT, int& h, int& cin, void* last_out, int b_begin,
+                         int b_end) {
         const int planes = kStages[li][0], blocks = kStages[li][1];
         const bool chain = net.x3 && li < 2;  // stages 1-2 in x3 mode: non-first blocks run as the fused chain (fused.hip)
-        for (int b = 0; b < blocks; ++b) {
+        for (int b = b_begin; b < b_end; ++b) {
             const int stride = b == 0 ? kStages[li][2] : 1;
             const std::string p = "l" + std::to_string(li + 1) + "." + std::to_string(b) + ".";
             const int oh = (h - 1) / stride + 1;
-            void* dst = (b == blocks - 1 && last_out) ? last_out : OUT;
+            void* dst = (b == b_end - 1 && last_out) ? last_out : OUT;
             if (net.x3 && li == 2 && b >= 1) {
                 // stage 3: conv2 stays a conv_gemm launch; conv3 + residual and the next block's conv1 share one (fused.hip)
                 if (b == 1)
@@ -476,15 +487,23 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
                 net.tap("l1b0", X, (size_t)nb * h * h * cin * es);
             }
         }
-        net.tap(("layer" + std::to_string(li + 1)).c_str(), X, (size_t)nb * h * h * cin * es);
+        if (b_end == blocks) net.tap(("layer" + std::to_string(li + 1)).c_str(), X, (size_t)nb * h * h * cin * es);
     };
-    for (int s0 = 0; s0 < n; s0 += NB) {
-        const int nb = std::min(NB, n - s0);
-        void *X, *T1 = buf[2], *T2 = buf[3], *OUT = buf[0];
-        int h = 55, cin = 64;
-        run_stem(s0, nb, buf);
-        X = buf[1];
-        for (int li = 0; li < 4; ++li) run_stage(li, nb, X, T1, T2, OUT, h, cin, nullptr);
+    for (int s0 = 0; s0 < n; s0 += NS) {
+        const int nb = std::min(NS, n - s0);
+        for (int c0 = 0; c0 < nb; c0 += NB) {  // front passes: stem, stage 1, first block of stage 2 -> bbuf[0]
+            const int cn = std::min(NB, nb - c0);
+            void *X, *T1 = buf[2], *T2 = buf[3], *OUT = buf[0];
+            int h = 55, cin = 64;
+            run_stem(s0 + c0, cn, buf);
+            X = buf[1];
+            run_stage(0, cn, X, T1, T2, OUT, h, cin, nullptr, 0, kStages[0][1]);
+            run_stage(1, cn, X, T1, T2, OUT, h, cin, (char*)bbuf[0] + (size_t)c0 * 28 * 28 * 512 * es, 0, 1);
+        }
+        void *X = bbuf[0], *T1 = bbuf[2], *T2 = bbuf[3], *OUT = bbuf[1];
+        int h = 28, cin = 512;
+        run_stage(1, nb, X, T1, T2, OUT, h, cin, nullptr, 1, kStages[1][1]);
+        for (int li = 2; li < 4; ++li) run_stage(li, nb, X, T1, T2, OUT, h, cin, nullptr, 0, kStages[li][1]);
         net.chk(k_avgpool_hw(ctx, X, pooled, nb, h * h, 2048, act, st));
         net.tap("avgpool", pooled, (size_t)nb * 2048 * 4);
         float* fo = feats ? feats + (size_t)s0 * 512 : feat_ws;
