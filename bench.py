@@ -131,6 +131,8 @@ def parse():
     ap.add_argument("--cpu-clips", type=int, default=64, help="upper bound of the CPU baseline sample (sized to ~12 s)")
     ap.add_argument("--parity-clips", type=int, default=2)
     ap.add_argument("--no-configs", action="store_true", help="skip the per-model BASELINE configs 2 and 3")
+    ap.add_argument("--no-events", action="store_true", help="diagnostic: time the steps without the per-launch HIP events "
+                                                            "(the roofline object is then empty)")
     return ap.parse_args()
 
 
@@ -375,7 +377,7 @@ def main():
     def measure(name, steps, warmup):
         set_mode(name)
         log(f"timing {name}: {warmup} warm-up + {steps} steps of {args.clips} clips/GPU")
-        dt, kern_ms, launches = timed(pipe, frames, wav, n_total, steps, warmup, device, profile=True)
+        dt, kern_ms, launches = timed(pipe, frames, wav, n_total, steps, warmup, device, profile=not args.no_events)
         flops_gemm = GFLOP_CLIP_GEMM * 1e9 * args.clips * steps  # algorithmic FLOPs this rank pushed through the MFMA kernels
         ach = flops_gemm / (kern_ms * 1e-3) / 1e12 if kern_ms else None
         traffic, traffic_src, stamp = pmc_traffic(name, args.clips)
