@@ -1092,6 +1092,12 @@ extern "C" int avcer_split_weight_rows(avcer_ctx* ctx, const float* w, void* out
     return k_split_weight_rows(ctx, w, (bf16_t*)out, n, k, (hipStream_t)stream);
 }
 
+extern "C" int avcer_measure_ceilings(avcer_ctx* ctx, double* mfma_bf16_tflops, double* hbm_copy_tbs, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return measure_ceilings(ctx, mfma_bf16_tflops, hbm_copy_tbs, (hipStream_t)stream);
+}
+
 extern "C" int avcer_gemm_stats(avcer_ctx* ctx, int64_t* launches, double* flops, int reset) {
     if (!ctx) return AVCER_EINVAL;
     if (launches) *launches = ctx->gemm_launches;

@@ -97,6 +97,8 @@ int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t
 int launch_bneck_tail(avcer_ctx* ctx, int planes, long M, const void* t2, const void* x, void* out, void* t1n, const void* w3,
                       const float* b3, const void* w1n, const float* b1n, hipStream_t st);
 
+int measure_ceilings(avcer_ctx* ctx, double* mfma_bf16_tflops, double* hbm_copy_tbs, hipStream_t st);
+
 // ---- kernels.hip (element-wise / reduction kernels; T selects f32 (0) or bf16 (1) activations)
 // kind: 0 = f32 [n,230,230,4], 1 = bf16, 3 = planar bf16 hi / lo (two [n,230,230,4] planes, the stem_pool input)
 int k_preprocess(avcer_ctx*, const uint8_t* frames, int n, int in_h, int in_w, void* out, int kind, hipStream_t);

@@ -606,6 +606,38 @@ __global__ void __launch_bounds__(256, 2) bneck_tail_kernel(const BneckParams p)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ on-box ceilings
+// Two micro-kernels that bench.py runs once to put MEASURED ceilings of this very GPU next to the guide's peaks:
+// back-to-back v_mfma_f32_16x16x32_bf16 on register operands (two waves per SIMD, 16 independent accumulators each,
+// non-trivial operand bits), and a 16-byte-per-lane streaming copy.
+__global__ void __launch_bounds__(256, 2) mfma_rate_kernel(float* sink, int iters) {
+    const int lane = threadIdx.x & 63;
+    bf16x8_t a, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        a[j] = (__bf16)(0.25f + 0.001f * (float)((lane * 8 + j) % 97));
+        b[j] = (__bf16)(-0.5f + 0.002f * (float)((lane * 5 + j * 3 + blockIdx.x) % 89));
+    }
+    f32x4_t acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4_t{0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][3];
+    if (s == 12345.678f) sink[0] = s;  // keeps the chain alive without a store on the measured path
+}
+
+__global__ void copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    // four independent 16-byte loads per thread in flight, then four stores; n16 is a multiple of 4 * 256 * gridDim.x
+    const size_t t = (size_t)gridDim.x * blockDim.x, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint4 a = src[i], b = src[i + t], c = src[i + 2 * t], d = src[i + 3 * t];
+    dst[i] = a; dst[i + t] = b; dst[i + 2 * t] = c; dst[i + 3 * t] = d;
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -684,5 +716,38 @@ int launch_bneck_tail(avcer_ctx* ctx, int planes, long M, const void* t2, const 
     if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "bneck_tail launch: %s", hipGetErrorString(e));
     ctx->gemm_launches += 1;
     ctx->gemm_flops += 2.0 * (double)M * planes * planes * 8.0;
+    return AVCER_OK;
+}
+
+// Measured ceilings of this GPU: dense bf16 MFMA issue rate (TFLOP/s) and streaming-copy bandwidth (TB/s, read + write bytes).
+int measure_ceilings(avcer_ctx* ctx, double* mfma_bf16_tflops, double* hbm_copy_tbs, hipStream_t st) {
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    void* buf = nullptr;
+    const size_t bytes = (size_t)1 << 30;  // 1 GiB source + 1 GiB destination: far beyond the 256 MiB memory-side cache
+    TRY(ws_reserve(ctx, 5, 2 * bytes, &buf));
+    float ms = 0.f;
+    const int blocks = 256 * 2, iters = 20000;
+    mfma_rate_kernel<<<blocks, 256, 0, st>>>((float*)buf, 2000);  // warm-up (clock ramp)
+    HIP_TRY(ctx, hipEventRecord(e0, st));
+    mfma_rate_kernel<<<blocks, 256, 0, st>>>((float*)buf, iters);
+    HIP_TRY(ctx, hipEventRecord(e1, st));
+    HIP_TRY(ctx, hipEventSynchronize(e1));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+    if (mfma_bf16_tflops) *mfma_bf16_tflops = (double)blocks * 4 * iters * 16 * (2.0 * 16 * 16 * 32) / (ms * 1e-3) / 1e12;
+    HIP_TRY(ctx, hipMemsetAsync(buf, 1, bytes, st));
+    const int cgrid = (int)(bytes / 16 / (4 * 256));
+    copy16_kernel<<<cgrid, 256, 0, st>>>((const uint4*)buf, (uint4*)((char*)buf + bytes), bytes / 16);
+    HIP_TRY(ctx, hipEventRecord(e0, st));
+    for (int i = 0; i < 4; ++i) copy16_kernel<<<cgrid, 256, 0, st>>>((const uint4*)buf, (uint4*)((char*)buf + bytes), bytes / 16);
+    HIP_TRY(ctx, hipEventRecord(e1, st));
+    HIP_TRY(ctx, hipEventSynchronize(e1));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+    if (hbm_copy_tbs) *hbm_copy_tbs = 4.0 * 2.0 * (double)bytes / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "measure_ceilings: %s", hipGetErrorString(e));
     return AVCER_OK;
 }

@@ -292,6 +292,12 @@ class Engine:
         self._check(self.lib.avcer_bneck_chain(self.ctx, planes, nb, h, w, _ptr(t1), _ptr(x), int(ds_cin), _ptr(out), _ptr(t1n), _ptr(w2),
                                                _ptr(b2), _ptr(w3), _ptr(b3), _ptr(w1n), _ptr(b1n), self._stream()))
 
+    def measure_ceilings(self):
+        """(bf16 MFMA TFLOP/s of a register-only MFMA loop, TB/s of a 1 GiB streaming copy) measured on this GPU."""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        self._check(self.lib.avcer_measure_ceilings(self.ctx, C.byref(a), C.byref(b), self._stream()))
+        return a.value, b.value
+
     def gemm_stats(self, reset: bool = True):
         n, f = C.c_int64(0), C.c_double(0.0)
         self._check(self.lib.avcer_gemm_stats(self.ctx, C.byref(n), C.byref(f), int(reset)))

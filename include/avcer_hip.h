@@ -240,6 +240,11 @@ int avcer_split_weights(avcer_ctx* ctx, const float* w, void* out, size_t numel,
  * the output row (direct whole-line stores).  scale / bias / residual / output stay in natural channel order. */
 int avcer_split_weight_rows(avcer_ctx* ctx, const float* w, void* out, int n, int k, avcer_stream_t stream);
 
+/* Measured ceilings of the GPU this context lives on (about 0.2 s): dense bf16 MFMA issue rate of a register-only
+ * v_mfma_f32_16x16x32_bf16 loop in TFLOP/s, and the bandwidth of a 1 GiB -> 1 GiB 16-byte-per-lane copy in TB/s (bytes read
+ * + bytes written).  bench.py prints them next to the datasheet peaks it divides by.  Uses 2 GiB of workspace. */
+int avcer_measure_ceilings(avcer_ctx* ctx, double* mfma_bf16_tflops, double* hbm_copy_tbs, avcer_stream_t stream);
+
 /* Last launch statistics of the dominant kernel (for bench.py's roofline object): number of conv_gemm
  * launches and their summed algorithmic FLOPs since the previous call to this function. */
 int avcer_gemm_stats(avcer_ctx* ctx, int64_t* launches, double* flops, int reset);
