@@ -131,6 +131,7 @@ def parse():
     ap.add_argument("--cpu-clips", type=int, default=64, help="upper bound of the CPU baseline sample (sized to ~12 s)")
     ap.add_argument("--parity-clips", type=int, default=2)
     ap.add_argument("--no-configs", action="store_true", help="skip the per-model BASELINE configs 2 and 3")
+    ap.add_argument("--overlap", action="store_true", help="experiment: audio branch on its own HIP stream")
     ap.add_argument("--no-events", action="store_true", help="diagnostic: time the steps without the per-launch HIP events "
                                                             "(the roofline object is then empty)")
     return ap.parse_args()
@@ -367,6 +368,7 @@ def main():
     torch.set_num_threads(min(usable_cores(), 16))
     log(f"rank {rank}/{world}: building pipeline (synthetic weights, seed 42)")
     pipe = AVPipeline(device=local_rank, seed=42, mode=modes[args.mode])
+    pipe.overlap_branches = bool(args.overlap)
     log("generating inputs")
     frames, wav = make_inputs(args.clips, rank, device)
     n_total = args.clips * world

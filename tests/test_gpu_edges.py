@@ -62,3 +62,21 @@ def test_fusion_without_audio_coverage_raises_like_reference(engine):
     with pytest.raises(IndexError):  # audio_df[-1] on an empty table, run.py:100
         fusion.fuse(engine, np.zeros((4, 7), np.float32), np.zeros((4, 7), np.float32), np.zeros((1, 8), np.float32),
                     [10], [12])
+
+
+def test_c_abi_audio_chunks_empty_chunk_in_repeat_mode_is_nan_not_a_fault(engine):
+    """The raw C entry (no host-side guard): an empty chunk in mode 2 (repeat) must not index with i % 0.  The row comes
+    back as NaN, the other rows are untouched."""
+    import ctypes as C
+
+    wav = torch.arange(1, 101, dtype=torch.float32, device=engine.device)
+    starts = torch.tensor([0, 50, 100], dtype=torch.int32, device=engine.device)
+    ends = torch.tensor([10, 50, 100], dtype=torch.int32, device=engine.device)      # rows 1 and 2 are empty
+    out = torch.zeros(3, 16, device=engine.device)
+    rc = engine.lib.avcer_audio_chunks(engine.ctx, C.c_void_p(wav.data_ptr()), C.c_void_p(starts.data_ptr()),
+                                       C.c_void_p(ends.data_ptr()), 3, 16, 2, C.c_void_p(out.data_ptr()), engine._stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    o = out.cpu()
+    assert o[0].tolist() == [float(1 + i % 10) for i in range(16)]
+    assert torch.isnan(o[1]).all() and torch.isnan(o[2]).all()
