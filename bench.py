@@ -352,10 +352,19 @@ def main():
         if not rehearse and torch.cuda.device_count() <= local_rank:
             sys.exit(f"bench.py: rank {rank} has no GPU {local_rank} ({torch.cuda.device_count()} visible)")
         torch.cuda.set_device(local_rank)
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # the collective libraries may greet on fd 1 ("[Gloo] Rank 0 is connected ..."): stdout carries ONE JSON line only
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if rehearse:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
         backend = dist.get_backend()
         if dist.get_world_size() != args.gpus:
             sys.exit(f"bench.py: process group has {dist.get_world_size()} ranks, expected {args.gpus}")
