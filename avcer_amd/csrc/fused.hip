@@ -213,15 +213,24 @@ struct BneckParams {
 // X is the block input [M][32 NQX], the operand of the downsample convolution, whose weights are the K tail of W3
 // ([4P][P + 32 NQX], both BN scales folded, packing.py c3d): its rows are loaded straight into B-operand fragments
 // (an sp32 row IS the fragment layout: 16 bytes hi + 16 bytes lo per lane group and K-step) and there is no residual.
-template <int P, int BM, bool NEXT, int NQX>
+//
+// PATCH (conv2 phase): instead of gathering a fresh [BM][32] activation tile per (tap, channel chunk) -- 9 x the bytes --
+// the block keeps, per 32-channel chunk, the HALO PATCH of its 128 consecutive positions resident in LDS: every image row
+// the positions touch plus one above and below, each with one zero slot left and right (image borders and the gap between
+// two images are zero rows / slots supplied by the DMA's bounds check).  A tap is then a constant slot offset
+// (dy * (W + 2) + dx) on the fragment reads, and only the weight tile streams per K-step (L2 -> LDS bytes of the phase
+// -37 % at planes 128).  Used at planes 128; see launch_bneck for why not at planes 64.
+template <int P, int BM, bool NEXT, int NQX, bool PATCH>
 __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
     constexpr int NQ = P / 32;            // K-steps of a P-channel contraction
     constexpr int NQT = NQ + NQX;         // K-steps of conv3 (+ downsample)
+    constexpr int PSLOTS = PATCH ? (P == 64 ? 456 : 304) : 0;  // patch slots (x 128 B): 10 rows x 30 (28x28); 8 x 57 would serve 55x55
     constexpr int NT = BM / 64;           // 16-position tiles per wave
     constexpr int NG = 4 * P / 32;        // 32-channel groups of the block output
     constexpr int TILE_A = (BM + P) * ROWB;
     constexpr int TILE_B = (32 * NQT + P) * ROWB;
-    constexpr int TILES = 2 * (TILE_A > TILE_B ? TILE_A : TILE_B);
+    constexpr int PHASE_A = PATCH ? PSLOTS * ROWB + 2 * P * ROWB : 2 * TILE_A;  // patch + two weight tiles, or two full stages
+    constexpr int TILES = PHASE_A > 2 * TILE_B ? PHASE_A : 2 * TILE_B;
     constexpr int NBIAS = 6 * P;  // b2 [P], b1n [P], b3 [4P]: read back as broadcast float4 pairs in the epilogues
     __shared__ __attribute__((aligned(16))) char smem[TILES + NBIAS * 4];
     float* sbias = reinterpret_cast<float*>(smem + TILES);
@@ -241,7 +250,84 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
     // ---------------- phase A: T2 = relu(bn2(conv3x3(T1))), K = 9 taps x P channels, accumulators [P][BM/4] per wave
     constexpr int A_ISS = BM / 32;  // A-tile DMA instructions per wave per K-step (8 rows each)
     constexpr int W_ISS = P / 32;
-    unsigned a_off[A_ISS], w_off[W_ISS];
+    unsigned w_off[W_ISS];
+#pragma unroll
+    for (int j = 0; j < W_ISS; ++j) {
+        const int row = wave * (W_ISS * 8) + j * 8 + lrow8;
+        w_off[j] = (unsigned)((long)row * (9 * P * 4) + ((slot ^ swz_key(row)) << 4));
+    }
+    f32x4_t acc2[P / 16][NT];
+#pragma unroll
+    for (int i = 0; i < P / 16; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc2[i][t] = f32x4_t{0};
+    if constexpr (PATCH) {
+        // virtual rows: image b, row y (-1 .. H) -> b * (H + 2) + y + 1; a virtual row has W + 2 slots (x = -1 .. W)
+        const int PW = p.Wd + 2, VH = p.H + 2;
+        const int m_last = min(m_base + BM, p.M) - 1;
+        const int b0 = m_base / (p.H * p.Wd), y0 = (m_base / p.Wd) % p.H;
+        const int b1 = m_last / (p.H * p.Wd), y1 = (m_last / p.Wd) % p.H;
+        const int vr0 = b0 * VH + y0;                       // one virtual row above the first position's row
+        const int nslots = (b1 * VH + y1 + 3 - vr0) * PW;   // ... through one below the last position's row (<= PSLOTS, checked on the host)
+        const int ninstr = (nslots + 7) >> 3;
+        constexpr int PI = (PSLOTS / 8 + 3) / 4;            // patch DMA instructions per wave (instruction ii = wave + 4 i)
+        unsigned p_off[PI];
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const int sl = (wave + 4 * i) * 8 + lrow8;
+            const int vr = vr0 + sl / PW, px = sl - (sl / PW) * PW;
+            const int b = vr / VH, yy = vr - b * VH - 1, xx = px - 1;
+            const bool ok = sl < nslots && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.Wd;
+            p_off[i] = ok ? (unsigned)(((long)(b * p.H + yy) * p.Wd + xx) * (P * 4) + ((slot ^ swz_key(sl)) << 4)) : OOB;
+        }
+        // slot of this lane's positions at tap (0, 0): position m -> (virtual row - vr0) * PW + x + 1
+        int sb[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int m = min(m_base + wave * (BM / 4) + t * 16 + l15, p.M - 1);
+            const int x = m % p.Wd, yb = m / p.Wd;           // yb = b * H + y
+            const int b = yb / p.H, y = yb - b * p.H;
+            sb[t] = (b * VH + y + 1 - vr0) * PW + x + 1;
+        }
+        char* patch = smem;
+        char* wt0 = smem + PSLOTS * ROWB;
+        for (int c = 0; c < NQ; ++c) {
+            // the previous chunk's last barrier freed the patch and both weight tiles
+#pragma unroll
+            for (int i = 0; i < PI; ++i)
+                if (wave + 4 * i < ninstr) dma16(t1rs, patch + (wave + 4 * i) * 1024, p_off[i], (unsigned)(c * ROWB));
+#pragma unroll
+            for (int j = 0; j < W_ISS; ++j) dma16(w2rs, wt0 + wave * (W_ISS * 1024) + j * 1024, w_off[j], (unsigned)(c * ROWB));
+            __syncthreads();
+            int cur = 0;
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 1 < 9) {
+#pragma unroll
+                    for (int j = 0; j < W_ISS; ++j)
+                        dma16(w2rs, wt0 + (cur ^ 1) * (P * ROWB) + wave * (W_ISS * 1024) + j * 1024, w_off[j],
+                              (unsigned)(((tap + 1) * P + 32 * c) * 4));
+                }
+                const int toff = (tap / 3 - 1) * PW + (tap % 3 - 1);
+                const char* sbw = wt0 + cur * (P * ROWB);
+                bf16x8_t ah[NT], al[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    ah[t] = ldfrag(patch, sb[t] + toff, g);
+                    al[t] = ldfrag(patch, sb[t] + toff, 4 + g);
+                }
+#pragma unroll
+                for (int i = 0; i < P / 16; ++i) {
+                    const bf16x8_t wh = ldfrag(sbw, i * 16 + l15, g), wl = ldfrag(sbw, i * 16 + l15, 4 + g);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) mfma3(acc2[i][t], wh, wl, ah[t], al[t]);
+                }
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+    } else {
+    unsigned a_off[A_ISS];
     int a_y[A_ISS], a_x[A_ISS];
 #pragma unroll
     for (int j = 0; j < A_ISS; ++j) {
@@ -254,16 +340,6 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
         a_x[j] = x;
         a_off[j] = (unsigned)((long)mm * (P * 4) + ((slot ^ swz_key(row)) << 4));
     }
-#pragma unroll
-    for (int j = 0; j < W_ISS; ++j) {
-        const int row = wave * (W_ISS * 8) + j * 8 + lrow8;
-        w_off[j] = (unsigned)((long)row * (9 * P * 4) + ((slot ^ swz_key(row)) << 4));
-    }
-    f32x4_t acc2[P / 16][NT];
-#pragma unroll
-    for (int i = 0; i < P / 16; ++i)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc2[i][t] = f32x4_t{0};
     {
         int ky = 0, kx = 0, kq = 0;
         unsigned wk = 0;
@@ -306,6 +382,7 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
             __syncthreads();
             cur ^= 1;
         }
+    }
     }
 
     // ---------------- weights of output group G -> LDS buffer (G & 1)
@@ -681,14 +758,25 @@ int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t
     const int grid = (int)((M + BM - 1) / BM);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     TRY(prof_begin(ctx, st, &ev0, &ev1));
+    // Resident halo patch for the conv2 phase: planes 128 only (28x28: -5..7 % per launch).  At planes 64 (55x55) the patch
+    // costs the third resident block (76 KiB of LDS) and measured +2..4 %, so that form keeps the per-tap gather.
+    // Worst case of the patch: the image rows 128 consecutive positions can touch (+ 2 when they cross into the next
+    // image) + 2 halo rows, W + 2 slots each, must fit the kernel's LDS image.
+    const int rows_worst = (w - 1 + BM + w - 1) / w + 2 + 2;
+    const bool patch = planes == 128 && (long)h * w >= BM && rows_worst * (w + 2) <= 304;
     if (ds_cin) {
-        bneck_kernel<64, BM, true, 2><<<dim3(grid), dim3(256), 0, st>>>(p);
+        bneck_kernel<64, BM, true, 2, false><<<dim3(grid), dim3(256), 0, st>>>(p);
     } else if (planes == 64) {
-        if (t1n) bneck_kernel<64, BM, true, 0><<<dim3(grid), dim3(256), 0, st>>>(p);
-        else bneck_kernel<64, BM, false, 0><<<dim3(grid), dim3(256), 0, st>>>(p);
+        if (t1n) bneck_kernel<64, BM, true, 0, false><<<dim3(grid), dim3(256), 0, st>>>(p);
+        else bneck_kernel<64, BM, false, 0, false><<<dim3(grid), dim3(256), 0, st>>>(p);
     } else {
-        if (t1n) bneck_kernel<128, BM, true, 0><<<dim3(grid), dim3(256), 0, st>>>(p);
-        else bneck_kernel<128, BM, false, 0><<<dim3(grid), dim3(256), 0, st>>>(p);
+        if (t1n) {
+            if (patch) bneck_kernel<128, BM, true, 0, true><<<dim3(grid), dim3(256), 0, st>>>(p);
+            else bneck_kernel<128, BM, true, 0, false><<<dim3(grid), dim3(256), 0, st>>>(p);
+        } else {
+            if (patch) bneck_kernel<128, BM, false, 0, true><<<dim3(grid), dim3(256), 0, st>>>(p);
+            else bneck_kernel<128, BM, false, 0, false><<<dim3(grid), dim3(256), 0, st>>>(p);
+        }
     }
     if (ev1) (void)hipEventRecord(ev1, st);
     hipError_t e = hipGetLastError();
