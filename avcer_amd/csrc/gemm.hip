@@ -63,6 +63,7 @@ struct GemmParams {
     int KH;
     int fast;  // pad-free gather with a scalar K / tap advance (see AVCER_ISSUE_TILES)
     int tile_n;  // 0 = choose, 64, 128
+    int tap_inner;  // K-steps walk (channel chunk, ky, kx) instead of (ky, kx, channel chunk): see launch_conv_gemm
 };
 
 // Epilogue, staged through LDS so that HBM sees whole 128-byte lines: every wave first parks its scaled/biased
@@ -496,11 +497,16 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
         if (!p.fast) {                                                                                              \
             _Pragma("unroll") for (int j = 0; j < B_ISS; ++j) dma16(wrs, sb_ + j * 1024, w_off[j] + wk);            \
         }                                                                                                           \
-        wk += ROWB;                                                                                                 \
-        kc += BK;                                                                                                   \
-        while (kc >= p.Cin) {                                                                                       \
-            kc -= p.Cin;                                                                                            \
-            if (++kx == p.KW) { kx = 0; ++ky; }                                                                     \
+        if (p.tap_inner) {                                                                                          \
+            if (++kx == p.KW) { kx = 0; if (++ky == p.KH) { ky = 0; kc += BK; } }                                   \
+            wk = (unsigned)(((ky * p.KW + kx) * p.Cin + kc) * ES);                                                  \
+        } else {                                                                                                    \
+            wk += ROWB;                                                                                             \
+            kc += BK;                                                                                               \
+            while (kc >= p.Cin) {                                                                                   \
+                kc -= p.Cin;                                                                                        \
+                if (++kx == p.KW) { kx = 0; ++ky; }                                                                 \
+            }                                                                                                       \
         }                                                                                                           \
     } while (0)
 
@@ -627,6 +633,13 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
     p.Y = (char*)y;
     p.M = (int)M; p.N = d.n; p.K = (int)K;
     p.OH = d.out_h; p.OW = d.out_w; p.H = d.in_h; p.Wd = d.in_w; p.Cin = d.cin; p.KW = d.kw; p.KH = d.kh;
+    // Multi-tap convolutions whose Cin is a whole number of K-steps walk K as (channel chunk, ky, kx): the taps of one
+    // chunk re-read the same or neighbouring pixels in CONSECUTIVE K-steps, while they are still in the XCD's 4 MiB L2.
+    // In (ky, kx, chunk) order a pixel comes back only after Cin/BK steps of every block of the XCD, and the 3x3 layers of
+    // stages 3-4 fetched 5.8-13 x their compulsory bytes through the fabric (per-dispatch FETCH_SIZE, round 2).  The
+    // weight rows are addressed by the same (ky, kx, chunk) offset, so the [N][kh][kw][Cin] layout is unchanged; only the
+    // order of the f32 accumulation differs.
+    p.tap_inner = !x2 && d.kh * d.kw > 1 && d.cin % bk == 0 && d.cin > bk;
     p.sh = d.stride_h; p.sw = d.stride_w; p.ph = d.pad_h; p.pw = d.pad_w; p.dh = d.dil_h; p.dw = d.dil_w;
     p.sB = d.x_stride_b; p.sH = d.x_stride_h; p.sW = d.x_stride_w; p.coff = d.x_coff;
     p.ldY = d.y_ld; p.yoff = d.y_coff; p.ldR = d.r_ld; p.roff = d.r_coff;
