@@ -565,16 +565,16 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
 // global memory straight into B fragments (an sp32 row is the fragment layout), OUT is written once and never re-read
 // by a conv1 launch.  64 positions per block (16 per wave), weights of one 32-channel output group at a time:
 // W3 group [32 rows][P] and W1N K-step [P rows][32] sit in two 32 KiB LDS halves that refill while the other is in use.
-template <int P>
-__global__ void __launch_bounds__(256, 2) bneck_tail_kernel(const BneckParams p) {
-    constexpr int BM = 64;
+template <int P, int NW>
+__global__ void __launch_bounds__(64 * NW, 2) bneck_tail_kernel(const BneckParams p) {
+    constexpr int BM = 16 * NW;     // 16 positions per wave; NW = 4 or 8 waves
     constexpr int NQ = P / 32;      // K-steps of conv3
     constexpr int NG = 4 * P / 32;  // 32-channel groups of the block output = K-steps of conv1'
     constexpr int W3B = 32 * NQ * ROWB, W1B = P * ROWB;
     constexpr int NBIAS = 5 * P;    // b1n [P], b3 [4P]
     __shared__ __attribute__((aligned(16))) char smem[W3B + W1B + NBIAS * 4];
     float* sbias = reinterpret_cast<float*>(smem + W3B + W1B);
-    for (int i = threadIdx.x; i < NBIAS; i += 256) sbias[i] = i < P ? p.b1n[i] : p.b3[i - P];
+    for (int i = threadIdx.x; i < NBIAS; i += 64 * NW) sbias[i] = i < P ? p.b1n[i] : p.b3[i - P];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
@@ -582,25 +582,29 @@ __global__ void __launch_bounds__(256, 2) bneck_tail_kernel(const BneckParams p)
     const int m_base = xcd_remap(blockIdx.x, gridDim.x) * BM;
     const auto w3rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W3), (short)0, 4 * P * P * 4, 0x00020000);
     const auto w1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W1N), (short)0, 4 * P * P * 4, 0x00020000);
-    constexpr int W_ISS = P / 32;   // DMA instructions per wave: W3 group = NQ tiles x 4 instr, W1N K-step = P/8 instr
-    unsigned g3_off[NQ], g1_off[W_ISS];
+    // DMA instructions (8 rows x 128 B each) per wave: W3 group = NQ tiles x 4 instr, W1N K-step = P / 8 instr, dealt over NW waves
+    constexpr int G3_ISS = NQ * 4 / NW, G1_ISS = P / 8 / NW;
+    unsigned g3_off[G3_ISS], g1_off[G1_ISS];
+    int g3_dst[G3_ISS];
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-        const int row = wave * 8 + lrow8;
-        g3_off[j] = (unsigned)((long)row * (P * 4) + j * ROWB + ((slot ^ swz_key(row)) << 4));
+    for (int j = 0; j < G3_ISS; ++j) {
+        const int ii = wave * G3_ISS + j;            // instruction ii: K-step tile ii / 4, rows 8 (ii % 4) .. + 8 of the 32-row group
+        const int row = (ii & 3) * 8 + lrow8;
+        g3_off[j] = (unsigned)((long)row * (P * 4) + (ii >> 2) * ROWB + ((slot ^ swz_key(row)) << 4));
+        g3_dst[j] = (ii >> 2) * (32 * ROWB) + (ii & 3) * 1024;
     }
 #pragma unroll
-    for (int j = 0; j < W_ISS; ++j) {
-        const int row = wave * (W_ISS * 8) + j * 8 + lrow8;
+    for (int j = 0; j < G1_ISS; ++j) {
+        const int row = (wave * G1_ISS + j) * 8 + lrow8;
         g1_off[j] = (unsigned)((long)row * (4 * P * 4) + ((slot ^ swz_key(row)) << 4));
     }
     auto issue_w3 = [&](int G) {
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) dma16(w3rs, smem + j * (32 * ROWB) + wave * 1024, g3_off[j], (unsigned)(G * 32 * P * 4));
+        for (int j = 0; j < G3_ISS; ++j) dma16(w3rs, smem + g3_dst[j], g3_off[j], (unsigned)(G * 32 * P * 4));
     };
     auto issue_w1 = [&](int G) {
 #pragma unroll
-        for (int j = 0; j < W_ISS; ++j) dma16(w1rs, smem + W3B + wave * (W_ISS * 1024) + j * 1024, g1_off[j], (unsigned)(G * ROWB));
+        for (int j = 0; j < G1_ISS; ++j) dma16(w1rs, smem + W3B + (wave * G1_ISS + j) * 1024, g1_off[j], (unsigned)(G * ROWB));
     };
     issue_w3(0);
 
@@ -795,10 +799,10 @@ int launch_bneck_tail(avcer_ctx* ctx, int planes, long M, const void* t2, const 
     p.T1 = (const char*)t2; p.X = (const char*)x; p.OUT = (char*)out; p.T1N = (char*)t1n;
     p.W3 = (const char*)w3; p.W1N = (const char*)w1n; p.b3 = b3; p.b1n = b1n;
     p.M = (int)M;
-    const int grid = (int)((M + 63) / 64);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     TRY(prof_begin(ctx, st, &ev0, &ev1));
-    bneck_tail_kernel<256><<<dim3(grid), dim3(256), 0, st>>>(p);
+    if (ctx->tail_waves == 4) bneck_tail_kernel<256, 4><<<dim3((int)((M + 63) / 64)), dim3(256), 0, st>>>(p);
+    else bneck_tail_kernel<256, 8><<<dim3((int)((M + 127) / 128)), dim3(512), 0, st>>>(p);
     if (ev1) (void)hipEventRecord(ev1, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "bneck_tail launch: %s", hipGetErrorString(e));

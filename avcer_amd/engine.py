@@ -99,6 +99,10 @@ class Engine:
     def set_static_batch(self, frames: int):
         self._check(self.lib.avcer_set_static_batch(self.ctx, int(frames)))
 
+    def set_option(self, name: str, value: int):
+        """Tuning knobs that never change results (include/avcer_hip.h: avcer_set_option)."""
+        self._check(self.lib.avcer_set_option(self.ctx, name.encode(), int(value)))
+
     # ------------------------------------------------------------------ forward passes
     def static_forward(self, frames_u8, mode: int = MODE_FP32):
         """frames u8 [N,H,W,3] RGB -> (logits [N,7], probs [N,7], feats [N,512] pre-ReLU)."""

@@ -73,6 +73,10 @@ int avcer_static_forward(avcer_ctx* ctx, const uint8_t* frames_hwc, int n, int i
 /* Frames per internal pass of the static CNN, 1..1024 (default 1024). Larger passes fill the chip on layers 3/4. */
 int avcer_set_static_batch(avcer_ctx* ctx, int frames);
 
+/* Tuning knobs that never change results (sweeps, A/B measurements).  "tail_waves" = 4 | 8: waves per block of the
+ * stage-3 conv3 + next-conv1 kernel. */
+int avcer_set_option(avcer_ctx* ctx, const char* name, int value);
+
 /* The same model on an already preprocessed tensor, i.e. the exact argument of the reference's
  * `pth_model_static(x)`:  x f32 [n,3,224,224] (BGR, mean-subtracted).   ref: get_prob_video.py:103-109 */
 int avcer_static_forward_nchw(avcer_ctx* ctx, const float* x, int n, int mode, float* logits, float* probs,
