@@ -835,10 +835,12 @@ __device__ __forceinline__ int att_swz(int row, int chunk) {
     return row * 128 + ((chunk ^ (int)((0x32765410u >> (((row >> 1) & 7) * 4)) & 7u)) << 4);
 }
 
-template <typename T, typename TO, int NKT, int X3>
+template <typename T, typename TO, int NKT, int X3, int D>
 __global__ void __launch_bounds__(256) attention_mfma_kernel(const T* __restrict__ qkv, TO* __restrict__ out, int s, int heads,
                                                            float scale) {
-    constexpr int D = 64;
+    static_assert(D == 64 || D == 32, "head dimension 64 (wav2vec2 layers, tl2) or 32 (tl1)");
+    constexpr int KS = D / 32;               // 32-wide K-steps of Q.K^T
+    constexpr int TV = D / 16;               // 16-row tiles of V^T / O^T
     constexpr int SP = NKT * 16;             // padded key count
     constexpr int VROW = SP * 2 + 16;        // bytes per V^T row (16-byte pad against bank conflicts)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -854,8 +856,8 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const T* __restrict
     const int g = lane >> 4, q16 = lane & 15;
 
     // ---- stage K (row-major) and V (transposed + permuted) as bf16 planes
-    for (int it = tid; it < SP * 8; it += 256) {
-        const int r = it >> 3, c = it & 7;   // key row, chunk of 8 head-dim elements
+    for (int it = tid; it < SP * (D / 8); it += 256) {
+        const int r = it / (D / 8), c = it % (D / 8);   // key row, chunk of 8 head-dim elements (K rows keep a 128-byte pitch)
         float kv[8], vv[8];
         if (r < s) {
             ld4<T>(base, (long)r * rowstride + e + 8 * c, kv);
@@ -890,9 +892,9 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const T* __restrict
     for (int tq = wv; tq < nqt; tq += 4) {
         const int qrow = tq * 16 + q16;
         // ---- Q fragments (B operand): this lane's query row, head-dim 32ks + 8g .. +7, pre-scaled
-        att_bf16x8_t qh[2], ql[2];
+        att_bf16x8_t qh[KS], ql[KS];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             float qv[8];
             if (qrow < s) {
                 ld4<T>(base, (long)qrow * rowstride + 32 * ks + 8 * g, qv);
@@ -915,7 +917,7 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const T* __restrict
         for (int t = 0; t < NKT; ++t) {
             sc[t] = att_f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
                 const int off = att_swz(t * 16 + q16, ks * 4 + g);
                 const att_bf16x8_t kh = *reinterpret_cast<const att_bf16x8_t*>(khi + off);
                 if (X3) {
@@ -949,9 +951,9 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const T* __restrict
         den += __shfl_xor(den, 16, 64);
         den += __shfl_xor(den, 32, 64);
         // ---- O^T = V^T . P^T over key blocks of 32
-        att_f32x4_t oc[4];
+        att_f32x4_t oc[TV];
 #pragma unroll
-        for (int tv = 0; tv < 4; ++tv) oc[tv] = att_f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int tv = 0; tv < TV; ++tv) oc[tv] = att_f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < NKT / 2; ++kb) {
             att_bf16x8_t ph, pl;
@@ -963,7 +965,7 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const T* __restrict
                 pl[j] = (__bf16)(x - (float)hh);
             }
 #pragma unroll
-            for (int tv = 0; tv < 4; ++tv) {
+            for (int tv = 0; tv < TV; ++tv) {
                 const int off = (tv * 16 + q16) * VROW + (kb * 4 + g) * 16;
                 const att_bf16x8_t vh = *reinterpret_cast<const att_bf16x8_t*>(vhi + off);
                 if (X3) {
@@ -978,7 +980,7 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const T* __restrict
         if (qrow < s) {
             const float inv = 1.f / den;
 #pragma unroll
-            for (int tv = 0; tv < 4; ++tv) {
+            for (int tv = 0; tv < TV; ++tv) {
                 float o4[4] = {oc[tv][0] * inv, oc[tv][1] * inv, oc[tv][2] * inv, oc[tv][3] * inv};
                 st4<TO>(out, ((long)b * s + qrow) * e + h * D + 16 * tv + 4 * g, o4);
             }
@@ -1283,23 +1285,25 @@ int k_attention(avcer_ctx* ctx, const void* qkv, void* out, int n, int s, int he
     if (in_kind == 2 || (in_kind == 1) != (out_kind == 1))
         return set_err(ctx, AVCER_EINVAL, "attention: unsupported storage combination %d -> %d", in_kind, out_kind);
     const int grid = n * heads;
-    // 64-wide heads in the bf16 / split-bf16 modes: QK^T and PV on the MFMA (the f32 mode keeps exact f32 arithmetic)
-    if (d == 64 && (in_kind == 1 || out_kind == 2)) {
+    // bf16 / split-bf16 modes: QK^T and PV on the MFMA, 64- and 32-wide heads (the f32 mode keeps exact f32 arithmetic)
+    if (in_kind == 1 || out_kind == 2) {
         const int nkt = s <= 128 ? 8 : 16;
         const int sp = nkt * 16, x3 = out_kind == 2;
-        const size_t lds_m = (size_t)sp * 128 * (x3 ? 2 : 1) + (size_t)64 * (sp * 2 + 16) * (x3 ? 2 : 1);
-#define ATTM(T, TO, NKT, X3)                                                                                          \
+        const size_t lds_m = (size_t)sp * 128 * (x3 ? 2 : 1) + (size_t)d * (sp * 2 + 16) * (x3 ? 2 : 1);
+#define ATTM(T, TO, NKT, X3, D)                                                                                       \
     do {                                                                                                              \
         static uint64_t attr_dev = 0; /* the attribute is per device: one bit per device index */                    \
         if (!((attr_dev >> (ctx->device & 63)) & 1)) {                                                                \
-            HIP_TRY(ctx, hipFuncSetAttribute((const void*)attention_mfma_kernel<T, TO, NKT, X3>,                      \
+            HIP_TRY(ctx, hipFuncSetAttribute((const void*)attention_mfma_kernel<T, TO, NKT, X3, D>,                   \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));               \
             attr_dev |= 1ull << (ctx->device & 63);                                                                   \
         }                                                                                                             \
-        attention_mfma_kernel<T, TO, NKT, X3><<<grid, 256, lds_m, st>>>((const T*)qkv, (TO*)out, s, heads, scale);    \
+        attention_mfma_kernel<T, TO, NKT, X3, D><<<grid, 256, lds_m, st>>>((const T*)qkv, (TO*)out, s, heads, scale); \
     } while (0)
-        if (x3) { if (nkt == 8) ATTM(float, sp32_t, 8, 1); else ATTM(float, sp32_t, 16, 1); }
-        else { if (nkt == 8) ATTM(bf16_t, bf16_t, 8, 0); else ATTM(bf16_t, bf16_t, 16, 0); }
+#define ATTM_D(T, TO, NKT, X3) do { if (d == 64) ATTM(T, TO, NKT, X3, 64); else ATTM(T, TO, NKT, X3, 32); } while (0)
+        if (x3) { if (nkt == 8) ATTM_D(float, sp32_t, 8, 1); else ATTM_D(float, sp32_t, 16, 1); }
+        else { if (nkt == 8) ATTM_D(bf16_t, bf16_t, 8, 0); else ATTM_D(bf16_t, bf16_t, 16, 0); }
+#undef ATTM_D
 #undef ATTM
         CHECK_LAUNCH(ctx, "attention_mfma");
         return AVCER_OK;
