@@ -302,6 +302,17 @@ class Engine:
         self._check(self.lib.avcer_measure_ceilings(self.ctx, C.byref(a), C.byref(b), self._stream()))
         return a.value, b.value
 
+    def stem_pool(self, planes_hi_lo, w_split, scale, bias, n: int):
+        """Kernel-level entry of the fused stem (csrc/fused.hip): planes int16 [2, n, 230, 230, 4] (bf16 hi plane, lo plane)
+        -> sp32 [n, 55, 55, 64] as int16 [n, 55, 55, 128]."""
+        planes = self._dev(planes_hi_lo, torch.int16)
+        if tuple(planes.shape) != (2, n, 230, 230, 4):
+            raise ValueError("stem_pool: planes [2, n, 230, 230, 4] int16 (bf16 bits)")
+        y = torch.empty(n, 55, 55, 128, dtype=torch.int16, device=self.device)
+        self._check(self.lib.avcer_stem_pool(self.ctx, _ptr(planes), n * 230 * 230 * 4 * 2, _ptr(w_split), _ptr(scale), _ptr(bias),
+                                             _ptr(y), n, self._stream()))
+        return y
+
     def gemm_stats(self, reset: bool = True):
         n, f = C.c_int64(0), C.c_double(0.0)
         self._check(self.lib.avcer_gemm_stats(self.ctx, C.byref(n), C.byref(f), int(reset)))

@@ -333,3 +333,31 @@ def test_bneck_chain_first_block_with_downsample(engine):
     e1 = (from_sp32(d_t1n.cpu()).permute(0, 3, 1, 2).double() - t1n).abs().max().item()
     print(f"bneck first block: max|out err| {e0:.2e} (max {out.abs().max().item():.1f}), max|t1n err| {e1:.2e}")
     assert e0 < 2e-5 * max(1.0, out.abs().max().item()) and e1 < 2e-5 * max(1.0, t1n.abs().max().item())
+
+
+def test_stem_pool_vs_float64(engine):
+    """conv 7x7/2 with TF-"same" padding (2 before, 3 after) + BN + ReLU + max-pool 3x3/2 (video.py:63-90,98-103,116-117) in
+    one launch, from the planar bf16 hi/lo image, against float64 torch ops."""
+    g = torch.Generator().manual_seed(11)
+    n = 3
+    img = torch.randn(n, 3, 224, 224, generator=g) * 60.0                 # preprocessed BGR - mean values
+    w = torch.randn(64, 3, 7, 7, generator=g) / (147 ** 0.5)
+    scale, bias = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    x = F.pad(img.double(), (2, 3, 2, 3))
+    ref = F.max_pool2d(F.relu(F.conv2d(x, w.double(), stride=2) * scale.double()[None, :, None, None] + bias.double()[None, :, None, None]),
+                       3, 2)                                               # [n, 64, 55, 55]
+    # zero-bordered NHWC4 image (border = the padding, 4th channel 0), split into bf16 hi / lo planes
+    pad = torch.zeros(n, 230, 230, 4)
+    pad[:, 2:226, 2:226, :3] = img.permute(0, 2, 3, 1)
+    hi = pad.to(torch.bfloat16)
+    lo = (pad - hi.float()).to(torch.bfloat16)
+    planes = torch.stack([hi.view(torch.int16), lo.view(torch.int16)])
+    w7 = torch.zeros(64, 7, 8, 4)
+    w7[:, :, :7, :3] = w.permute(0, 2, 3, 1)                               # [O][kh][kw][I] with kw, I zero-padded to 8 x 4
+    dev = engine.device
+    y = engine.stem_pool(planes.to(dev), engine.split_weight_rows(w7.reshape(64, 224)), scale.to(dev), bias.to(dev), n)
+    torch.cuda.synchronize()
+    got = from_sp32(y.cpu()).permute(0, 3, 1, 2).double()
+    err = (got - ref).abs().max().item()
+    print(f"stem_pool: max|err| {err:.2e} (max|ref| {ref.abs().max().item():.1f})")
+    assert err < 2e-5 * max(1.0, ref.abs().max().item())
