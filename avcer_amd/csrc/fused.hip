@@ -27,6 +27,22 @@ __device__ __forceinline__ void mfma3(f32x4_t& acc, const bf16x8_t wh, const bf1
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, acc, 0, 0, 0);
 }
 
+// Keeps every MFMA that produced these accumulators in front of what follows (a barrier): left alone, hipcc hoists the
+// s_waitcnt vmcnt(0) + s_barrier that ends a K-step above the last quarter to half of the step's MFMAs, and the LDS-DMA
+// issued at the top of the step gets that much less time to land.
+template <int A, int B>
+__device__ __forceinline__ void pin(f32x4_t (&acc)[A][B]) {
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int b = 0; b < B; ++b) asm volatile("" : "+v"(acc[a][b]));
+}
+template <int A>
+__device__ __forceinline__ void pin(f32x4_t (&acc)[A]) {
+#pragma unroll
+    for (int a = 0; a < A; ++a) asm volatile("" : "+v"(acc[a]));
+}
+
 __device__ __forceinline__ bf16x8_t ldfrag(const char* tile, int row, int chunk) {
     return *reinterpret_cast<const bf16x8_t*>(tile + swz(row, chunk));
 }
@@ -139,6 +155,7 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
 #pragma unroll
             for (int fm = 0; fm < 4; ++fm) mfma3(acc[fn][fm], wh, wl, ah[fm], al[fm]);
         }
+        pin(acc);
         __syncthreads();
         cur ^= 1;
     }
@@ -322,6 +339,7 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) mfma3(acc2[i][t], wh, wl, ah[t], al[t]);
                 }
+                pin(acc2);
                 __syncthreads();
                 cur ^= 1;
             }
@@ -379,6 +397,7 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) mfma3(acc2[i][t], wh, wl, ah[t], al[t]);
             }
+            pin(acc2);
             __syncthreads();
             cur ^= 1;
         }
@@ -527,6 +546,7 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) mfma3(acc1[i][t], wh, wl, oh[t], ol[t]);
             }
+            pin(acc1);
         }
         __syncthreads();
     };
@@ -665,6 +685,7 @@ __global__ void __launch_bounds__(64 * NW, 2) bneck_tail_kernel(const BneckParam
 #pragma unroll
         for (int i = 0; i < P / 16; ++i)
             mfma3(acc1[i], ldfrag(smem + W3B, i * 16 + l15, g), ldfrag(smem + W3B, i * 16 + l15, 4 + g), oh, ol);
+        pin(acc1);
         __syncthreads();  // W3 group G+1 has landed; every wave is done with the W1N half
     };
     for (int G = 0; G < NG; G += 2) {

@@ -542,6 +542,12 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
     for (int step = 0; step < nk; ++step) {
         if (step + 1 < nk) AVCER_ISSUE_TILES(cur ^ 1);
         mfma_step<MODE, BMT, BN, TILE_BYTES>(p, smem, cur, acc, wm, wn, lane);
+        // Keep every MFMA of this K-step in front of the barrier.  Left alone, hipcc hoists the s_waitcnt vmcnt(0) +
+        // s_barrier above the second half of them, so the DMA issued at the top of the step gets half a step to land.
+#pragma unroll
+        for (int a = 0; a < NFN; ++a)
+#pragma unroll
+            for (int b = 0; b < NFM; ++b) asm volatile("" : "+v"(acc[a][b]));
         __syncthreads();
         cur ^= 1;
     }
