@@ -66,6 +66,14 @@ __device__ __forceinline__ void unpack8(const uint4 h, const uint4 l, float (&r)
     }
 }
 
+// 8 consecutive floats from LDS by inline asm.  A ds_read that hipcc can see makes it drain every LDS-DMA in flight first
+// (s_waitcnt vmcnt(0): it cannot prove that the read does not alias the DMA destination), which would undo the counted
+// wait of bneck_tail2_kernel; the table read here was written long before (barriers in between).
+__device__ __forceinline__ void lds_read8(const float* ptr, f32x4_t& a, f32x4_t& b) {
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)ptr;
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(addr) : "memory");
+}
+
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7, idx = bid >> 3;
@@ -580,6 +588,7 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
 
 
 // ------------------------------------------------------------------------------------------------ bottleneck tail (wide stages)
+// (First form, kept as the fallback and for A/B: avcer_set_option "tail_waves" 4 | 8; the default 16 is bneck_tail2_kernel.)
 // Stage 3 (planes 256): the 3x3 convolution stays a plain conv_gemm launch (a wave cannot hold 256 x BM accumulators next
 // to the fragments), but conv3 + residual + ReLU and the NEXT block's conv1 still share one launch: T2 is read from
 // global memory straight into B fragments (an sp32 row is the fragment layout), OUT is written once and never re-read
@@ -709,6 +718,152 @@ __global__ void __launch_bounds__(64 * NW, 2) bneck_tail_kernel(const BneckParam
 }
 
 
+// Second form of the tail (the one launched): the block's VGPRs (228) leave room for ONE 8-wave block per CU, so nothing
+// else on the CU hides a stall, and the first form's two __syncthreads() per group each drain vmcnt to zero -- including the
+// residual loads just issued for two groups ahead, i.e. every group pays a whole HBM round trip.  Here the 133 KiB that one
+// block may use hold BOTH weight tiles twice: the DMA of group G+1 (W3 group and W1N K-step) is issued at the top of group G,
+// one raw s_barrier ends a group, and the wait in front of it is counted -- s_waitcnt vmcnt(4) leaves this group's two
+// stores and two residual loads in flight.  Every vector-memory instruction of the loop is issued unconditionally (rows
+// past M store through a buffer descriptor with an out-of-range offset, which the hardware drops), so the count is exact.
+template <int P>
+__global__ void __launch_bounds__(512, 2) bneck_tail2_kernel(const BneckParams p) {
+    constexpr int NW = 8;
+    constexpr int BM = 16 * NW;
+    constexpr int NQ = P / 32;      // K-steps of conv3
+    constexpr int NG = 4 * P / 32;  // 32-channel groups of the block output = K-steps of conv1'
+    constexpr int W3B = 32 * NQ * ROWB, W1B = P * ROWB;
+    constexpr int NBIAS = 5 * P;    // b1n [P], b3 [4P]
+    __shared__ __attribute__((aligned(16))) char smem[2 * W3B + 2 * W1B + NBIAS * 4];
+    float* sbias = reinterpret_cast<float*>(smem + 2 * W3B + 2 * W1B);
+    for (int i = threadIdx.x; i < NBIAS; i += 64 * NW) sbias[i] = i < P ? p.b1n[i] : p.b3[i - P];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const int lrow8 = lane >> 3, slot = lane & 7;
+    const int m_base = xcd_remap(blockIdx.x, gridDim.x) * BM;
+    const auto w3rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W3), (short)0, 4 * P * P * 4, 0x00020000);
+    const auto w1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W1N), (short)0, 4 * P * P * 4, 0x00020000);
+    const auto outrs = __builtin_amdgcn_make_buffer_rsrc(p.OUT, (short)0, (int)p.t1_bytes, 0x00020000);  // t1_bytes: bytes of OUT here
+    constexpr int G3_ISS = NQ * 4 / NW, G1_ISS = P / 8 / NW;
+    unsigned g3_off[G3_ISS], g1_off[G1_ISS];
+    int g3_dst[G3_ISS];
+#pragma unroll
+    for (int j = 0; j < G3_ISS; ++j) {
+        const int ii = wave * G3_ISS + j;
+        const int row = (ii & 3) * 8 + lrow8;
+        g3_off[j] = (unsigned)((long)row * (P * 4) + (ii >> 2) * ROWB + ((slot ^ swz_key(row)) << 4));
+        g3_dst[j] = (ii >> 2) * (32 * ROWB) + (ii & 3) * 1024;
+    }
+#pragma unroll
+    for (int j = 0; j < G1_ISS; ++j) {
+        const int row = (wave * G1_ISS + j) * 8 + lrow8;
+        g1_off[j] = (unsigned)((long)row * (4 * P * 4) + ((slot ^ swz_key(row)) << 4));
+    }
+    auto issue_weights = [&](int G) {  // both tiles of group G into the buffers of parity G & 1: G3_ISS + G1_ISS vector-memory operations
+        char* b3 = smem + (G & 1) * W3B;
+        char* b1 = smem + 2 * W3B + (G & 1) * W1B;
+#pragma unroll
+        for (int j = 0; j < G3_ISS; ++j) dma16(w3rs, b3 + g3_dst[j], g3_off[j], (unsigned)(G * 32 * P * 4));
+#pragma unroll
+        for (int j = 0; j < G1_ISS; ++j) dma16(w1rs, b1 + (wave * G1_ISS + j) * 1024, g1_off[j], (unsigned)(G * ROWB));
+    };
+    issue_weights(0);
+
+    const long m = (long)m_base + wave * 16 + l15;
+    const bool m_ok = m < p.M;
+    const long mc = m_ok ? m : 0;
+    const long x_row = mc * (4L * P * 4) + 16 * g;
+    const unsigned o_row = m_ok ? (unsigned)x_row : OOB;  // rows past M: the buffer store is dropped
+    bf16x8_t t2h[NQ], t2l[NQ];
+    {
+        const char* tp = p.T1 + mc * (P * 4L) + 16 * g;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            t2h[q] = *reinterpret_cast<const bf16x8_t*>(tp + q * 128);
+            t2l[q] = *reinterpret_cast<const bf16x8_t*>(tp + q * 128 + 64);
+        }
+    }
+    // Residual ring, two groups deep.  The loads are inline asm so that hipcc does not wait for them itself (inside the loop
+    // it can only drain to zero, DMA of the next group included); the counted wait that ends the previous group is what
+    // guarantees them, and it names the registers so that no use can be scheduled in front of it.
+    u32x4_t rh0, rl0, rh1, rl1;
+    const char* xrow_p = p.X + x_row;
+#define AVCER_LOAD_RES(G, H, L)                                                                              \
+    do {                                                                                                     \
+        const char* rp_ = xrow_p + (G) * 128;                                                                \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(H) : "v"(rp_) : "memory");                     \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(L) : "v"(rp_) : "memory");           \
+    } while (0)
+    AVCER_LOAD_RES(0, rh0, rl0);
+    AVCER_LOAD_RES(1, rh1, rl1);
+    f32x4_t acc1[P / 16];
+#pragma unroll
+    for (int i = 0; i < P / 16; ++i) acc1[i] = f32x4_t{0};
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rh0), "+v"(rl0), "+v"(rh1), "+v"(rl1)::"memory");
+    __syncthreads();  // weights of group 0 and the bias table are in LDS (this one drains everything, once)
+
+    // One 32-channel output group.  (H, L): residual of this group, reloaded for group G+2 once consumed; (HN, LN): residual
+    // of the next group, which the wait at the end guarantees.  Vector-memory operations of a wave, in order:
+    // [G3_ISS + G1_ISS DMA of group G+1] [2 stores] [2 residual loads of group G+2].
+#define AVCER_TAIL_GROUP(G, H, L, HN, LN)                                                                                      \
+    do {                                                                                                                       \
+        if ((G) + 1 < NG) issue_weights((G) + 1); /* buffers of the other parity: every wave left group G-1 at the barrier */  \
+        asm volatile("" ::: "memory");            /* nothing below may be hoisted above the DMA: the count relies on it */       \
+        const char* w3t = smem + ((G) & 1) * W3B;                                                                              \
+        const char* w1t = smem + 2 * W3B + ((G) & 1) * W1B;                                                                    \
+        f32x4_t acc3[2] = {f32x4_t{0}, f32x4_t{0}};                                                                            \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) _Pragma("unroll") for (int tp = 0; tp < 2; ++tp) {                      \
+            const char* wt = w3t + q * (32 * ROWB);                                                                            \
+            mfma3(acc3[tp], ldfrag(wt, tp * 16 + l15, g), ldfrag(wt, tp * 16 + l15, 4 + g), t2h[q], t2l[q]);                   \
+        }                                                                                                                      \
+        f32x4_t b0, b1;                                                                                                        \
+        lds_read8(sbias + P + 32 * (G) + 8 * g, b0, b1);                                                                       \
+        float r[8];                                                                                                            \
+        unpack8(__builtin_bit_cast(uint4, H), __builtin_bit_cast(uint4, L), r);                                                \
+        const float v[8] = {relu_nan(acc3[0][0] + b0[0] + r[0]), relu_nan(acc3[0][1] + b0[1] + r[1]),                          \
+                            relu_nan(acc3[0][2] + b0[2] + r[2]), relu_nan(acc3[0][3] + b0[3] + r[3]),                          \
+                            relu_nan(acc3[1][0] + b1[0] + r[4]), relu_nan(acc3[1][1] + b1[1] + r[5]),                          \
+                            relu_nan(acc3[1][2] + b1[2] + r[6]), relu_nan(acc3[1][3] + b1[3] + r[7])};                         \
+        bf16x8_t oh, ol;                                                                                                       \
+        split8v(v, oh, ol);                                                                                                    \
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, oh), outrs, o_row, (G) * 128, 0);                   \
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ol), outrs, o_row, (G) * 128 + 64, 0);              \
+        asm volatile("" ::: "memory");                                                                                         \
+        AVCER_LOAD_RES((G) + 2 < NG ? (G) + 2 : NG - 1, H, L); /* unconditional (the last two re-fetch group NG-1) */          \
+        _Pragma("unroll") for (int i = 0; i < P / 16; ++i)                                                                     \
+            mfma3(acc1[i], ldfrag(w1t, i * 16 + l15, g), ldfrag(w1t, i * 16 + l15, 4 + g), oh, ol);                            \
+        pin(acc1);                                                                                                             \
+        if ((G) + 1 < NG) {                                                                                                    \
+            /* the weight DMA of group G+1 and the residual of group G+1 have landed; still in flight: this group's two */     \
+            /* stores and its two residual loads */                                                                            \
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(HN), "+v"(LN)::"memory");                                                 \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
+            __builtin_amdgcn_s_barrier();                                                                                      \
+            asm volatile("" ::: "memory");                                                                                     \
+        }                                                                                                                      \
+    } while (0)
+    for (int G = 0; G < NG; G += 2) {
+        AVCER_TAIL_GROUP(G, rh0, rl0, rh1, rl1);
+        AVCER_TAIL_GROUP(G + 1, rh1, rl1, rh0, rl0);
+    }
+#undef AVCER_TAIL_GROUP
+#undef AVCER_LOAD_RES
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const float4 b0 = *reinterpret_cast<const float4*>(sbias + 32 * q + 8 * g), b1 = *reinterpret_cast<const float4*>(sbias + 32 * q + 8 * g + 4);
+        const f32x4_t lo4 = acc1[2 * q], hi4 = acc1[2 * q + 1];
+        const float v[8] = {relu_nan(lo4[0] + b0.x), relu_nan(lo4[1] + b0.y), relu_nan(lo4[2] + b0.z), relu_nan(lo4[3] + b0.w),
+                            relu_nan(hi4[0] + b1.x), relu_nan(hi4[1] + b1.y), relu_nan(hi4[2] + b1.z), relu_nan(hi4[3] + b1.w)};
+        bf16x8_t hi, lo;
+        split8v(v, hi, lo);
+        if (m_ok) {
+            char* yp = p.T1N + m * (P * 4L) + q * 128 + 16 * g;
+            *reinterpret_cast<bf16x8_t*>(yp) = hi;
+            *reinterpret_cast<bf16x8_t*>(yp + 64) = lo;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ on-box ceilings
 // Two micro-kernels that bench.py runs once to put MEASURED ceilings of this very GPU next to the guide's peaks:
 // back-to-back v_mfma_f32_16x16x32_bf16 on register operands (two waves per SIMD, 16 independent accumulators each,
@@ -822,7 +977,11 @@ int launch_bneck_tail(avcer_ctx* ctx, int planes, long M, const void* t2, const 
     p.M = (int)M;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     TRY(prof_begin(ctx, st, &ev0, &ev1));
-    if (ctx->tail_waves == 4) bneck_tail_kernel<256, 4><<<dim3((int)((M + 63) / 64)), dim3(256), 0, st>>>(p);
+    // the counted-wait form stores through a buffer descriptor: OUT must stay under 4 GiB (5 349 frames of 14 x 14)
+    if (ctx->tail_waves == 16 && M * 4096L < (1L << 32) - 4096) {
+        p.t1_bytes = (unsigned)(M * 4096L);
+        bneck_tail2_kernel<256><<<dim3((int)((M + 127) / 128)), dim3(512), 0, st>>>(p);
+    } else if (ctx->tail_waves == 4) bneck_tail_kernel<256, 4><<<dim3((int)((M + 63) / 64)), dim3(256), 0, st>>>(p);
     else bneck_tail_kernel<256, 8><<<dim3((int)((M + 127) / 128)), dim3(512), 0, st>>>(p);
     if (ev1) (void)hipEventRecord(ev1, st);
     hipError_t e = hipGetLastError();

@@ -73,8 +73,8 @@ int avcer_static_forward(avcer_ctx* ctx, const uint8_t* frames_hwc, int n, int i
 /* Frames per internal pass of the static CNN, 1..1024 (default 1024). Larger passes fill the chip on layers 3/4. */
 int avcer_set_static_batch(avcer_ctx* ctx, int frames);
 
-/* Tuning knobs that never change results (sweeps, A/B measurements).  "tail_waves" = 4 | 8: waves per block of the
- * stage-3 conv3 + next-conv1 kernel. */
+/* Tuning knobs that never change results (sweeps, A/B measurements).  "tail_waves" = 16 (default: the
+ * counted-wait form of the stage-3 conv3 + next-conv1 kernel) | 4 | 8 (waves per block of its first form). */
 int avcer_set_option(avcer_ctx* ctx, const char* name, int value);
 
 /* The same model on an already preprocessed tensor, i.e. the exact argument of the reference's

@@ -119,6 +119,21 @@ def test_static_resize_path(engine_static, sd_static):
     assert np.abs(probs.cpu().numpy() - ref).max() < PROB_TOL
 
 
+def test_stage3_tail_forms_are_bit_identical(engine_static):
+    """avcer_set_option("tail_waves"): the counted-wait tail kernel (16, default) and both block sizes of the first form
+    accumulate in the same order -- same bits, also on a position count that is not a multiple of the 128-row tile."""
+    frames = torch.from_numpy(synth.face_frames(5, 21))  # 21 * 196 = 4116 positions = 32 tiles + 20 rows
+    out = {}
+    try:
+        for waves in (16, 8, 4):
+            engine_static.set_option("tail_waves", waves)
+            out[waves] = [t.cpu() for t in engine_static.static_forward(frames, MODE_BF16X3)]
+    finally:
+        engine_static.set_option("tail_waves", 16)
+    for waves in (8, 4):
+        assert all(torch.equal(a, b) for a, b in zip(out[16], out[waves])), waves
+
+
 def test_static_batch_invariance_256(engine_static):
     """BASELINE config 2 size: results must not depend on batch composition (sub-batching at 256)."""
     frames = torch.from_numpy(synth.face_frames(99, 300))
