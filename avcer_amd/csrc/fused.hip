@@ -101,10 +101,23 @@ __device__ __forceinline__ int stage64(int row, int chunk) { return row * 256 + 
 // One block = one 8 x 7 tile of pooled outputs of one frame: the 17 x 15 stem positions under it are one 256-row
 // implicit-GEMM tile (K = 7 tap rows x 8 pixels x 4 channels, N = 64), the pool runs on the f32 image in LDS.
 // Neighbouring tiles recompute one shared stem row / column (255 positions per 224 useful ones).
+//
+// The A operand is never expanded: the 39 x 36-pixel patch of the (already padded) planar image under the tile is copied
+// to LDS once, as it lies in memory (hi plane, then lo plane; 22 KiB), and a fragment is read straight out of it -- the
+// 8 K-elements of lane group g in tap row ky are the 2 pixels x 4 channels at patch[(2 ry + ky)][2 rx + 2 g], 16
+// contiguous, 16-byte-aligned bytes.  (An im2col tile per tap row moved 224 KiB through the L2 -> LDS path per block.)
+// All seven weight tiles (56 KiB) arrive with the same burst, so the K loop has no barrier and no wait in it; the second
+// block of the CU computes while this one waits for its burst.  Rows of positions outside the 112 x 112 map read whatever
+// follows in memory (or zeros past the planes): each output row depends on its own A row only, and the pool never reads them.
 __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
-    constexpr int BM = 256, BN = 64, NK = 7;
-    constexpr int TILE = (BM + BN) * ROWB;  // 40 KiB
-    __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
+    constexpr int BN = 64, NK = 7;
+    constexpr int PROWS = 2 * (ST_RH - 1) + NK, PCH = (2 * (ST_RW - 1) + 8) / 2;  // 39 patch rows of 18 16-byte chunks (36 pixels)
+    constexpr int PLANE = PROWS * PCH * 16;                                       // 11 232 B per plane
+    constexpr int NCH = 2 * PROWS * PCH;                                          // 1 404 chunks
+    constexpr int WOFF = ((2 * PLANE + 1023) / 1024) * 1024;                      // weights behind the patch
+    constexpr int WT = BN * ROWB;                                                 // one tap row's weight tile, 8 KiB
+    constexpr int LDS_BYTES = WOFF + NK * WT > 256 * 256 ? WOFF + NK * WT : 256 * 256;
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
@@ -113,30 +126,27 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
 
     const auto prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.P), (short)0, (int)p.p_bytes, 0x00020000);
     const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W), (short)0, 64 * NK * ROWB, 0x00020000);
-    const int lrow8 = lane >> 3, slot = lane & 7;
-    unsigned a_off[8], w_off[2];
+    // patch: chunk c of the LDS image = chunk (c % 702) of plane c / 702; one DMA instruction copies 64 consecutive chunks
+    const unsigned origin = (unsigned)((((long)b * 230 + 4 * ST_TH * ty) * 230 + 4 * ST_TW * tx) * 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int row = wave * 64 + j * 8 + lrow8;
-        const int ry = row / ST_RW, rx = row - ry * ST_RW;
-        const int sy = 2 * ST_TH * ty + ry, sx = 2 * ST_TW * tx + rx;  // stem output position
-        const bool ok = row < ST_RH * ST_RW && sy <= 111 && sx <= 111;
-        const int c = slot ^ swz_key(row);  // data chunk: 0-3 = 8 pixels x 4 channels of the hi plane, 4-7 = lo plane
-        a_off[j] = ok ? (unsigned)((((long)b * 230 + 2 * sy) * 230 + 2 * sx) * 8 + (c & 3) * 16) + (c >> 2) * p.plane_bytes : OOB;
+    for (int j = 0; j < (NCH + 255) / 256; ++j) {
+        const int piece = wave + 4 * j;
+        const int c = piece * 64 + lane;
+        const int plane = c >= NCH / 2, ci = c - plane * (NCH / 2);
+        const int prow = ci / PCH, pc = ci - prow * PCH;
+        const unsigned off = c < NCH ? origin + (unsigned)(prow * (230 * 8) + pc * 16) + plane * p.plane_bytes : OOB;
+        if (piece * 64 < NCH) dma16(prs, smem + piece * 1024, off);
     }
+    // weights: tap row ky = rows [64][32 K] of p.W at column block ky, 8 DMA instructions of 8 rows each, swizzled like every tile
+    {
+        const int lrow8 = lane >> 3, slot = lane & 7;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = wave * 16 + j * 8 + lrow8;
-        w_off[j] = (unsigned)(row * (NK * ROWB) + ((slot ^ swz_key(row)) << 4));
+        for (int j = 0; j < NK * 8 / 4; ++j) {
+            const int piece = wave + 4 * j;  // 0 .. 55
+            const int ky = piece >> 3, row = (piece & 7) * 8 + lrow8;
+            dma16(wrs, smem + WOFF + piece * 1024, (unsigned)(row * (NK * ROWB) + ky * ROWB + ((slot ^ swz_key(row)) << 4)));
+        }
     }
-    auto issue = [&](int buf, int ky) {
-        char* sa = smem + buf * TILE + wave * (8 * 1024);
-        char* sb = smem + buf * TILE + BM * ROWB + wave * (2 * 1024);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dma16(prs, sa + j * 1024, a_off[j], (unsigned)(ky * 230 * 8));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) dma16(wrs, sb + j * 1024, w_off[j], (unsigned)(ky * ROWB));
-    };
 
     f32x4_t acc[4][4];  // [channel tile][position tile]: wave = 64 positions x 64 channels
 #pragma unroll
@@ -144,18 +154,22 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[a][c] = f32x4_t{0};
     const int g = lane >> 4, l15 = lane & 15;
-    issue(0, 0);
-    __syncthreads();
-    int cur = 0;
+    int abase[4];  // byte offset of this lane's fragment in tap row 0 of the hi plane
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm) {
+        const int row = wave * 64 + fm * 16 + l15;
+        const int ry = row / ST_RW, rx = row - ry * ST_RW;
+        abase[fm] = row < ST_RH * ST_RW ? ((2 * ry) * PCH + rx + g) * 16 : 0;
+    }
+    __syncthreads();  // patch and weights have landed
+#pragma unroll
     for (int ky = 0; ky < NK; ++ky) {
-        if (ky + 1 < NK) issue(cur ^ 1, ky + 1);
-        const char* sa = smem + cur * TILE;
-        const char* sb = sa + BM * ROWB;
+        const char* sb = smem + WOFF + ky * WT;
         bf16x8_t ah[4], al[4];
 #pragma unroll
         for (int fm = 0; fm < 4; ++fm) {
-            ah[fm] = ldfrag(sa, wave * 64 + fm * 16 + l15, g);
-            al[fm] = ldfrag(sa, wave * 64 + fm * 16 + l15, 4 + g);
+            ah[fm] = *reinterpret_cast<const bf16x8_t*>(smem + abase[fm] + ky * (PCH * 16));
+            al[fm] = *reinterpret_cast<const bf16x8_t*>(smem + PLANE + abase[fm] + ky * (PCH * 16));
         }
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) {
@@ -163,10 +177,9 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
 #pragma unroll
             for (int fm = 0; fm < 4; ++fm) mfma3(acc[fn][fm], wh, wl, ah[fm], al[fm]);
         }
-        pin(acc);
-        __syncthreads();
-        cur ^= 1;
     }
+    pin(acc);
+    __syncthreads();  // every wave is done with the patch: the f32 image below overwrites it
     // BN + ReLU, parked as an f32 [256 positions][64 channels] image (64 KiB of the 80 KiB tile buffers)
 #pragma unroll
     for (int fn = 0; fn < 4; ++fn) {

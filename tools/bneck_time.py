@@ -23,3 +23,20 @@ def run(planes, nb, hw, nxt, iters=5):
     e1.record(); torch.cuda.synchronize()
     print(f"bneck planes={planes} next={nxt}: {e0.elapsed_time(e1)/iters*1e3:8.1f} us")
 run(64, 1024, 55, True); run(64, 1024, 55, False); run(128, 1024, 28, True); run(128, 1024, 28, False)
+
+
+def run_stem(n=1024, iters=5):
+    planes = torch.randint(-3000, 3000, (2, n, 230, 230, 4), dtype=torch.int16, device=dev)
+    w = eng.split_weight_rows(torch.randn(64, 224, device=dev) * 0.05)
+    sc, bi = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+    for _ in range(2):
+        eng.stem_pool(planes, w, sc, bi, n)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        eng.stem_pool(planes, w, sc, bi, n)
+    e1.record(); torch.cuda.synchronize()
+    print(f"stem_pool {n} frames: {e0.elapsed_time(e1)/iters*1e3:8.1f} us")
+
+
+run_stem()
