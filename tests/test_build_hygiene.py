@@ -45,3 +45,19 @@ def test_library_reads_no_environment_and_exports_the_header():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert re.search(rf"\b{name}\b", defined), name
+
+
+def test_tail_kernel_asm_loaded_registers_are_untouched_until_their_wait(tmp_path):
+    """bneck_tail2_kernel loads its residual ring by inline asm, so only the counted `s_waitcnt vmcnt(4)` that names the
+    registers protects them; tools/audit_asm_loads.py checks the generated ISA for any earlier read or write."""
+    import importlib.util
+
+    asm = tmp_path / "fused.s"
+    flags = [f for f in build.FLAGS if f not in ("-fPIC", "-shared")]
+    r = subprocess.run([_hipcc()] + flags + ["-S", "--cuda-device-only", "-o", str(asm), os.path.join(CSRC, "fused.hip")],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    spec = importlib.util.spec_from_file_location("audit_asm_loads", os.path.join(os.path.dirname(CSRC), "..", "tools", "audit_asm_loads.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.audit(str(asm)) == []
