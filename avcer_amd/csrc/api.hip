@@ -1018,18 +1018,6 @@ extern "C" int avcer_set_static_batch(avcer_ctx* ctx, int frames) {
     return AVCER_OK;
 }
 
-// Tuning knobs that do not change results.  "tail_waves": 16 = bneck_tail2_kernel (default), 4 | 8 = waves per block of
-// bneck_tail_kernel.
-extern "C" int avcer_set_option(avcer_ctx* ctx, const char* name, int value) {
-    if (!ctx || !name) return AVCER_EINVAL;
-    if (strcmp(name, "tail_waves") == 0) {
-        if (value != 4 && value != 8 && value != 16) return set_err(ctx, AVCER_EINVAL, "tail_waves %d (4, 8 or 16)", value);
-        ctx->tail_waves = value;
-        return AVCER_OK;
-    }
-    return set_err(ctx, AVCER_EINVAL, "unknown option '%s'", name);
-}
-
 extern "C" int avcer_profile_enable(avcer_ctx* ctx, int on) {
     if (!ctx) return AVCER_EINVAL;
     ctx->prof = on != 0;

@@ -41,7 +41,6 @@ struct avcer_ctx {
     char err[512] = {0};
     Model stat, dyn, aud, face;
     int aud_classes = 0;
-    int tail_waves = 16;      // stage-3 tail: 16 = bneck_tail2_kernel (counted waits), 4 | 8 = waves per block of bneck_tail_kernel
     int static_batch = 1024;  // frames per internal pass of the static CNN (4 GiB buffer-descriptor limit at f32)
     // grow-only workspace arenas (activations), one per pipeline
     DevBuf ws[8];

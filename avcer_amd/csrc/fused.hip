@@ -601,139 +601,15 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
 
 
 // ------------------------------------------------------------------------------------------------ bottleneck tail (wide stages)
-// (First form, kept as the fallback and for A/B: avcer_set_option "tail_waves" 4 | 8; the default 16 is bneck_tail2_kernel.)
 // Stage 3 (planes 256): the 3x3 convolution stays a plain conv_gemm launch (a wave cannot hold 256 x BM accumulators next
 // to the fragments), but conv3 + residual + ReLU and the NEXT block's conv1 still share one launch: T2 is read from
 // global memory straight into B fragments (an sp32 row is the fragment layout), OUT is written once and never re-read
-// by a conv1 launch.  64 positions per block (16 per wave), weights of one 32-channel output group at a time:
-// W3 group [32 rows][P] and W1N K-step [P rows][32] sit in two 32 KiB LDS halves that refill while the other is in use.
-template <int P, int NW>
-__global__ void __launch_bounds__(64 * NW, 2) bneck_tail_kernel(const BneckParams p) {
-    constexpr int BM = 16 * NW;     // 16 positions per wave; NW = 4 or 8 waves
-    constexpr int NQ = P / 32;      // K-steps of conv3
-    constexpr int NG = 4 * P / 32;  // 32-channel groups of the block output = K-steps of conv1'
-    constexpr int W3B = 32 * NQ * ROWB, W1B = P * ROWB;
-    constexpr int NBIAS = 5 * P;    // b1n [P], b3 [4P]
-    __shared__ __attribute__((aligned(16))) char smem[W3B + W1B + NBIAS * 4];
-    float* sbias = reinterpret_cast<float*>(smem + W3B + W1B);
-    for (int i = threadIdx.x; i < NBIAS; i += 64 * NW) sbias[i] = i < P ? p.b1n[i] : p.b3[i - P];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, l15 = lane & 15;
-    const int lrow8 = lane >> 3, slot = lane & 7;
-    const int m_base = xcd_remap(blockIdx.x, gridDim.x) * BM;
-    const auto w3rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W3), (short)0, 4 * P * P * 4, 0x00020000);
-    const auto w1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W1N), (short)0, 4 * P * P * 4, 0x00020000);
-    // DMA instructions (8 rows x 128 B each) per wave: W3 group = NQ tiles x 4 instr, W1N K-step = P / 8 instr, dealt over NW waves
-    constexpr int G3_ISS = NQ * 4 / NW, G1_ISS = P / 8 / NW;
-    unsigned g3_off[G3_ISS], g1_off[G1_ISS];
-    int g3_dst[G3_ISS];
-#pragma unroll
-    for (int j = 0; j < G3_ISS; ++j) {
-        const int ii = wave * G3_ISS + j;            // instruction ii: K-step tile ii / 4, rows 8 (ii % 4) .. + 8 of the 32-row group
-        const int row = (ii & 3) * 8 + lrow8;
-        g3_off[j] = (unsigned)((long)row * (P * 4) + (ii >> 2) * ROWB + ((slot ^ swz_key(row)) << 4));
-        g3_dst[j] = (ii >> 2) * (32 * ROWB) + (ii & 3) * 1024;
-    }
-#pragma unroll
-    for (int j = 0; j < G1_ISS; ++j) {
-        const int row = (wave * G1_ISS + j) * 8 + lrow8;
-        g1_off[j] = (unsigned)((long)row * (4 * P * 4) + ((slot ^ swz_key(row)) << 4));
-    }
-    auto issue_w3 = [&](int G) {
-#pragma unroll
-        for (int j = 0; j < G3_ISS; ++j) dma16(w3rs, smem + g3_dst[j], g3_off[j], (unsigned)(G * 32 * P * 4));
-    };
-    auto issue_w1 = [&](int G) {
-#pragma unroll
-        for (int j = 0; j < G1_ISS; ++j) dma16(w1rs, smem + W3B + (wave * G1_ISS + j) * 1024, g1_off[j], (unsigned)(G * ROWB));
-    };
-    issue_w3(0);
-
-    const long m = (long)m_base + wave * 16 + l15;
-    const bool m_ok = m < p.M;
-    const long mc = m_ok ? m : 0;
-    const long x_row = mc * (4L * P * 4) + 16 * g;
-    // T2 of this lane's position as B fragments: K-step q = channels 32q..32q+31, lane group g holds 8g..8g+7
-    bf16x8_t t2h[NQ], t2l[NQ];
-    {
-        const char* tp = p.T1 + mc * (P * 4L) + 16 * g;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            t2h[q] = *reinterpret_cast<const bf16x8_t*>(tp + q * 128);
-            t2l[q] = *reinterpret_cast<const bf16x8_t*>(tp + q * 128 + 64);
-        }
-    }
-    uint4 rh[2], rl[2];
-    auto load_res = [&](int G, uint4& h, uint4& l) {
-        const char* rp = p.X + x_row + G * 128;
-        h = *reinterpret_cast<const uint4*>(rp);
-        l = *reinterpret_cast<const uint4*>(rp + 64);
-    };
-    load_res(0, rh[0], rl[0]);
-    load_res(1, rh[1], rl[1]);
-    f32x4_t acc1[P / 16];
-#pragma unroll
-    for (int i = 0; i < P / 16; ++i) acc1[i] = f32x4_t{0};
-    __syncthreads();  // W3 group 0 and the bias table are in LDS
-
-    auto group = [&](int G, uint4& h, uint4& l) {
-        issue_w1(G);  // the W1N half is free: phase C of the previous group ended on a barrier
-        f32x4_t acc3[2] = {f32x4_t{0}, f32x4_t{0}};
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int tp = 0; tp < 2; ++tp) {
-                const char* wt = smem + q * (32 * ROWB);
-                mfma3(acc3[tp], ldfrag(wt, tp * 16 + l15, g), ldfrag(wt, tp * 16 + l15, 4 + g), t2h[q], t2l[q]);
-            }
-        const float* bp = sbias + P + 32 * G + 8 * g;
-        const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
-        float r[8];
-        unpack8(h, l, r);
-        const float v[8] = {relu_nan(acc3[0][0] + b0.x + r[0]), relu_nan(acc3[0][1] + b0.y + r[1]), relu_nan(acc3[0][2] + b0.z + r[2]),
-                            relu_nan(acc3[0][3] + b0.w + r[3]), relu_nan(acc3[1][0] + b1.x + r[4]), relu_nan(acc3[1][1] + b1.y + r[5]),
-                            relu_nan(acc3[1][2] + b1.z + r[6]), relu_nan(acc3[1][3] + b1.w + r[7])};
-        bf16x8_t oh, ol;
-        split8v(v, oh, ol);
-        if (m_ok) {
-            char* yp = p.OUT + x_row + G * 128;
-            *reinterpret_cast<bf16x8_t*>(yp) = oh;
-            *reinterpret_cast<bf16x8_t*>(yp + 64) = ol;
-        }
-        if (G + 2 < NG) load_res(G + 2, h, l);
-        __syncthreads();  // W1N K-step G has landed; every wave is done with the W3 half
-        if (G + 1 < NG) issue_w3(G + 1);
-#pragma unroll
-        for (int i = 0; i < P / 16; ++i)
-            mfma3(acc1[i], ldfrag(smem + W3B, i * 16 + l15, g), ldfrag(smem + W3B, i * 16 + l15, 4 + g), oh, ol);
-        pin(acc1);
-        __syncthreads();  // W3 group G+1 has landed; every wave is done with the W1N half
-    };
-    for (int G = 0; G < NG; G += 2) {
-        group(G, rh[0], rl[0]);
-        group(G + 1, rh[1], rl[1]);
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const float4 b0 = *reinterpret_cast<const float4*>(sbias + 32 * q + 8 * g), b1 = *reinterpret_cast<const float4*>(sbias + 32 * q + 8 * g + 4);
-        const f32x4_t lo4 = acc1[2 * q], hi4 = acc1[2 * q + 1];
-        const float v[8] = {relu_nan(lo4[0] + b0.x), relu_nan(lo4[1] + b0.y), relu_nan(lo4[2] + b0.z), relu_nan(lo4[3] + b0.w),
-                            relu_nan(hi4[0] + b1.x), relu_nan(hi4[1] + b1.y), relu_nan(hi4[2] + b1.z), relu_nan(hi4[3] + b1.w)};
-        bf16x8_t hi, lo;
-        split8v(v, hi, lo);
-        if (m_ok) {
-            char* yp = p.T1N + m * (P * 4L) + q * 128 + 16 * g;
-            *reinterpret_cast<bf16x8_t*>(yp) = hi;
-            *reinterpret_cast<bf16x8_t*>(yp + 64) = lo;
-        }
-    }
-}
-
-
-// Second form of the tail (the one launched): the block's VGPRs (228) leave room for ONE 8-wave block per CU, so nothing
-// else on the CU hides a stall, and the first form's two __syncthreads() per group each drain vmcnt to zero -- including the
-// residual loads just issued for two groups ahead, i.e. every group pays a whole HBM round trip.  Here the 133 KiB that one
+// by a conv1 launch.  128 positions per block (16 per wave), weights of one 32-channel output group at a time.
+//
+// A first form of this kernel (two 32 KiB LDS halves, two __syncthreads() per group) is archived with its bit-identity
+// evidence in profiles/experiments/r02_bneck_tail_first_form.hip.txt: its 228 VGPRs leave room for ONE 8-wave block per
+// CU, so nothing else on the CU hides a stall, and each of its barriers drains vmcnt to zero -- including the residual
+// loads just issued for two groups ahead, i.e. every group pays a whole HBM round trip.  Here the 133 KiB that one
 // block may use hold BOTH weight tiles twice: the DMA of group G+1 (W3 group and W1N K-step) is issued at the top of group G,
 // one raw s_barrier ends a group, and the wait in front of it is counted -- s_waitcnt vmcnt(4) leaves this group's two
 // stores and two residual loads in flight.  Every vector-memory instruction of the loop is issued unconditionally (rows
@@ -861,6 +737,10 @@ __global__ void __launch_bounds__(512, 2) bneck_tail2_kernel(const BneckParams p
     }
 #undef AVCER_TAIL_GROUP
 #undef AVCER_LOAD_RES
+    // The last two groups re-fetched group NG-1 into the ring (the count needs every group to issue the same operations) and
+    // nothing consumed those loads: wait for them HERE, naming the registers, so that they stay allocated until the data
+    // has landed -- hipcc does not know an asm load is asynchronous and could otherwise hand the registers to the epilogue.
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rh0), "+v"(rl0), "+v"(rh1), "+v"(rl1)::"memory");
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const float4 b0 = *reinterpret_cast<const float4*>(sbias + 32 * q + 8 * g), b1 = *reinterpret_cast<const float4*>(sbias + 32 * q + 8 * g + 4);
@@ -983,6 +863,9 @@ int launch_bneck_tail(avcer_ctx* ctx, int planes, long M, const void* t2, const 
                       const float* b3, const void* w1n, const float* b1n, hipStream_t st) {
     if (!t2 || !x || !out || !t1n || !w3 || !b3 || !w1n || !b1n || M <= 0) return set_err(ctx, AVCER_EINVAL, "bneck_tail: bad arguments");
     if (planes != 256) return set_err(ctx, AVCER_EINVAL, "bneck_tail: planes %d (256)", planes);
+    // OUT is stored through a buffer descriptor (rows past M are dropped by its bounds check): it must stay under 4 GiB,
+    // i.e. 5 349 frames of 14 x 14 -- a back pass of the static CNN is at most 2 048
+    if (M * 4096L >= (1L << 32) - 4096) return set_err(ctx, AVCER_EINVAL, "bneck_tail: M=%ld exceeds the 4 GiB descriptor range", M);
     BneckParams p;
     memset(&p, 0, sizeof(p));
     p.T1 = (const char*)t2; p.X = (const char*)x; p.OUT = (char*)out; p.T1N = (char*)t1n;
@@ -990,12 +873,8 @@ int launch_bneck_tail(avcer_ctx* ctx, int planes, long M, const void* t2, const 
     p.M = (int)M;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     TRY(prof_begin(ctx, st, &ev0, &ev1));
-    // the counted-wait form stores through a buffer descriptor: OUT must stay under 4 GiB (5 349 frames of 14 x 14)
-    if (ctx->tail_waves == 16 && M * 4096L < (1L << 32) - 4096) {
-        p.t1_bytes = (unsigned)(M * 4096L);
-        bneck_tail2_kernel<256><<<dim3((int)((M + 127) / 128)), dim3(512), 0, st>>>(p);
-    } else if (ctx->tail_waves == 4) bneck_tail_kernel<256, 4><<<dim3((int)((M + 63) / 64)), dim3(256), 0, st>>>(p);
-    else bneck_tail_kernel<256, 8><<<dim3((int)((M + 127) / 128)), dim3(512), 0, st>>>(p);
+    p.t1_bytes = (unsigned)(M * 4096L);
+    bneck_tail2_kernel<256><<<dim3((int)((M + 127) / 128)), dim3(512), 0, st>>>(p);
     if (ev1) (void)hipEventRecord(ev1, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "bneck_tail launch: %s", hipGetErrorString(e));

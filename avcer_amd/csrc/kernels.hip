@@ -220,9 +220,10 @@ __global__ void face_decode_kernel(const float* __restrict__ loc, const float* _
 // retina_face_predictor.py:86-108 + py_cpu_nms.py:11-39 on the GPU: confidence floor, descending-score order, greedy
 // NMS with the "+1 pixel" areas, top-k, final threshold.  Two kernels per batch of frames:
 //   face_rank_kernel   position of every candidate (score > conf_thresh) in the descending order of py_cpu_nms
-//                      (`scores.argsort()[: -top_k - 1 : -1]`; equal scores: the lower prior index first, i.e. a stable
-//                      descending sort -- numpy's default argsort leaves the order of ties undefined) by counting,
-//                      written as order[rank] = prior index
+//                      (`scores.argsort()[: -top_k - 1 : -1]`: an ascending sort read backwards, so wherever that sort
+//                      keeps tied scores in index order -- numpy's default does on short arrays, `kind="stable"` always
+//                      -- ties are visited HIGHER prior index first; that is the rule here) by counting, written as
+//                      order[rank] = prior index
 //   face_nms_kernel    one workgroup per frame: the top nms_top_k boxes sit in LDS, boxes are visited in order, a kept
 //                      box clears every later box whose IoU with it exceeds the threshold (one barrier per KEPT box)
 // f32 arithmetic in numpy's evaluation order, contraction off, so the keep decisions are the reference's.
@@ -244,7 +245,7 @@ __global__ void face_rank_kernel(const float* __restrict__ dets, int P, float co
             const int lim = min(256, P - j0);
             for (int k = 0; k < lim; ++k) {
                 const float sj = sc[k];
-                rank += (sj > conf_thresh) && (sj > si || (sj == si && j0 + k < i));
+                rank += (sj > conf_thresh) && (sj > si || (sj == si && j0 + k > i));
             }
         }
     }

@@ -99,10 +99,6 @@ class Engine:
     def set_static_batch(self, frames: int):
         self._check(self.lib.avcer_set_static_batch(self.ctx, int(frames)))
 
-    def set_option(self, name: str, value: int):
-        """Tuning knobs that never change results (include/avcer_hip.h: avcer_set_option)."""
-        self._check(self.lib.avcer_set_option(self.ctx, name.encode(), int(value)))
-
     # ------------------------------------------------------------------ forward passes
     def static_forward(self, frames_u8, mode: int = MODE_FP32):
         """frames u8 [N,H,W,3] RGB -> (logits [N,7], probs [N,7], feats [N,512] pre-ReLU)."""
@@ -271,7 +267,8 @@ class Engine:
         return int(self.lib.avcer_debug_tap_copied(self.ctx))
 
     def split_weights(self, w):
-        """f32 [N,K] -> split-bf16 layout for conv_gemm dtype 3 (returned as an int16 tensor of 2*N*K entries)."""
+        """f32 tensor (numel a multiple of 32) -> sp32 ACTIVATION layout (hi / lo bf16 per group of 32; int16 tensor of
+        2 * numel entries): the A operand of conv_gemm dtypes 5 / 6.  Not valid for weights: use split_weight_rows."""
         w = self._dev(w, torch.float32)
         out = torch.empty(w.numel() * 2, dtype=torch.int16, device=self.device)
         self._check(self.lib.avcer_split_weights(self.ctx, _ptr(w), _ptr(out), w.numel(), self._stream()))

@@ -7,9 +7,10 @@ Mirrors, with the reference's names and argument meaning:
   * `SimpleFaceTracker`                                   utils/simple_face_tracker.py:10-90     -> SimpleFaceTracker
   * `VideoPredictor.process`                              data/get_face_images.py:38-63          -> VideoTiler.process
 
-What runs where: box / landmark decoding and the crop + NEAREST resize into the u8 tile buffer are HIP kernels
-(`avcer_face_decode`, `avcer_crop_tiles`); the confidence filter, NMS, top-k and the IoU/Hungarian tracker act on a few
-dozen boxes per frame and stay on the host, as in the reference (numpy / scipy there too).  The RetinaFace-R50
+What runs where: box / landmark decoding, the confidence filter + NMS + top-k + final threshold (one launch per batch
+of frames, only the kept rows return to the host) and the crop + NEAREST resize into the u8 tile buffer are HIP kernels
+(`avcer_face_decode`, `avcer_face_nms`, `avcer_crop_tiles`); the IoU/Hungarian tracker acts on a handful of boxes per
+frame, is sequential in time and stays on the host, as in the reference (scipy there too).  The RetinaFace-R50
 network runs on the same implicit-GEMM kernel as the recognition models (`avcer_face_forward`, mirror
 `RetinaFacePredictor` below).  Tiles go straight to `avcer_static_forward`; the reference's JPEG file round trip
 (cv2.imwrite -> PIL.Image.open) is gone, which is the only intended difference.  Video decoding is not part of this build.
@@ -89,7 +90,7 @@ class FaceDetections:
 
 class RetinaFacePredictor:
     """`RetinaFacePredictor(threshold, device, model)` (retina_face_predictor.py:17-108) on the HIP path: the network,
-    box decoding and the host-side filter / NMS / top-k.  `state_dict` = RetinaFace(cfg_re50).state_dict() (the file
+    box decoding and the device-side filter / NMS / top-k (`FaceDetections`).  `state_dict` = RetinaFace(cfg_re50).state_dict() (the file
     `Resnet50_Final.pth`, with or without the `module.` prefix)."""
 
     def __init__(self, engine, state_dict, threshold: float = 0.8, mode: int = 0):

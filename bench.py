@@ -132,7 +132,6 @@ def parse():
     ap.add_argument("--parity-clips", type=int, default=2)
     ap.add_argument("--no-configs", action="store_true", help="skip the per-model BASELINE configs 2 and 3")
     ap.add_argument("--overlap", action="store_true", help="experiment: audio branch on its own HIP stream")
-    ap.add_argument("--option", action="append", default=[], metavar="NAME=INT", help="avcer_set_option tuning knob (A/B runs)")
     ap.add_argument("--no-events", action="store_true", help="diagnostic: time the steps without the per-launch HIP events "
                                                             "(the roofline object is then empty)")
     return ap.parse_args()
@@ -379,8 +378,6 @@ def main():
     log(f"rank {rank}/{world}: building pipeline (synthetic weights, seed 42)")
     pipe = AVPipeline(device=local_rank, seed=42, mode=modes[args.mode])
     pipe.overlap_branches = bool(args.overlap)
-    for kv in args.option:
-        pipe.engine.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     log("generating inputs")
     frames, wav = make_inputs(args.clips, rank, device)
     n_total = args.clips * world

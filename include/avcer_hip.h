@@ -73,10 +73,6 @@ int avcer_static_forward(avcer_ctx* ctx, const uint8_t* frames_hwc, int n, int i
 /* Frames per internal pass of the static CNN, 1..1024 (default 1024). Larger passes fill the chip on layers 3/4. */
 int avcer_set_static_batch(avcer_ctx* ctx, int frames);
 
-/* Tuning knobs that never change results (sweeps, A/B measurements).  "tail_waves" = 16 (default: the
- * counted-wait form of the stage-3 conv3 + next-conv1 kernel) | 4 | 8 (waves per block of its first form). */
-int avcer_set_option(avcer_ctx* ctx, const char* name, int value);
-
 /* The same model on an already preprocessed tensor, i.e. the exact argument of the reference's
  * `pth_model_static(x)`:  x f32 [n,3,224,224] (BGR, mean-subtracted).   ref: get_prob_video.py:103-109 */
 int avcer_static_forward_nchw(avcer_ctx* ctx, const float* x, int n, int mode, float* logits, float* probs,
@@ -141,8 +137,10 @@ int avcer_face_forward(avcer_ctx* ctx, const uint8_t* frames, int n, int h, int 
  *        retina_face/py_cpu_nms.py:11-39 (greedy NMS, "+1 pixel" areas, visit order = descending score).
  * dets f32 [n_frames, n_priors, 15] as avcer_face_decode writes them; out f32 [n_frames, top_k, 15] receives, per frame,
  * the kept rows in the reference's order; out_n i32 [n_frames] their number.  nms_top_k <= 6144, top_k <= 1024.
- * Equal scores are visited lower prior index first (a stable descending sort); numpy's default argsort does not define
- * the order of ties, so for exactly tied scores a given numpy build may visit (and keep) a different member of the tie. */
+ * Equal scores are visited HIGHER prior index first: the reference's `scores.argsort()[::-1]` is an ascending sort read
+ * backwards, so this is its order wherever that sort keeps ties in index order (`kind="stable"`; numpy's default sort on
+ * short arrays).  On long arrays numpy's default sort does not define the order of ties, so for exactly tied scores a
+ * given numpy build may visit (and keep) a different member of the tie. */
 int avcer_face_nms(avcer_ctx* ctx, const float* dets, int n_frames, int n_priors, float conf_thresh, float nms_thresh,
                    int nms_top_k, int top_k, float threshold, float* out, int32_t* out_n, avcer_stream_t stream);
 
@@ -233,8 +231,11 @@ int avcer_bneck_chain(avcer_ctx* ctx, int planes, int nb, int h, int w, const vo
 int avcer_stem_pool(avcer_ctx* ctx, const void* planes_hi_lo, size_t plane_bytes, const void* w, const float* scale,
                     const float* bias, void* y, int n, avcer_stream_t stream);
 
-/* Weight layout of dtype 3: for every group of 32 K-elements, 32 bf16 "hi" values then 32 bf16 "lo" values with
- * w = hi + lo (+ O(2^-17 |w|)).  w f32 [n*k] (k a multiple of 32) -> out, same size in bytes. Both device pointers. */
+/* The sp32 split of an ACTIVATION tensor (what a producer's epilogue writes with dtype 4 / 5): for every group of 32
+ * elements, 32 bf16 "hi" values then 32 bf16 "lo" values with x = hi + lo (+ O(2^-17 |x|)).  x f32 [numel] (a multiple
+ * of 32) -> out, same size in bytes.  Both device pointers.  NOT a weight layout: the weights of dtypes 3-6 additionally
+ * need their rows permuted (avcer_split_weight_rows below); a weight matrix split with this call would come out with
+ * its output channels silently permuted inside every group of 32. */
 int avcer_split_weights(avcer_ctx* ctx, const float* w, void* out, size_t numel, avcer_stream_t stream);
 
 /* The split of a WEIGHT matrix w f32 [n][k] (n, k multiples of 32) as the split-bf16 contractions (dtype 3-6 of

@@ -62,11 +62,13 @@ def decode_landm(pre, priors, variance=VARIANCE) -> np.ndarray:
     return out
 
 
-def nms(dets, thresh, top_k):
-    """py_cpu_nms.py:11-39 (areas with the +1 pixel convention, float32)."""
+def nms(dets, thresh, top_k, stable=False):
+    """py_cpu_nms.py:11-39 (areas with the +1 pixel convention, float32).  `stable`: the same expression with
+    `argsort(kind="stable")`, which pins the order of exactly tied scores (higher index first after the reversal);
+    numpy's default sort leaves it unspecified on long arrays."""
     x1, y1, x2, y2, scores = (dets[:, c] for c in range(5))
     areas = (x2 - x1 + 1) * (y2 - y1 + 1)
-    order = list(scores.argsort()[: -top_k - 1: -1])
+    order = list((scores.argsort(kind="stable") if stable else scores.argsort())[: -top_k - 1: -1])
     keep = []
     while order:
         i = order.pop(0)
@@ -82,7 +84,7 @@ def nms(dets, thresh, top_k):
     return keep
 
 
-def detections(loc, conf, landms, image_size, threshold=0.8) -> np.ndarray:
+def detections(loc, conf, landms, image_size, threshold=0.8, stable=False) -> np.ndarray:
     """retina_face_predictor.py:58-108 after `self.net(image)`: decode, scale, confidence floor, NMS, top-k, threshold."""
     h, w = image_size
     priors = prior_boxes(image_size)
@@ -94,7 +96,7 @@ def detections(loc, conf, landms, image_size, threshold=0.8) -> np.ndarray:
         return np.empty((0, 15), dtype=np.float32)
     dets = np.hstack((boxes[inds], scores[inds, None])).astype(np.float32)
     lm = lm[inds]
-    keep = nms(dets, NMS_THRESH, NMS_TOP_K)
+    keep = nms(dets, NMS_THRESH, NMS_TOP_K, stable)
     dets = np.concatenate((dets[keep][:TOP_K], lm[keep][:TOP_K]), axis=1)
     sel = np.where(dets[:, 4] >= threshold)[0]
     return dets[sel] if len(sel) else np.empty((0, 15), dtype=np.float32)

@@ -80,13 +80,3 @@ def test_c_abi_audio_chunks_empty_chunk_in_repeat_mode_is_nan_not_a_fault(engine
     o = out.cpu()
     assert o[0].tolist() == [float(1 + i % 10) for i in range(16)]
     assert torch.isnan(o[1]).all() and torch.isnan(o[2]).all()
-
-
-def test_set_option_rejects_unknown_names_and_values(engine):
-    """include/avcer_hip.h avcer_set_option: tuning knobs only; anything else is AVCER_EINVAL with a message, state unchanged."""
-    with pytest.raises(AvcerError, match="unknown option"):
-        engine.set_option("no_such_knob", 1)
-    with pytest.raises(AvcerError, match="tail_waves"):
-        engine.set_option("tail_waves", 3)
-    for ok in (4, 8, 16):
-        engine.set_option("tail_waves", ok)

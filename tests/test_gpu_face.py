@@ -34,21 +34,32 @@ def test_detections_match_reference_predictor(engine, name, thr):
     ref = G[f"pred_{name}_t{int(thr * 100)}"]
     assert got.shape == ref.shape and got.dtype == np.float32
     np.testing.assert_array_equal(got[:, 4], ref[:, 4])   # same scores in the same order, ties included
-    # py_cpu_nms visits equal scores in whatever order numpy's (unstable) default argsort leaves them; the kernel visits
-    # them lower prior index first.  Rows whose score is unique among the candidates must be the reference's rows; a
-    # tied row must be one of the decoded candidates carrying that score.
+    # py_cpu_nms visits equal scores in whatever order numpy's default argsort leaves them (unspecified on arrays this
+    # long); the kernel's rule is `argsort(kind="stable")` read backwards: ties higher prior index first.  EVERY row, tied
+    # ones included, must be what that rule gives (the oracle with the stable sort), and rows whose score is unique
+    # among the candidates must also be the rows of the golden file the reference itself produced.
+    rule = of.detections(G[f"loc_{name}"], G[f"conf_{name}"], G[f"landms_{name}"], size, thr, stable=True)
+    assert rule.shape == got.shape
+    np.testing.assert_allclose(got, rule, rtol=3e-6, atol=3e-5)
     scores = G[f"conf_{name}"][:, 1]
     cand = scores[scores > 0.02]
     uniq, cnt = np.unique(cand, return_counts=True)
     tied = np.isin(got[:, 4], uniq[cnt > 1])
     np.testing.assert_allclose(got[~tied], ref[~tied], rtol=3e-6, atol=3e-5)
-    if tied.any():
-        pri = of.prior_boxes(size)
-        h, w = size
-        boxes = of.decode(G[f"loc_{name}"], pri) * np.array([w, h, w, h], np.float32)
-        for row in got[tied]:
-            same = boxes[scores == row[4]]
-            assert (np.abs(same - row[:4]).max(axis=1) < 1e-3).any()
+
+
+def test_nms_tied_scores_are_visited_higher_index_first(engine):
+    """Saturated detections tie at exactly 1.0f: of two overlapping boxes with equal scores the one with the higher prior
+    index is kept (`scores.argsort()[::-1]` on a tie-preserving sort), and non-overlapping tied boxes come out in that order."""
+    d = np.zeros((1, 6, 15), np.float32)
+    d[0, :, :5] = [[10, 10, 50, 50, 1.0], [12, 12, 52, 52, 1.0],      # overlap: index 1 wins
+                   [200, 200, 240, 240, 0.5], [201, 201, 241, 241, 0.5],  # overlap: index 3 wins
+                   [400, 10, 440, 50, 1.0], [300, 300, 340, 340, 0.9]]
+    d[0, :, 5] = np.arange(6)
+    out, cnt = engine.face_nms(d, conf_thresh=0.02, nms_thresh=0.4, nms_top_k=5000, top_k=750, threshold=0.3)
+    got = out[0, :int(cnt[0]), 5].cpu().numpy().astype(int).tolist()
+    assert got == [4, 1, 5, 3]
+    assert got == [int(i) for i in of.nms(d[0, :, :5], 0.4, 5000, stable=True)]
 
 
 def test_nms_kernel_matches_reference_keep_lists(engine):

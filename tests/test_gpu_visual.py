@@ -119,19 +119,14 @@ def test_static_resize_path(engine_static, sd_static):
     assert np.abs(probs.cpu().numpy() - ref).max() < PROB_TOL
 
 
-def test_stage3_tail_forms_are_bit_identical(engine_static):
-    """avcer_set_option("tail_waves"): the counted-wait tail kernel (16, default) and both block sizes of the first form
-    accumulate in the same order -- same bits, also on a position count that is not a multiple of the 128-row tile."""
-    frames = torch.from_numpy(synth.face_frames(5, 21))  # 21 * 196 = 4116 positions = 32 tiles + 20 rows
-    out = {}
-    try:
-        for waves in (16, 8, 4):
-            engine_static.set_option("tail_waves", waves)
-            out[waves] = [t.cpu() for t in engine_static.static_forward(frames, MODE_BF16X3)]
-    finally:
-        engine_static.set_option("tail_waves", 16)
-    for waves in (8, 4):
-        assert all(torch.equal(a, b) for a, b in zip(out[16], out[waves])), waves
+def test_stage3_tail_ragged_rows_match_whole_batch(engine_static):
+    """The stage-3 tail kernel (conv3 + residual + next conv1, fused.hip) on a position count that is not a multiple of its
+    128-row tile: 21 frames = 4116 positions = 32 tiles + 20 rows.  The rows of the ragged last tile are bit-identical to
+    the same frames inside a larger call (rows past M are dropped by the store descriptor, never written elsewhere)."""
+    frames = torch.from_numpy(synth.face_frames(5, 40))
+    big = [t.cpu() for t in engine_static.static_forward(frames, MODE_BF16X3)]
+    part = [t.cpu() for t in engine_static.static_forward(frames[:21], MODE_BF16X3)]
+    assert all(torch.equal(a[:21], b) for a, b in zip(big, part))
 
 
 def test_static_batch_invariance_256(engine_static):

@@ -4,7 +4,9 @@
 Its residual loads are inline asm (hipcc must not wait for them itself), so nothing tells the compiler that their
 destination registers are not valid until the counted `s_waitcnt vmcnt(4)` two groups later.  This script checks the
 generated ISA: between each residual load inside the loop and the second `s_waitcnt vmcnt(4)` after it (the one that
-names the registers), no instruction may read or write the destination registers.
+names the registers), no instruction may read or write the destination registers; and between the loop's last wait and
+the inline-asm `s_waitcnt vmcnt(0)` behind the loop (which covers the last trip's never-consumed loads) no instruction
+may touch any ring register.
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -o /tmp/fused.s avcer_amd/csrc/fused.hip
     python tools/audit_asm_loads.py /tmp/fused.s
@@ -58,6 +60,24 @@ def audit(path, kernel="bneck_tail2_kernel"):
                 used |= regs(k)
             if used & dst:
                 problems.append(f"line {i}: '{t[:70]}' touches {sorted(used & dst)} loaded at line {li} before their wait")
+    # After the loop: the last trip's loads are never consumed.  They must be covered by the asm `s_waitcnt vmcnt(0)` that
+    # follows the loop (it names the ring registers), and nothing between the loop's last wait and that one may touch them.
+    post = [i for i in range(w1 + 1, len(body)) if body[i].startswith("s_waitcnt vmcnt(0)") and body[i - 1].startswith(";;#ASMSTART")]
+    if not post:
+        problems.append("no inline-asm s_waitcnt vmcnt(0) between the loop and s_endpgm: the last residual loads are never waited for")
+    else:
+        ring = set()
+        for li in in_loop:
+            ring |= regs(body[li].split()[1].rstrip(","))
+        for i in range(w1 + 1, post[0]):
+            t = body[i]
+            if not t or t.startswith(";") or t.startswith("."):
+                continue
+            used = set()
+            for k in re.findall(r"v\[\d+:\d+\]|v\d+", t):
+                used |= regs(k)
+            if used & ring:
+                problems.append(f"line {i}: '{t[:70]}' touches ring registers {sorted(used & ring)} between the loop and the final wait")
     return problems
 
 
