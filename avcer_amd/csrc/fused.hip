@@ -783,10 +783,11 @@ __global__ void __launch_bounds__(256, 2) mfma_rate_kernel(float* sink, int iter
 }
 
 __global__ void copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
-    // four independent 16-byte loads per thread in flight, then four stores; n16 is a multiple of 4 * 256 * gridDim.x
-    const size_t t = (size_t)gridDim.x * blockDim.x, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint4 a = src[i], b = src[i + t], c = src[i + 2 * t], d = src[i + 3 * t];
-    dst[i] = a; dst[i + t] = b; dst[i + 2 * t] = c; dst[i + 3 * t] = d;
+    // ONE 16-byte load and store per thread, one thread per element: measured 6.19 TB/s on this pool against 5.0-5.7 with
+    // 2-16 accesses in flight per thread, 4.4-4.8 for persistent grid-stride forms and 4.8 for hipMemcpyAsync
+    // (tools/copy_sweep.hip, profiles/r03_copy_sweep.txt): wave-level parallelism, not per-thread unrolling, feeds HBM here
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
 }
 }  // namespace
 
@@ -901,7 +902,7 @@ int measure_ceilings(avcer_ctx* ctx, double* mfma_bf16_tflops, double* hbm_copy_
     HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
     if (mfma_bf16_tflops) *mfma_bf16_tflops = (double)blocks * 4 * iters * 16 * (2.0 * 16 * 16 * 32) / (ms * 1e-3) / 1e12;
     HIP_TRY(ctx, hipMemsetAsync(buf, 1, bytes, st));
-    const int cgrid = (int)(bytes / 16 / (4 * 256));
+    const int cgrid = (int)(bytes / 16 / 256);
     copy16_kernel<<<cgrid, 256, 0, st>>>((const uint4*)buf, (uint4*)((char*)buf + bytes), bytes / 16);
     HIP_TRY(ctx, hipEventRecord(e0, st));
     for (int i = 0; i < 4; ++i) copy16_kernel<<<cgrid, 256, 0, st>>>((const uint4*)buf, (uint4*)((char*)buf + bytes), bytes / 16);

@@ -36,6 +36,17 @@ def _f32(v) -> np.ndarray:
     return np.ascontiguousarray(_np(v), dtype=np.float32)
 
 
+def _unwrap(sd):
+    """The forms a checkpoint file comes in: the audio trainer saves {"epoch": ..., "model_state_dict": ...}
+    (audio/net_trainer/net_trainer.py:273-285, read back at get_prob_audio_8_cl.py:58-65), and a model saved from
+    nn.DataParallel prefixes every key with "module." (stripped by retina_face_predictor.py:28-33 for the detector)."""
+    if "model_state_dict" in sd and not hasattr(sd["model_state_dict"], "shape"):
+        sd = sd["model_state_dict"]
+    if sd and all(k.startswith("module.") for k in sd):
+        sd = {k[len("module."):]: v for k, v in sd.items()}
+    return sd
+
+
 def _bn_fold(sd, p, eps, conv_bias=None):
     g, b = _f32(sd[p + ".weight"]), _f32(sd[p + ".bias"])
     m, v = _f32(sd[p + ".running_mean"]), _f32(sd[p + ".running_var"])
@@ -56,6 +67,7 @@ def _conv1d_w(w) -> np.ndarray:
 
 def pack_static(sd) -> "OrderedDict[str, np.ndarray]":
     """ResNet50(7) state_dict (architectures/video.py:93-166)."""
+    sd = _unwrap(sd)
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     w = _f32(sd["conv_layer_s2_same.weight"])  # [64, 3, 7, 7]
     stem = np.zeros((64, 8, 8, 4), np.float32)
@@ -87,7 +99,7 @@ def pack_static(sd) -> "OrderedDict[str, np.ndarray]":
                         continue
                     k = f"l{li}.{b}.c{i}"
                     out[k + ".wf"] = np.ascontiguousarray(out[k + ".w"] * out[k + ".s"][:, None])
-        if li == 3:  # stage 3: conv3 (+x) of block b and conv1 of block b+1 share a launch (bneck_tail_kernel), b = 1..blocks-2
+        if li == 3:  # stage 3: conv3 (+x) of block b and conv1 of block b+1 share a launch (bneck_tail2_kernel), b = 1..blocks-2
             for b in range(1, blocks - 1):
                 for k in (f"l{li}.{b}.c3", f"l{li}.{b + 1}.c1"):
                     out[k + ".wf"] = np.ascontiguousarray(out[k + ".w"] * out[k + ".s"][:, None])
@@ -113,6 +125,7 @@ def permute_rows_for_mfma(w: np.ndarray) -> np.ndarray:
 def pack_face(sd) -> "OrderedDict[str, np.ndarray]":
     """RetinaFace(cfg_re50).state_dict() (retina_face/retina_face.py:46-76; `body.*` = torchvision ResNet-50 children)."""
     eps = 1e-5  # torch.nn.BatchNorm2d default, used by torchvision's ResNet and by retina_face_net.py
+    sd = _unwrap(sd)
     sd = {(k.split("module.", 1)[-1] if k.startswith("module.") else k): v for k, v in sd.items()}  # predictor.py:28-33
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     w = _f32(sd["body.conv1.weight"])  # [64, 3, 7, 7] -> 8 tap rows x (8 pixels x 4 channels), zero-filled
@@ -156,6 +169,7 @@ def pack_face(sd) -> "OrderedDict[str, np.ndarray]":
 
 def pack_dynamic(sd) -> "OrderedDict[str, np.ndarray]":
     """LSTMPyTorch state_dict (architectures/video.py:169-185)."""
+    sd = _unwrap(sd)
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     for name in ("lstm1", "lstm2"):
         out[f"{name}.wih.w"] = _f32(sd[f"{name}.weight_ih_l0"])
@@ -180,7 +194,11 @@ def pos_conv_weight(sd) -> np.ndarray:
 
 
 def pack_audio(sd) -> "OrderedDict[str, np.ndarray]":
-    """ExprModelV3 / ExprModelV2 state_dict (architectures/audio_8_cl.py:131-190, audio_7_cl.py)."""
+    """ExprModelV3 / ExprModelV2 state_dict (architectures/audio_8_cl.py:131-190, audio_7_cl.py), bare or inside the
+    trainer's {"model_state_dict": ...} checkpoint; the positional-conv weight norm in any of its three spellings
+    (torch >= 2.1 parametrizations.weight.original0/1, torch 2.0-style weight_g / weight_v as the published checkpoint was
+    written under torch 2.1.2 + transformers 4.36.2, or an already materialised .weight)."""
+    sd = _unwrap(sd)
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     w2 = "wav2vec2."
     for i in range(7):

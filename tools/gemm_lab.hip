@@ -1,0 +1,387 @@
+// Structure lab for the split-bf16 ("x3") contraction of avcer_amd/csrc/gemm.hip (tools only, never linked into the library):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/gemm_lab tools/gemm_lab.hip && /tmp/gemm_lab [M N K [iters]]
+// A plain Linear (sp32 activations [M][K], split weights [N][K], f32 output) in several kernel structures, each checked
+// bit for bit against the first (same product order => same bits), timed A/B/A/B in one process on random operands.
+//
+//   base      the shipped structure: A and W tiles through LDS by DMA, 2 stages, s_waitcnt vmcnt(0) + barrier per K-step
+//   wdirect   W fragments straight from global memory into registers (weights pre-packed in MFMA fragment order, one
+//             coalesced 1 KiB load per fragment), only the A tile goes through LDS: half the LDS bytes written, a 3-stage
+//             A ring in 48 KiB (two blocks per CU), counted waits (the A tile of step s+2 stays in flight across the barrier)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
+constexpr int ROWB = 128;
+constexpr unsigned OOB = 0xFFFFFF00u;
+
+template <typename Rsrc>
+__device__ __forceinline__ void dma16(Rsrc rs, char* lds_wave_base, unsigned voff, unsigned soff = 0u) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ int swz_key(int row) { return (int)((0x32765410u >> (((row >> 1) & 7) * 4)) & 7u); }
+__device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ swz_key(row)) << 4); }
+
+struct P {
+    const char* A;   // sp32 [M][K]
+    const char* W;   // split rows [N][K] (hi / lo per 32-element K group)
+    const char* WF;  // the same weights in fragment order: [N/16][K/32][hi, lo][64 lanes][16 B]
+    float* Y;        // f32 [M][N]
+    int M, N, K;
+    int ntm, ntn, nwg, gm;
+    unsigned a_bytes, w_bytes;
+};
+
+__device__ __forceinline__ void tile_of_block(const P& p, int& tile_m, int& tile_n) {
+    int bid = blockIdx.x;
+    const int q = p.nwg >> 3, r = p.nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int per_group = p.gm * p.ntn;
+    const int group = bid / per_group, within = bid - group * per_group;
+    const int first_m = group * p.gm;
+    const int gsize = min(p.gm, p.ntm - first_m);
+    tile_m = first_m + within % gsize;
+    tile_n = within / gsize;
+}
+
+template <int NFN, int NFM>
+__device__ __forceinline__ void store_acc(const P& p, f32x4_t (&acc)[NFN][NFM], int m0, int n0, int lane) {
+#pragma unroll
+    for (int fn = 0; fn < NFN; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < NFM; ++fm) {
+            const long m = (long)m0 + fm * 16 + (lane & 15);
+            if (m < p.M) *reinterpret_cast<f32x4_t*>(p.Y + m * p.N + n0 + fn * 16 + 4 * (lane >> 4)) = acc[fn][fm];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ base
+__global__ void __launch_bounds__(256, 2) gemm_base(const P p) {
+    constexpr int BMT = 128, BN = 128, TILE_BYTES = (BMT + BN) * ROWB;
+    __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
+    int tile_m, tile_n;
+    tile_of_block(p, tile_m, tile_n);
+    const int m_base = tile_m * BMT, n_base = tile_n * BN;
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), (short)0, (int)p.a_bytes, 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W), (short)0, (int)p.w_bytes, 0x00020000);
+    const int lrow8 = lane >> 3, slot = lane & 7;
+    unsigned a_off[4], w_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lrow = wave * 32 + j * 8 + lrow8;
+        const int m = m_base + lrow;
+        a_off[j] = m < p.M ? (unsigned)((long)m * p.K * 4 + ((slot ^ swz_key(lrow)) << 4)) : OOB;
+        w_off[j] = (unsigned)((long)(n_base + lrow) * p.K * 4 + ((slot ^ swz_key(lrow)) << 4));
+    }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0};
+    const int nk = p.K / 32;
+    auto issue = [&](int buf, int ks) {
+        char* sa = smem + buf * TILE_BYTES + wave * 4096;
+        char* sb = smem + buf * TILE_BYTES + BMT * ROWB + wave * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16(xrs, sa + j * 1024, a_off[j], (unsigned)(ks * ROWB));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16(wrs, sb + j * 1024, w_off[j], (unsigned)(ks * ROWB));
+    };
+    issue(0, 0);
+    __syncthreads();
+    int cur = 0;
+    const int g = lane >> 4;
+    for (int step = 0; step < nk; ++step) {
+        if (step + 1 < nk) issue(cur ^ 1, step + 1);
+        const char* sa = smem + cur * TILE_BYTES;
+        const char* sb = sa + BMT * ROWB;
+        bf16x8_t ahi[4], alo[4];
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm) {
+            const int row = wm * 64 + fm * 16 + (lane & 15);
+            ahi[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, g));
+            alo[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, 4 + g));
+        }
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+            const int row = wn * 64 + fn * 16 + (lane & 15);
+            const bf16x8_t whi = *reinterpret_cast<const bf16x8_t*>(sb + swz(row, g));
+            const bf16x8_t wlo = *reinterpret_cast<const bf16x8_t*>(sb + swz(row, 4 + g));
+#pragma unroll
+            for (int fm = 0; fm < 4; ++fm) {
+                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, ahi[fm], acc[fn][fm], 0, 0, 0);
+                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, alo[fm], acc[fn][fm], 0, 0, 0);
+                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, ahi[fm], acc[fn][fm], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) asm volatile("" : "+v"(acc[a][b]));
+        __syncthreads();
+        cur ^= 1;
+    }
+    store_acc<4, 4>(p, acc, m_base + wm * 64, n_base + wn * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ wdirect
+// WMW x WNW waves (4 in all); STAGES-deep ring for the A tile; W fragments of step s+1 are requested at the top of step s.
+// Vector-memory operations of a wave, in issue order:  prologue A(0) W(0) A(1);  step s: W(s+1) [2 NFN loads]  A(s+2) [4 DMA].
+// The wait that ends step s is s_waitcnt vmcnt(4): everything up to W(s+1) -- hence also A(s+1), issued one step earlier --
+// has landed, the four DMA pieces of A(s+2) stay in flight across the barrier.  Past the end of K the same operations are
+// issued with a clamped step index (harmless re-loads into a free slot / dead registers), so the count is exact.
+template <int WMW, int WNW, int STAGES>
+__global__ void __launch_bounds__(256, 2) gemm_wdirect(const P p) {
+    constexpr int BMT = 128, BN = 128, ABYTES = BMT * ROWB;
+    constexpr int NFM = BMT / WMW / 16, NFN = BN / WNW / 16;
+    static_assert(WMW * WNW == 4 && STAGES == 3, "4 waves; the counted wait below is written for a 3-stage ring");
+    __shared__ __attribute__((aligned(16))) char smem[STAGES * ABYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WNW, wn = wave % WNW;
+    int tile_m, tile_n;
+    tile_of_block(p, tile_m, tile_n);
+    const int m_base = tile_m * BMT, n_base = tile_n * BN;
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), (short)0, (int)p.a_bytes, 0x00020000);
+    i32x4_t wfrs;
+    {
+        const uint64_t a = (uint64_t)p.WF;
+        wfrs[0] = (int)(a & 0xffffffffu);
+        wfrs[1] = (int)((a >> 32) & 0xffffu);
+        wfrs[2] = (int)p.w_bytes;
+        wfrs[3] = 0x00020000;
+    }
+    const int lrow8 = lane >> 3, slot = lane & 7;
+    const int nk = p.K / 32;
+    unsigned a_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lrow = wave * 32 + j * 8 + lrow8;
+        const int m = m_base + lrow;
+        a_off[j] = m < p.M ? (unsigned)((long)m * p.K * 4 + ((slot ^ swz_key(lrow)) << 4)) : OOB;
+    }
+    unsigned wv[NFN];  // byte offset of this lane's 16 bytes of fragment (n tile, K-step 0, hi)
+#pragma unroll
+    for (int fn = 0; fn < NFN; ++fn) wv[fn] = (unsigned)(((long)(n_base / 16 + wn * NFN + fn) * nk) * 2048 + lane * 16);
+    f32x4_t acc[NFN][NFM];
+#pragma unroll
+    for (int a = 0; a < NFN; ++a)
+#pragma unroll
+        for (int b = 0; b < NFM; ++b) acc[a][b] = f32x4_t{0};
+    u32x4_t wh0[NFN], wl0[NFN], wh1[NFN], wl1[NFN];
+
+#define LAB_LOAD_W(KS, WH, WL)                                                                                          \
+    do {                                                                                                                \
+        const unsigned so_ = (unsigned)(min((KS), nk - 1) * 2048);                                                       \
+        _Pragma("unroll") for (int fn = 0; fn < NFN; ++fn) {                                                             \
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(WH[fn]) : "v"(wv[fn]), "s"(wfrs), "s"(so_) : "memory"); \
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(WL[fn]) : "v"(wv[fn]), "s"(wfrs), "s"(so_) : "memory"); \
+        }                                                                                                               \
+    } while (0)
+#define LAB_ISSUE_A(KS)                                                                                                 \
+    do {                                                                                                                \
+        char* sa_ = smem + ((KS) % STAGES) * ABYTES + wave * 4096;                                                      \
+        const unsigned so_ = (unsigned)(min((KS), nk - 1) * ROWB);                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) dma16(xrs, sa_ + j * 1024, a_off[j], so_);                         \
+    } while (0)
+#define LAB_STEP(S, WH, WL, WHN, WLN)                                                                                   \
+    do {                                                                                                                \
+        LAB_LOAD_W((S) + 1, WHN, WLN);                                                                                  \
+        asm volatile("" ::: "memory");                                                                                  \
+        LAB_ISSUE_A((S) + 2);                                                                                           \
+        asm volatile("" ::: "memory");                                                                                  \
+        const char* sa = smem + ((S) % STAGES) * ABYTES;                                                                \
+        bf16x8_t ahi[NFM], alo[NFM];                                                                                    \
+        _Pragma("unroll") for (int fm = 0; fm < NFM; ++fm) {                                                             \
+            const int row = wm * (BMT / WMW) + fm * 16 + (lane & 15);                                                   \
+            ahi[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, g));                                             \
+            alo[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, 4 + g));                                         \
+        }                                                                                                               \
+        _Pragma("unroll") for (int fn = 0; fn < NFN; ++fn) {                                                             \
+            const bf16x8_t whi = __builtin_bit_cast(bf16x8_t, WH[fn]), wlo = __builtin_bit_cast(bf16x8_t, WL[fn]);      \
+            _Pragma("unroll") for (int fm = 0; fm < NFM; ++fm) {                                                         \
+                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, ahi[fm], acc[fn][fm], 0, 0, 0);              \
+                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, alo[fm], acc[fn][fm], 0, 0, 0);              \
+                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, ahi[fm], acc[fn][fm], 0, 0, 0);              \
+            }                                                                                                           \
+        }                                                                                                               \
+        _Pragma("unroll") for (int a = 0; a < NFN; ++a) _Pragma("unroll") for (int b = 0; b < NFM; ++b)                   \
+            asm volatile("" : "+v"(acc[a][b]));                                                                         \
+        LAB_WAIT4(WHN, WLN);                                                                                            \
+        __builtin_amdgcn_s_barrier();                                                                                   \
+        asm volatile("" ::: "memory");                                                                                  \
+    } while (0)
+
+    const int g = lane >> 4;
+    LAB_ISSUE_A(0);
+    asm volatile("" ::: "memory");
+    LAB_LOAD_W(0, wh0, wl0);
+    asm volatile("" ::: "memory");
+    LAB_ISSUE_A(1);
+    asm volatile("" ::: "memory");
+    if constexpr (NFN == 2) {
+#define LAB_WAIT4(H, L) asm volatile("s_waitcnt vmcnt(4)" : "+v"(H[0]), "+v"(L[0]), "+v"(H[1]), "+v"(L[1])::"memory")
+        LAB_WAIT4(wh0, wl0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        for (int s = 0; s < nk; s += 2) {
+            LAB_STEP(s, wh0, wl0, wh1, wl1);
+            LAB_STEP(s + 1, wh1, wl1, wh0, wl0);
+        }
+#undef LAB_WAIT4
+    } else {
+#define LAB_WAIT4(H, L)                                                                                                 \
+    asm volatile("s_waitcnt vmcnt(4)" : "+v"(H[0]), "+v"(L[0]), "+v"(H[1]), "+v"(L[1]), "+v"(H[2]), "+v"(L[2]), "+v"(H[3]), "+v"(L[3])::"memory")
+        LAB_WAIT4(wh0, wl0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        for (int s = 0; s < nk; s += 2) {
+            LAB_STEP(s, wh0, wl0, wh1, wl1);
+            LAB_STEP(s + 1, wh1, wl1, wh0, wl0);
+        }
+#undef LAB_WAIT4
+    }
+    // the clamped operations issued by the last steps are still in flight: drain them before the wave ends
+    if constexpr (NFN == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wh0[0]), "+v"(wl0[0]), "+v"(wh0[1]), "+v"(wl0[1]), "+v"(wh1[0]), "+v"(wl1[0]), "+v"(wh1[1]), "+v"(wl1[1])::"memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(wh0[0]), "+v"(wl0[0]), "+v"(wh0[1]), "+v"(wl0[1]), "+v"(wh0[2]), "+v"(wl0[2]), "+v"(wh0[3]), "+v"(wl0[3]),
+                     "+v"(wh1[0]), "+v"(wl1[0]), "+v"(wh1[1]), "+v"(wl1[1]), "+v"(wh1[2]), "+v"(wl1[2]), "+v"(wh1[3]), "+v"(wl1[3])::"memory");
+    store_acc<NFN, NFM>(p, acc, m_base + wm * (BMT / WMW), n_base + wn * (BN / WNW), lane);
+#undef LAB_STEP
+#undef LAB_ISSUE_A
+#undef LAB_LOAD_W
+}
+
+// ------------------------------------------------------------------------------------------------ host
+static uint16_t f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (uint16_t)((u + 0x7FFF + ((u >> 16) & 1)) >> 16);
+}
+static float bf2f(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// f32 [R][K] -> sp32 rows (per 32 elements: 32 hi then 32 lo)
+static void to_sp32(const std::vector<float>& x, int R, int K, std::vector<uint16_t>& out) {
+    out.resize((size_t)R * K * 2);
+    for (long r = 0; r < R; ++r)
+        for (int k = 0; k < K; ++k) {
+            const float v = x[r * K + k];
+            const uint16_t h = f2bf(v), l = f2bf(v - bf2f(h));
+            const size_t base = ((size_t)r * K + (k & ~31)) * 2;
+            out[base + (k & 31)] = h;
+            out[base + 32 + (k & 31)] = l;
+        }
+}
+// sp32 rows [N][K] -> fragment order [N/16][K/32][hi, lo][lane = 16 (k chunk) + row][8 bf16]
+static void to_frag(const std::vector<uint16_t>& w, int N, int K, std::vector<uint16_t>& out) {
+    out.resize(w.size());
+    const int nk = K / 32;
+    for (int nt = 0; nt < N / 16; ++nt)
+        for (int ks = 0; ks < nk; ++ks)
+            for (int hl = 0; hl < 2; ++hl)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int row = nt * 16 + (lane & 15), chunk = lane >> 4;
+                    const uint16_t* src = &w[((size_t)row * K + ks * 32) * 2 + hl * 32 + chunk * 8];
+                    uint16_t* dst = &out[((((size_t)nt * nk + ks) * 2 + hl) * 64 + lane) * 8];
+                    memcpy(dst, src, 16);
+                }
+}
+
+template <typename F>
+static float time_ms(F launch, int iters) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) launch();
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return ms / iters;
+}
+
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 12672, N = argc > 2 ? atoi(argv[2]) : 3072, K = argc > 3 ? atoi(argv[3]) : 1024;
+    const int iters = argc > 4 ? atoi(argv[4]) : 20;
+    if (N % 128 || K % 64) { printf("N %% 128, K %% 64\n"); return 1; }
+    srand(1);
+    std::vector<float> x((size_t)M * K), w((size_t)N * K);
+    for (auto& v : x) v = std::max(0.f, (float)rand() / RAND_MAX * 2.f - 0.7f);
+    for (auto& v : w) v = ((float)rand() / RAND_MAX * 2.f - 1.f) * 0.05f;
+    std::vector<uint16_t> xs, ws, wf;
+    to_sp32(x, M, K, xs);
+    to_sp32(w, N, K, ws);
+    to_frag(ws, N, K, wf);
+    char *dA, *dW, *dWF;
+    float *dY0, *dY1;
+    hipMalloc(&dA, xs.size() * 2);
+    hipMalloc(&dW, ws.size() * 2);
+    hipMalloc(&dWF, wf.size() * 2);
+    hipMalloc(&dY0, (size_t)M * N * 4);
+    hipMalloc(&dY1, (size_t)M * N * 4);
+    hipMemcpy(dA, xs.data(), xs.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dW, ws.data(), ws.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dWF, wf.data(), wf.size() * 2, hipMemcpyHostToDevice);
+    P p;
+    p.A = dA; p.W = dW; p.WF = dWF; p.Y = dY0; p.M = M; p.N = N; p.K = K;
+    p.ntm = (M + 127) / 128; p.ntn = N / 128; p.nwg = p.ntm * p.ntn; p.gm = 8;
+    p.a_bytes = (unsigned)((size_t)M * K * 4); p.w_bytes = (unsigned)((size_t)N * K * 4);
+    const double flop = 2.0 * M * N * (double)K;
+    auto run_base = [&] { gemm_base<<<p.nwg, 256>>>(p); };
+    P q = p;
+    q.Y = dY1;
+    auto run_w22 = [&] { gemm_wdirect<2, 2, 3><<<q.nwg, 256>>>(q); };
+    auto run_w14 = [&] { gemm_wdirect<1, 4, 3><<<q.nwg, 256>>>(q); };
+    std::vector<float> y0((size_t)M * N), y1((size_t)M * N);
+    run_base();
+    hipMemcpy(y0.data(), dY0, y0.size() * 4, hipMemcpyDeviceToHost);
+    // spot check against float64 on the host
+    double worst = 0;
+    for (int t = 0; t < 64; ++t) {
+        const long m = (long)rand() % M, n = rand() % N;
+        double s = 0;
+        for (int k = 0; k < K; ++k) s += (double)x[m * K + k] * w[(size_t)n * K + k];
+        worst = std::max(worst, std::fabs(s - y0[m * N + n]) / (std::fabs(s) + 1e-3));
+    }
+    printf("M %d N %d K %d  blocks %d (%.2f rounds of 512)  base vs f64 spot check: max rel err %.2e\n", M, N, K, p.nwg, p.nwg / 512.0, worst);
+    struct V { const char* name; std::function<void()> f; };
+    auto check = [&](const char* name, auto f) {
+        hipMemset(dY1, 0xff, (size_t)M * N * 4);
+        f();
+        hipDeviceSynchronize();
+        hipError_t e = hipGetLastError();
+        hipMemcpy(y1.data(), dY1, y1.size() * 4, hipMemcpyDeviceToHost);
+        size_t bad = 0;
+        for (size_t i = 0; i < y0.size(); ++i) bad += memcmp(&y0[i], &y1[i], 4) != 0;
+        printf("%-14s %s, %zu of %zu values differ from base\n", name, hipGetErrorString(e), bad, y0.size());
+    };
+    check("wdirect 2x2", run_w22);
+    check("wdirect 1x4", run_w14);
+    for (int round = 0; round < 3; ++round) {
+        const float t0 = time_ms(run_base, iters), t1 = time_ms(run_w22, iters), t2 = time_ms(run_w14, iters);
+        printf("round %d   base %8.1f us %6.1f TF   wdirect2x2 %8.1f us %6.1f TF   wdirect1x4 %8.1f us %6.1f TF\n", round, t0 * 1e3,
+               flop / t0 / 1e9, t1 * 1e3, flop / t1 / 1e9, t2 * 1e3, flop / t2 / 1e9);
+    }
+    return 0;
+}
