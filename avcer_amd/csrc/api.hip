@@ -507,7 +507,16 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
         net.chk(k_avgpool_hw(ctx, X, pooled, nb, h * h, 2048, act, st));
         net.tap("avgpool", pooled, (size_t)nb * 2048 * 4);
         float* fo = feats ? feats + (size_t)s0 * 512 : feat_ws;
-        net.gemm(linear_desc(nb, 2048, 512, 0), "fc1.w", nullptr, net.F("fc1.b"), pooled, nullptr, fo, 0, 0);
+        {
+            // fc1 on the exact f32 MFMA in the x3 mode too.  After the 7 x 7 average pool the position-independent part
+            // of the trunk's error is what is left (tools/x3_stage_error.py: 1.3e-5 relative at layer4, 4.6e-6 pooled),
+            // and a split-bf16 fc1 on top of it raised the feature / logit error by 40 % (6.4e-6) -- for a 4.3 GFLOP
+            // layer of 32 tiles that takes the same 50 us either way.
+            const int x3_saved = net.x3;
+            net.x3 = 0;
+            net.gemm(linear_desc(nb, 2048, 512, 0), "fc1.w", nullptr, net.F("fc1.b"), pooled, nullptr, fo, 0, 0);
+            net.x3 = x3_saved;
+        }
         if (logits || probs)
             net.chk(k_small_linear(ctx, fo, net.F("fc2.w"), net.F("fc2.b"), logits ? logits + (size_t)s0 * 7 : nullptr,
                                    probs ? probs + (size_t)s0 * 7 : nullptr, nb, 512, 7, 1, st));

@@ -1,11 +1,16 @@
 """Parity margin of the two parity-grade arithmetic modes over several synthetic weight draws and logit scales.
 
 Real checkpoints are not available offline, so the 1e-4 probability gate is exercised on 5 weight seeds x logit scale
-{1, 4} (the last Linear of every model scaled by 4: sharper softmax, the probabilities four times more sensitive to a
-logit error) at 8 frames + 2 audio windows, in the f32 mode and in the split-bf16 (x3) headline mode.  The worst
-|dprob| per mode and scale is printed.  Gate: 1e-4 at the models' own logit scale in both modes (measured: f32 3e-6,
-x3 3e-5) and for f32 at scale 4; the x3 logit error (~1e-4 absolute after 53 convolutions of 2^-18-grade roundings) is
-scale-independent, so at 4x sharper logits its probability error is bounded by 4e-4 (measured 1.0e-4)."""
+{1, 4, 8} (the last Linear of every model scaled: a sharper softmax makes the probabilities that many times more
+sensitive to a logit error -- trained emotion heads are routinely sharper than the synthetic generator's) at 8 frames + 2
+audio windows, in the f32 mode and in the split-bf16 (x3) headline mode.  Every case is printed.
+
+ONE gate for every mode and scale: 1e-4 (north_star).  Round 2 had to loosen x3 at scale 4 to 4e-4 (1.0e-4 measured); the
+owner of that error was found with tools/x3_error_probe.py / tools/x3_stage_error.py: per contraction the x3 error is
+4.5e-6 relative (split rounding 3.5e-6 + the dropped lo x lo product 2.8e-6; MFMA accumulation 0.1-0.7e-6, unbiased),
+the 7 x 7 average pool removes its position-independent two thirds (1.3e-5 at layer4 -> 4.6e-6 pooled), and a split-bf16
+fc1 then put 40 % back on top.  fc1 now runs on the exact f32 MFMA in the x3 mode as well (free: 32 tiles, 50 us either
+way): worst x3 |dprob| 1.7e-5 / 4.2e-5 at scale 1 / 4 (was 2.5e-5 / 8.9e-5..1.0e-4)."""
 import numpy as np
 import pytest
 import torch
@@ -19,7 +24,7 @@ from oracle import video as ov
 pytestmark = pytest.mark.gpu
 
 SEEDS = (42, 43, 44, 45, 46)
-SCALES = (1.0, 4.0)
+SCALES = (1.0, 4.0, 8.0)
 
 
 def _scaled(sd, keys, s):
@@ -65,6 +70,6 @@ def test_probability_gate_over_seeds_and_logit_scales():
         print("seed %d scale %.0f %-4s  static %.2e  dynamic %.2e  audio %.2e" % r)
     for sc in SCALES:
         print("worst |dprob| over %d seeds at logit scale %.0f: fp32 %.3e, x3 %.3e" % (len(SEEDS), sc, worst[("fp32", sc)], worst[("x3", sc)]))
-    assert worst[("fp32", 1.0)] < 1e-4 and worst[("x3", 1.0)] < 1e-4
-    assert worst[("fp32", 4.0)] < 1e-4 and worst[("x3", 4.0)] < 4e-4
+    for sc in SCALES:
+        assert worst[("fp32", sc)] < 1e-4 and worst[("x3", sc)] < 1e-4, (sc, worst)
     eng.close()

@@ -144,10 +144,12 @@ __global__ void __launch_bounds__(256, 2) gemm_base(const P p) {
 // The wait that ends step s is s_waitcnt vmcnt(4): everything up to W(s+1) -- hence also A(s+1), issued one step earlier --
 // has landed, the four DMA pieces of A(s+2) stay in flight across the barrier.  Past the end of K the same operations are
 // issued with a clamped step index (harmless re-loads into a free slot / dead registers), so the count is exact.
-template <int WMW, int WNW, int STAGES>
+template <int WMW, int WNW, int STAGES, int BN = 128>
 __global__ void __launch_bounds__(256, 2) gemm_wdirect(const P p) {
-    constexpr int BMT = 128, BN = 128, ABYTES = BMT * ROWB;
+#if defined(__HIP_DEVICE_COMPILE__)  // the asm statements below only parse for the device target
+    constexpr int BMT = 128, ABYTES = BMT * ROWB;
     constexpr int NFM = BMT / WMW / 16, NFN = BN / WNW / 16;
+    constexpr int MH = NFM > 4 && NFN > 2 ? 4 : NFM;  // A fragments held at a time (the wide tile reads them in two halves)
     static_assert(WMW * WNW == 4 && STAGES == 3, "4 waves; the counted wait below is written for a 3-stage ring");
     __shared__ __attribute__((aligned(16))) char smem[STAGES * ABYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -205,18 +207,22 @@ __global__ void __launch_bounds__(256, 2) gemm_wdirect(const P p) {
         LAB_ISSUE_A((S) + 2);                                                                                           \
         asm volatile("" ::: "memory");                                                                                  \
         const char* sa = smem + ((S) % STAGES) * ABYTES;                                                                \
-        bf16x8_t ahi[NFM], alo[NFM];                                                                                    \
-        _Pragma("unroll") for (int fm = 0; fm < NFM; ++fm) {                                                             \
-            const int row = wm * (BMT / WMW) + fm * 16 + (lane & 15);                                                   \
-            ahi[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, g));                                             \
-            alo[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, 4 + g));                                         \
-        }                                                                                                               \
-        _Pragma("unroll") for (int fn = 0; fn < NFN; ++fn) {                                                             \
-            const bf16x8_t whi = __builtin_bit_cast(bf16x8_t, WH[fn]), wlo = __builtin_bit_cast(bf16x8_t, WL[fn]);      \
-            _Pragma("unroll") for (int fm = 0; fm < NFM; ++fm) {                                                         \
-                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, ahi[fm], acc[fn][fm], 0, 0, 0);              \
-                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, alo[fm], acc[fn][fm], 0, 0, 0);              \
-                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, ahi[fm], acc[fn][fm], 0, 0, 0);              \
+        _Pragma("unroll") for (int h = 0; h < NFM / MH; ++h) {                                                           \
+            if (MH < NFM) __builtin_amdgcn_sched_barrier(0); /* keep the halves apart: hipcc would hoist all 16 reads */  \
+            bf16x8_t ahi[MH], alo[MH];                                                                                  \
+            _Pragma("unroll") for (int fm = 0; fm < MH; ++fm) {                                                          \
+                const int row = wm * (BMT / WMW) + (h * MH + fm) * 16 + (lane & 15);                                    \
+                ahi[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, g));                                         \
+                alo[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, 4 + g));                                     \
+            }                                                                                                           \
+            _Pragma("unroll") for (int fn = 0; fn < NFN; ++fn) {                                                         \
+                const bf16x8_t whi = __builtin_bit_cast(bf16x8_t, WH[fn]), wlo = __builtin_bit_cast(bf16x8_t, WL[fn]);  \
+                _Pragma("unroll") for (int fm = 0; fm < MH; ++fm) {                                                      \
+                    f32x4_t& c_ = acc[fn][h * MH + fm];                                                                 \
+                    c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, ahi[fm], c_, 0, 0, 0);                            \
+                    c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, alo[fm], c_, 0, 0, 0);                            \
+                    c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, ahi[fm], c_, 0, 0, 0);                            \
+                }                                                                                                       \
             }                                                                                                           \
         }                                                                                                               \
         _Pragma("unroll") for (int a = 0; a < NFN; ++a) _Pragma("unroll") for (int b = 0; b < NFM; ++b)                   \
@@ -264,6 +270,7 @@ __global__ void __launch_bounds__(256, 2) gemm_wdirect(const P p) {
 #undef LAB_STEP
 #undef LAB_ISSUE_A
 #undef LAB_LOAD_W
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -353,6 +360,9 @@ int main(int argc, char** argv) {
     q.Y = dY1;
     auto run_w22 = [&] { gemm_wdirect<2, 2, 3><<<q.nwg, 256>>>(q); };
     auto run_w14 = [&] { gemm_wdirect<1, 4, 3><<<q.nwg, 256>>>(q); };
+    P q2 = q;
+    q2.ntn = N / 256; q2.nwg = q2.ntm * q2.ntn;
+    auto run_w256 = [&] { gemm_wdirect<1, 4, 3, 256><<<q2.nwg, 256>>>(q2); };
     std::vector<float> y0((size_t)M * N), y1((size_t)M * N);
     run_base();
     hipMemcpy(y0.data(), dY0, y0.size() * 4, hipMemcpyDeviceToHost);
@@ -365,7 +375,6 @@ int main(int argc, char** argv) {
         worst = std::max(worst, std::fabs(s - y0[m * N + n]) / (std::fabs(s) + 1e-3));
     }
     printf("M %d N %d K %d  blocks %d (%.2f rounds of 512)  base vs f64 spot check: max rel err %.2e\n", M, N, K, p.nwg, p.nwg / 512.0, worst);
-    struct V { const char* name; std::function<void()> f; };
     auto check = [&](const char* name, auto f) {
         hipMemset(dY1, 0xff, (size_t)M * N * 4);
         f();
@@ -378,10 +387,12 @@ int main(int argc, char** argv) {
     };
     check("wdirect 2x2", run_w22);
     check("wdirect 1x4", run_w14);
+    if (N % 256 == 0) check("wdirect 1x4 BN256", run_w256);
     for (int round = 0; round < 3; ++round) {
         const float t0 = time_ms(run_base, iters), t1 = time_ms(run_w22, iters), t2 = time_ms(run_w14, iters);
-        printf("round %d   base %8.1f us %6.1f TF   wdirect2x2 %8.1f us %6.1f TF   wdirect1x4 %8.1f us %6.1f TF\n", round, t0 * 1e3,
-               flop / t0 / 1e9, t1 * 1e3, flop / t1 / 1e9, t2 * 1e3, flop / t2 / 1e9);
+        const float t3 = N % 256 == 0 ? time_ms(run_w256, iters) : 0.f;
+        printf("round %d   base %8.1f us %6.1f TF   wdirect2x2 %8.1f us %6.1f TF   wdirect1x4 %8.1f us %6.1f TF   1x4/BN256 %8.1f us %6.1f TF\n",
+               round, t0 * 1e3, flop / t0 / 1e9, t1 * 1e3, flop / t1 / 1e9, t2 * 1e3, flop / t2 / 1e9, t3 * 1e3, t3 > 0 ? flop / t3 / 1e9 : 0.0);
     }
     return 0;
 }
