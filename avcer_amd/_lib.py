@@ -67,6 +67,7 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, c_stream]),
     "avcer_split_weights": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_size_t, c_stream]),
     "avcer_split_weight_rows": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int, c_stream]),
+    "avcer_weight_frags": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int, c_stream]),
     "avcer_conv_gemm_dual": (C.c_int, [c_ctx, C.POINTER(ConvDesc), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
     "avcer_face_nms": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float,

@@ -147,9 +147,11 @@ int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
         const bool is_w = k.size() > 3 && (k.compare(k.size() - 2, 2, ".w") == 0 || k.compare(k.size() - 3, 3, ".wf") == 0);
         return !t.x3 && is_w && t.ndim == 2 && t.dims[1] % 32 == 0 && t.dims[0] % 64 == 0;
     };
+    // fragment-order copy for the weights-direct kernel (dtype 7 / 8): N a multiple of 256, an even number of K-steps
+    auto frag_ok = [](const Tensor& t) { return t.dims[0] % 256 == 0 && (t.dims[1] / 32) % 2 == 0; };
     size_t total = 0;
     for (auto& kv : m.t)
-        if (wanted(kv.first, kv.second)) total += (kv.second.numel * 4 + 255) & ~(size_t)255;
+        if (wanted(kv.first, kv.second)) total += ((kv.second.numel * 4 + 255) & ~(size_t)255) * (frag_ok(kv.second) ? 2 : 1);
     if (!total) return AVCER_OK;
     void* dev = nullptr;
     if (hipMalloc(&dev, total) != hipSuccess) {
@@ -160,12 +162,34 @@ int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
     size_t off = 0;
     for (auto& kv : m.t)
         if (wanted(kv.first, kv.second)) {
-            kv.second.x3 = (bf16_t*)((char*)dev + off);
+            Tensor& t = kv.second;
+            t.x3 = (bf16_t*)((char*)dev + off);
             // grouped weights ([groups*n][k], pos-conv) are stacked row blocks of multiples of 32 rows: same permutation
-            TRY(k_split_weight_rows(ctx, kv.second.f32, kv.second.x3, (int)kv.second.dims[0], (int)kv.second.dims[1], st));
-            off += (kv.second.numel * 4 + 255) & ~(size_t)255;
+            TRY(k_split_weight_rows(ctx, t.f32, t.x3, (int)t.dims[0], (int)t.dims[1], st));
+            off += (t.numel * 4 + 255) & ~(size_t)255;
+            if (frag_ok(t)) {
+                t.x3f = (bf16_t*)((char*)dev + off);
+                TRY(k_weight_frags(ctx, t.x3, t.x3f, (int)t.dims[0], (int)t.dims[1], st));
+                off += (t.numel * 4 + 255) & ~(size_t)255;
+            }
         }
     return AVCER_OK;
+}
+
+// Which form of the split-bf16 contraction serves a layer of M positions, N channels, K inputs: the weights-direct kernel
+// (128 x 256 tiles, dtype 7 / 8) or the LDS-staged one (128 x 128, dtype 5 / 6).  Results are bit-identical, so this is
+// speed only.  Model, calibrated on tools/ab_layers.py (profiles/r03_ab_layers.txt): a 128 x 256 tile costs 1.84 tiles of
+// 128 x 128 (1.95 where K <= 1024: the tile's prologue and epilogue weigh more), 512 blocks run at a time, a partial last
+// round of fraction f costs min(1, 0.3 + f) of a round, and a grid of at most one block per CU runs at 0.65 of a round.
+bool prefer_weights_direct(long M, int N, long K) {
+    auto rounds = [](long tiles) {
+        if (tiles <= 256) return 0.65;
+        if (tiles <= 512) return 1.0;
+        const double r = (double)tiles / 512.0, whole = std::floor(r), f = r - whole;
+        return whole + (f > 0.0 ? std::min(1.0, 0.3 + f) : 0.0);
+    };
+    const long mt = (M + 127) / 128;
+    return rounds(mt * (N / 256)) * (K <= 1024 ? 1.95 : 1.84) < rounds(mt * (N / 128));
 }
 
 struct Net {
@@ -197,6 +221,7 @@ struct Net {
         if (!w) return;
         int dtype = -1;
         const void* wp = nullptr;
+        const long K = (long)d.kh * d.kw * d.cin + (x2 ? d.x2_cin : 0);
         if (akind == 0 && okind == 0) {
             dtype = 0;
             wp = w->f32;
@@ -210,13 +235,18 @@ struct Net {
         } else if (x3 && ((akind == 0 && okind == 2) || akind == 2) && okind != 1) {
             dtype = akind == 0 ? 4 : (okind == 2 ? 5 : 6);
             wp = w->x3;
+            // sp32 activations: the weights-direct kernel wherever a fragment-order copy exists (one group, pad-free second source)
+            if (akind == 2 && w->x3f && d.groups <= 1 && (d.tile_n == 256 || (d.tile_n == 0 &&
+                    prefer_weights_direct((long)d.batch * d.out_h * d.out_w, d.n, K)))) {
+                dtype = okind == 2 ? 7 : 8;
+                wp = w->x3f;
+            }
         }
         if (dtype < 0 || !wp) {
             err = set_err(ctx, AVCER_ESTATE, "gemm %s: storage kinds %d -> %d unsupported or weights not prepared",
                           wname.c_str(), akind, okind);
             return;
         }
-        const long K = (long)d.kh * d.kw * d.cin + (x2 ? d.x2_cin : 0);
         if ((long)w->numel != (long)d.n * K * (d.groups > 1 ? d.groups : 1)) {
             err = set_err(ctx, AVCER_EFORMAT, "gemm %s: weight has %zu elements, expected %ld x %ld", wname.c_str(),
                           w->numel, (long)d.n, K);
@@ -1099,6 +1129,13 @@ extern "C" int avcer_split_weight_rows(avcer_ctx* ctx, const float* w, void* out
     if (!w || !out || n <= 0 || k <= 0) return set_err(ctx, AVCER_EINVAL, "split_weight_rows: bad arguments");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return k_split_weight_rows(ctx, w, (bf16_t*)out, n, k, (hipStream_t)stream);
+}
+
+extern "C" int avcer_weight_frags(avcer_ctx* ctx, const void* rows, void* out, int n, int k, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (!rows || !out || n <= 0 || k <= 0) return set_err(ctx, AVCER_EINVAL, "weight_frags: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return k_weight_frags(ctx, (const bf16_t*)rows, (bf16_t*)out, n, k, (hipStream_t)stream);
 }
 
 extern "C" int avcer_measure_ceilings(avcer_ctx* ctx, double* mfma_bf16_tflops, double* hbm_copy_tbs, avcer_stream_t stream) {

@@ -25,6 +25,7 @@ struct Tensor {
     float* f32 = nullptr;
     bf16_t* bf16 = nullptr;
     bf16_t* x3 = nullptr;  // split-bf16 (hi/lo per 32-element K group) copy for AVCER_MODE_BF16X3
+    bf16_t* x3f = nullptr; // the same in MFMA fragment order (conv_gemm dtype 7 / 8), where the shape allows it
     size_t numel = 0;
     int64_t dims[4] = {0, 0, 0, 0};
     int ndim = 0;
@@ -130,6 +131,7 @@ int k_audio_chunks(avcer_ctx*, const float* wav, const int32_t* starts, const in
                    float* out, hipStream_t);
 int k_split_weights(avcer_ctx*, const float* w, bf16_t* out, size_t n, hipStream_t);
 int k_split_weight_rows(avcer_ctx*, const float* w, bf16_t* out, int n, int k, hipStream_t);
+int k_weight_frags(avcer_ctx*, const bf16_t* rows, bf16_t* out, int n, int k, hipStream_t);
 int k_face_decode(avcer_ctx*, const float* loc, const float* conf, const float* landms, const float* priors, int P, int im_h,
                   int im_w, float var0, float var1, float* dets, hipStream_t);
 int k_face_nms(avcer_ctx*, const float* dets, int T, int P, float conf_thresh, float nms_thresh, int nms_top_k, int top_k,

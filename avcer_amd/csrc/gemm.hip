@@ -64,6 +64,8 @@ struct GemmParams {
     int fast;  // pad-free gather with a scalar K / tap advance (see AVCER_ISSUE_TILES)
     int tile_n;  // 0 = choose, 64, 128
     int tap_inner;  // K-steps walk (channel chunk, ky, kx) instead of (ky, kx, channel chunk): see launch_conv_gemm
+    const char* WF;  // dtype 7 / 8: the weights in MFMA fragment order (kernels.hip weight_frags_kernel), else null
+    int tapH4, tapW4;  // byte steps of one filter tap down / right: dil_h * x_stride_h * 4, dil_w * x_stride_w * 4
 };
 
 // Epilogue, staged through LDS so that HBM sees whole 128-byte lines: every wave first parks its scaled/biased
@@ -247,6 +249,11 @@ __device__ __forceinline__ void res_prefetch_direct(const GemmParams& p, int m0,
         }
 }
 
+__device__ __forceinline__ float4 scale_bias4(const f32x4_t a, const float4 s, const float4 b) {
+    return make_float4(__builtin_fmaf(a[0], s.x, b.x), __builtin_fmaf(a[1], s.y, b.y), __builtin_fmaf(a[2], s.z, b.z),
+                       __builtin_fmaf(a[3], s.w, b.w));
+}
+
 template <int OUT, int ACT, int NFN, int NFM>
 __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4_t (&acc)[NFN][NFM], int m0, int c0, int lane,
                                                 const uint4 (&rr)[NFN / 2][NFM][2]) {
@@ -261,9 +268,8 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4_t (&a
             const long m = (long)m0 + fm * 16 + (lane & 15);
             if (m >= p.M) continue;
             const f32x4_t lo = acc[2 * j][fm], hi = acc[2 * j + 1][fm];
-            finish8<OUT, ACT>(p, m, ch, make_float4(lo[0] * s0.x + b0.x, lo[1] * s0.y + b0.y, lo[2] * s0.z + b0.z, lo[3] * s0.w + b0.w),
-                              make_float4(hi[0] * s1.x + b1.x, hi[1] * s1.y + b1.y, hi[2] * s1.z + b1.z, hi[3] * s1.w + b1.w),
-                              rr[j][fm][0], rr[j][fm][1]);
+            // explicit fma: the two forms of the kernel (this one and conv_gemm_wd_kernel) must round alike whatever hipcc contracts
+            finish8<OUT, ACT>(p, m, ch, scale_bias4(lo, s0, b0), scale_bias4(hi, s1, b1), rr[j][fm][0], rr[j][fm][1]);
         }
     }
 }
@@ -568,6 +574,288 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ weights direct (dtype 7 / 8)
+// The split-bf16 contraction of sp32 activations in a second structure (round 3; tools/gemm_lab.hip is its test bench):
+//   * the WEIGHT fragments never touch LDS.  The weights are stored once more in MFMA fragment order -- [N/16][K/32][hi, lo]
+//     [64 lanes][16 B], rows permuted like every split weight -- so a wave gets a whole fragment with ONE coalesced 1 KiB
+//     load straight into the registers the MFMA reads (inline asm: hipcc would otherwise drain the LDS-DMA queue for it);
+//   * only the activation tile goes through LDS (16 KiB per K-step instead of 32): a THREE-stage ring fits twice per CU
+//     (48 KiB per block), the tile of step s+2 stays in flight across the barrier behind a counted s_waitcnt vmcnt(4);
+//   * 128 x 256 tiles, the four waves side by side along n, each owning all 128 positions x 64 channels: nobody loads a
+//     weight fragment twice and one LDS fragment read feeds 12 MFMAs (the 2 x 2 form: 6); the fragments of 16 positions are
+//     read while the 12 MFMAs of the previous 16 run (two register pairs, ping-pong).
+// Same product order per output element as conv_gemm_kernel<3, *, *>: bit-identical results (tests/test_gpu_gemm_wd.py).
+// Vector-memory operations of a wave, in issue order: prologue A(0) W(0) A(1); step s: W(s+1) [8 loads], A(s+2) [4 DMA
+// pieces].  The wait that ends step s is vmcnt(4): everything up to W(s+1), hence also A(s+1), has landed.  Past the end of
+// K the same operations are issued on dummy targets (out-of-range DMA = zeros into a free slot, a repeated weight load into
+// dead registers), so the count is exact.  The K position is a handful of scalars advanced by additions; GATHER selects the
+// activation addressing at compile time: 0 = plain matrix (every Linear and 1x1 convolution: one tap, no padding), 1 = the
+// same with a second source for the tail of K (conv3 + downsample), 2 = several taps without padding (Conv1d of the audio
+// model), 3 = zero padding by per-row bounds tests (3x3 convolutions).
+#define AVCER_WREGS4(H, L) "+v"(H[0]), "+v"(L[0]), "+v"(H[1]), "+v"(L[1]), "+v"(H[2]), "+v"(L[2]), "+v"(H[3]), "+v"(L[3])
+
+template <int OUT, int ACT, int NFN, int NFM>
+__device__ __forceinline__ void wd_epilogue(const GemmParams& p, f32x4_t (&acc)[NFN][NFM], int m_base, int c0, int lane) {
+    // straight from the accumulators (weight rows are permuted: lane group g holds channels 8g..8g+7 of every group of 32);
+    // the residual is read here, four positions at a time, into the registers the weight fragments left free
+#pragma unroll
+    for (int j = 0; j < NFN / 2; ++j) {
+        const int ch = c0 + 32 * j + 8 * (lane >> 4);
+        float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+        if (p.scale) { s0 = *reinterpret_cast<const float4*>(p.scale + ch); s1 = *reinterpret_cast<const float4*>(p.scale + ch + 4); }
+        if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + ch); b1 = *reinterpret_cast<const float4*>(p.bias + ch + 4); }
+#pragma unroll
+        for (int h = 0; h < NFM; h += 4) {
+            uint4 rr[4][2];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                rr[f][0] = make_uint4(0u, 0u, 0u, 0u);
+                rr[f][1] = make_uint4(0u, 0u, 0u, 0u);
+                const long m = (long)m_base + (h + f) * 16 + (lane & 15);
+                if (p.R && m < p.M) res_load<OUT>(p, m, ch, rr[f][0], rr[f][1]);
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const long m = (long)m_base + (h + f) * 16 + (lane & 15);
+                if (m >= p.M) continue;
+                finish8<OUT, ACT>(p, m, ch, scale_bias4(acc[2 * j][h + f], s0, b0), scale_bias4(acc[2 * j + 1][h + f], s1, b1), rr[f][0],
+                                  rr[f][1]);
+            }
+        }
+    }
+}
+
+template <int OUT, int GATHER>
+__global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the asm statements below only parse for the device target
+    constexpr int BMT = 128, BN = 256, NFM = 8, NFN = 4, STAGES = 3, ABYTES = BMT * ROWB;
+    __shared__ __attribute__((aligned(16))) char smem[STAGES * ABYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    {
+        const int q = p.nwg >> 3, r = p.nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int tile_n, tile_m;
+    {
+        const int per_group = p.gm * p.ntn;
+        const int group = bid / per_group, within = bid - group * per_group;
+        const int first_m = group * p.gm;
+        const int gsize = min(p.gm, p.ntm - first_m);
+        tile_m = first_m + within % gsize;
+        tile_n = within / gsize;
+    }
+    const int m_base = tile_m * BMT, n_base = tile_n * BN;
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.X), (short)0, (int)p.x_bytes, 0x00020000);
+    const auto x2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(GATHER == 1 ? p.X2 : p.X), (short)0,
+                                                        (int)(GATHER == 1 ? p.x2_bytes : p.x_bytes), 0x00020000);
+    (void)x2rs;
+    typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+    i32x4_t wfrs;
+    {
+        const uint64_t a = (uint64_t)p.WF;
+        wfrs[0] = (int)(a & 0xffffffffu);
+        wfrs[1] = (int)((a >> 32) & 0xffffu);
+        wfrs[2] = (int)p.w_bytes;
+        wfrs[3] = 0x00020000;
+    }
+    const int lrow8 = lane >> 3, slot = lane & 7, g = lane >> 4;
+    const int nk = p.K >> 5;
+    const int n1 = p.K1 >> 5;  // K-steps served by the first source
+    unsigned a_offk[4];
+    unsigned a_off2k[GATHER == 1 ? 4 : 1];
+    int a_iy[GATHER == 3 ? 4 : 1], a_ix[GATHER == 3 ? 4 : 1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lrow = wave * 32 + j * 8 + lrow8;
+        const int m = m_base + lrow;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int ox = mm % p.OW;
+        const int t = mm / p.OW;
+        const int oy = t % p.OH;
+        const int b = t / p.OH;
+        const int iy = oy * p.sh - p.ph, ix = ox * p.sw - p.pw;
+        const unsigned kcb = (unsigned)((slot ^ swz_key(lrow)) << 4);  // this lane's 16-byte chunk of the 128-byte K-step
+        a_offk[j] = ok ? (unsigned)(((long)b * p.sB + (long)iy * p.sH + (long)ix * p.sW + p.coff) * 4) + kcb : OOB;
+        if constexpr (GATHER == 1)
+            a_off2k[j] = ok ? (unsigned)(((long)b * p.sB2 + (long)oy * p.st2 * p.sH2 + (long)ox * p.st2 * p.sW2 + p.coff2) * 4) + kcb : OOB;
+        if constexpr (GATHER == 3) {
+            a_iy[j] = ok ? iy : -(1 << 28);
+            a_ix[j] = ix;
+        }
+    }
+    // byte offset of this lane's 16 bytes of the wave's first fragment (n tile, K-step 0, hi); the other three n tiles of the
+    // wave lie whole multiples of wstride further on, which travels in the scalar offset of the load
+    const unsigned wv0 = (unsigned)(((long)(n_base / 16 + wave * NFN) * nk) * 2048 + lane * 16);
+    const unsigned wstride = (unsigned)nk * 2048u;
+    f32x4_t acc[NFN][NFM];
+#pragma unroll
+    for (int a = 0; a < NFN; ++a)
+#pragma unroll
+        for (int b = 0; b < NFM; ++b) acc[a][b] = f32x4_t{0};
+    u32x4_t wh0[NFN], wl0[NFN], wh1[NFN], wl1[NFN];
+    // K position of the next A issue, all scalars: tap (ky, kx), channel byte offset kc4, byte offset a_so of that (tap,
+    // chunk) relative to a row's first tap, byte offset wk of the K-step inside a weight row; w_saved lags one issue behind
+    const int cin4 = p.Cin * 4;
+    int kc4 = 0, kx = 0, ky = 0;
+    unsigned a_so = 0, x2_so = 0, wk = 0, w_saved = 0;
+    int islot = 0;  // ring slot of the next A issue
+
+#define AVCER_WD_LOAD_W(WH, WL)                                                                                         \
+    do {                                                                                                                \
+        unsigned so_ = w_saved * 16u; /* K-step index * 2048 */                                                         \
+        _Pragma("unroll") for (int fn = 0; fn < NFN; ++fn) {                                                             \
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(WH[fn]) : "v"(wv0), "s"(wfrs), "s"(so_) : "memory"); \
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(WL[fn]) : "v"(wv0), "s"(wfrs), "s"(so_) : "memory"); \
+            so_ += wstride;                                                                                             \
+        }                                                                                                               \
+    } while (0)
+// T >= nk: past the end of K -- four out-of-range DMA pieces (zeros into the free slot) keep the count exact
+#define AVCER_WD_ISSUE_A(T)                                                                                             \
+    do {                                                                                                                \
+        char* sa_ = smem + islot * ABYTES + wave * 4096;                                                                \
+        islot = islot == STAGES - 1 ? 0 : islot + 1;                                                                    \
+        if ((T) >= nk) {                                                                                                \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) dma16(xrs, sa_ + j * 1024, OOB);                               \
+        } else {                                                                                                        \
+            w_saved = wk;                                                                                               \
+            if constexpr (GATHER == 0) { /* plain matrix: one tap, channels in order */                                 \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) dma16(xrs, sa_ + j * 1024, a_offk[j], a_so);               \
+                a_so += ROWB;                                                                                           \
+                wk += ROWB;                                                                                             \
+            } else if (GATHER == 1 && (T) >= n1) { /* tail of K: the second source */                                   \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) dma16(x2rs, sa_ + j * 1024, a_off2k[GATHER == 1 ? j : 0], x2_so); \
+                x2_so += ROWB;                                                                                          \
+                wk += ROWB;                                                                                             \
+            } else if constexpr (GATHER == 1) {                                                                         \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) dma16(xrs, sa_ + j * 1024, a_offk[j], a_so);               \
+                a_so += ROWB;                                                                                           \
+                wk += ROWB;                                                                                             \
+            } else {                                                                                                    \
+                if constexpr (GATHER == 3) {                                                                            \
+                    const int dy = ky * p.dh, dx = kx * p.dw;                                                           \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
+                        const int iy = a_iy[GATHER == 3 ? j : 0] + dy, ix = a_ix[GATHER == 3 ? j : 0] + dx;             \
+                        const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.Wd);               \
+                        /* the tap offset goes into the per-lane offset: the hardware bounds test ignores the scalar */ \
+                        /* offset, and a border row's base offset is negative (wrapped) until its tap is added        */ \
+                        dma16(xrs, sa_ + j * 1024, ok ? a_offk[j] + a_so : OOB);                                        \
+                    }                                                                                                   \
+                } else {                                                                                                \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) dma16(xrs, sa_ + j * 1024, a_offk[j], a_so);           \
+                }                                                                                                       \
+                if (p.tap_inner) { /* (channel chunk, ky, kx) order: the next tap of the same chunk */                  \
+                    a_so += p.tapW4;                                                                                    \
+                    wk += cin4;                                                                                         \
+                    if (++kx == p.KW) {                                                                                 \
+                        kx = 0;                                                                                         \
+                        a_so += p.tapH4 - p.KW * p.tapW4;                                                               \
+                        if (++ky == p.KH) { ky = 0; a_so += ROWB - p.KH * p.tapH4; kc4 += ROWB; wk = (unsigned)kc4; }   \
+                    }                                                                                                   \
+                } else { /* (ky, kx, channel chunk) order */                                                            \
+                    a_so += ROWB;                                                                                       \
+                    wk += ROWB;                                                                                         \
+                    kc4 += ROWB;                                                                                        \
+                    if (kc4 == cin4) {                                                                                  \
+                        kc4 = 0;                                                                                        \
+                        a_so += p.tapW4 - cin4;                                                                         \
+                        if (++kx == p.KW) { kx = 0; a_so += p.tapH4 - p.KW * p.tapW4; ++ky; }                           \
+                    }                                                                                                   \
+                }                                                                                                       \
+            }                                                                                                           \
+        }                                                                                                               \
+    } while (0)
+#define AVCER_WD_WAIT(N, H, L) asm volatile("s_waitcnt vmcnt(" #N ")" : AVCER_WREGS4(H, L)::"memory")
+#define AVCER_WD_READ(R, AH, AL)                                                                                        \
+    do {                                                                                                                \
+        const int row = (R) * 16 + (lane & 15);                                                                         \
+        AH = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, g));                                                      \
+        AL = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, 4 + g));                                                  \
+    } while (0)
+#define AVCER_WD_MFMA(R, AH, AL, WH, WL)                                                                                \
+    _Pragma("unroll") for (int fn = 0; fn < NFN; ++fn) {                                                                 \
+        const bf16x8_t whi = __builtin_bit_cast(bf16x8_t, WH[fn]), wlo = __builtin_bit_cast(bf16x8_t, WL[fn]);          \
+        f32x4_t& c_ = acc[fn][R];                                                                                       \
+        c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, AH, c_, 0, 0, 0);                                             \
+        c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, AL, c_, 0, 0, 0);                                             \
+        c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, AH, c_, 0, 0, 0);                                             \
+    }
+#define AVCER_WD_STEP(S, WH, WL, WHN, WLN)                                                                              \
+    do {                                                                                                                \
+        AVCER_WD_LOAD_W(WHN, WLN);                                                                                      \
+        asm volatile("" ::: "memory");                                                                                  \
+        AVCER_WD_ISSUE_A((S) + 2);                                                                                      \
+        asm volatile("" ::: "memory");                                                                                  \
+        const char* sa = smem + rslot * ABYTES;                                                                         \
+        rslot = rslot == STAGES - 1 ? 0 : rslot + 1;                                                                    \
+        /* one 16-position tile at a time: the two fragment reads of tile t+1 are issued in front of the 12 MFMAs of */ \
+        /* tile t (two register pairs, ping-pong).  The scheduling fences pin that order: left alone, hipcc either   */ \
+        /* hoists all sixteen reads (no registers left for them) or sinks each pair behind the MFMAs it should cover */ \
+        bf16x8_t a0h, a0l, a1h, a1l;                                                                                    \
+        AVCER_WD_READ(0, a0h, a0l);                                                                                     \
+        _Pragma("unroll") for (int t = 0; t < NFM; t += 2) {                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            AVCER_WD_READ(t + 1, a1h, a1l);                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            AVCER_WD_MFMA(t, a0h, a0l, WH, WL);                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            if (t + 2 < NFM) AVCER_WD_READ(t + 2, a0h, a0l);                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            AVCER_WD_MFMA(t + 1, a1h, a1l, WH, WL);                                                                     \
+        }                                                                                                               \
+        _Pragma("unroll") for (int a = 0; a < NFN; ++a) _Pragma("unroll") for (int b = 0; b < NFM; ++b)                   \
+            asm volatile("" : "+v"(acc[a][b]));                                                                         \
+        AVCER_WD_WAIT(4, WHN, WLN);                                                                                     \
+        __builtin_amdgcn_s_barrier();                                                                                   \
+        asm volatile("" ::: "memory");                                                                                  \
+    } while (0)
+
+    int rslot = 0;  // ring slot the current step reads
+    AVCER_WD_ISSUE_A(0);
+    asm volatile("" ::: "memory");
+    AVCER_WD_LOAD_W(wh0, wl0);
+    asm volatile("" ::: "memory");
+    AVCER_WD_ISSUE_A(1);
+    asm volatile("" ::: "memory");
+    AVCER_WD_WAIT(4, wh0, wl0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int s = 0; s < nk; s += 2) {  // nk is even (checked by the launcher)
+        AVCER_WD_STEP(s, wh0, wl0, wh1, wl1);
+        AVCER_WD_STEP(s + 1, wh1, wl1, wh0, wl0);
+    }
+    // the dummy operations of the last steps are still in flight: drain them before the registers are reused
+    AVCER_WD_WAIT(0, wh0, wl0);
+    AVCER_WD_WAIT(0, wh1, wl1);
+#undef AVCER_WD_STEP
+#undef AVCER_WD_MFMA
+#undef AVCER_WD_READ
+#undef AVCER_WD_WAIT
+#undef AVCER_WD_ISSUE_A
+#undef AVCER_WD_LOAD_W
+    const int c0 = n_base + wave * (BN / 4);
+    if (p.act == 2) wd_epilogue<OUT, 2, NFN, NFM>(p, acc, m_base, c0, lane);
+    else if (p.act == 1) wd_epilogue<OUT, 1, NFN, NFM>(p, acc, m_base, c0, lane);
+    else wd_epilogue<OUT, 0, NFN, NFM>(p, acc, m_base, c0, lane);
+#endif
+}
+
+template <int OUT>
+void launch_wd(const GemmParams& p0, hipStream_t st) {
+    GemmParams p = p0;
+    p.ntm = (p.M + 127) / 128;
+    p.gm = 8;
+    p.ntn = p.N / 256;
+    p.nwg = p.ntm * p.ntn;
+    if (p.X2) conv_gemm_wd_kernel<OUT, 1><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
+    else if (p.fast && p.KH * p.KW == 1) conv_gemm_wd_kernel<OUT, 0><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
+    else if (p.fast) conv_gemm_wd_kernel<OUT, 2><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
+    else conv_gemm_wd_kernel<OUT, 3><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
+}
+
 // Tile width by shape.  K <= 128: bandwidth-bound 1x1 convolutions, the 48 KiB BN = 64 tile lets three blocks share a CU.
 inline bool choose_bn128(const GemmParams& p) { return p.K > 128; }
 
@@ -608,9 +896,10 @@ int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1)
 int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const void* x, const void* w,
                      const float* scale, const float* bias, const void* residual, void* y, hipStream_t st,
                      const void* x2) {
-    if (dtype < 0 || dtype > 6) return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d", dtype);
+    if (dtype < 0 || dtype > 8) return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d", dtype);
     const int es = (dtype == 1 || dtype == 2) ? 2 : 4;
-    const bool a_split = dtype == 5 || dtype == 6, o_split = dtype == 4 || dtype == 5;
+    const bool wdirect = dtype >= 7;  // 7 / 8: dtype 5 / 6 with the weights in fragment order (conv_gemm_wd_kernel)
+    const bool a_split = dtype == 5 || dtype == 6 || wdirect, o_split = dtype == 4 || dtype == 5 || dtype == 7;
     const int vec = 16 / es;
     const int bk = ROWB / es;  // 32 elements (f32, split-bf16) or 64 (bf16) per K-step
     const long M = (long)d.batch * d.out_h * d.out_w;
@@ -667,13 +956,21 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
         p.sB2 = d.x2_stride_b; p.sH2 = d.x2_stride_h; p.sW2 = d.x2_stride_w; p.coff2 = d.x2_coff; p.st2 = d.x2_stride;
     }
     p.ntn = 0; p.nwg = 0; p.groups = groups;
-    if (d.tile_n != 0 && d.tile_n != 64 && d.tile_n != 128) return set_err(ctx, AVCER_EINVAL, "conv_gemm: tile_n %d (0, 64 or 128)", d.tile_n);
+    if (d.tile_n != 0 && d.tile_n != 64 && d.tile_n != 128 && d.tile_n != 256)
+        return set_err(ctx, AVCER_EINVAL, "conv_gemm: tile_n %d (0, 64, 128 or 256)", d.tile_n);
     p.tile_n = d.tile_n;
+    p.WF = wdirect ? (const char*)w : nullptr;
+    if (wdirect && (d.n % 256 || (K / bk) % 2 || groups != 1 || d.tile_n == 64 || d.tile_n == 128))
+        return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d needs N %% 256 == 0, an even number of K-steps, one group (N=%d, K=%ld)",
+                       dtype, d.n, K);
+    p.tapH4 = (int)((long)d.dil_h * d.x_stride_h * 4);
+    p.tapW4 = (int)((long)d.dil_w * d.x_stride_w * 4);
     // Fast gather: Cin a multiple of the K-step, no padding, and the last tap of the last output position inside the
     // input -- true for every Linear, 1x1 convolution and un-padded Conv1d of both models.
     p.fast = d.cin % bk == 0 && d.pad_h == 0 && d.pad_w == 0 &&
              (long)(d.out_h - 1) * d.stride_h + (long)(d.kh - 1) * d.dil_h < d.in_h &&
              (long)(d.out_w - 1) * d.stride_w + (long)(d.kw - 1) * d.dil_w < d.in_w;
+    if (wdirect && x2 && !p.fast) return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d with a second source needs a pad-free gather", dtype);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     TRY(prof_begin(ctx, st, &ev0, &ev1));
     switch (dtype) {
@@ -683,7 +980,9 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
         case 3: launch_t<2, 0>(p, st); break;  // f32 (split on the fly) -> f32
         case 4: launch_t<2, 2>(p, st); break;  // f32 (split on the fly) -> sp32
         case 5: launch_t<3, 2>(p, st); break;  // sp32 -> sp32
-        default: launch_t<3, 0>(p, st); break; // sp32 -> f32
+        case 6: launch_t<3, 0>(p, st); break;  // sp32 -> f32
+        case 7: launch_wd<2>(p, st); break;    // sp32 -> sp32, weights direct
+        default: launch_wd<0>(p, st); break;   // sp32 -> f32, weights direct
     }
     if (ev1) (void)hipEventRecord(ev1, st);
     hipError_t e = hipGetLastError();

@@ -1049,6 +1049,22 @@ __global__ void split_weight_rows_kernel(const float* __restrict__ w, bf16_t* __
     out[o + 32] = f2bf(v - bf2f(h));
 }
 
+// The row-split weights once more, in MFMA fragment order for conv_gemm_wd_kernel (gemm.hip): [N/16][K/32][hi, lo][64 lanes]
+// [8 bf16], lane l of a fragment = stored row 16 nt + (l & 15), K elements 8 (l >> 4) .. + 8 of the K-step -- the 16 bytes
+// that lane feeds the MFMA as its A operand, so a wave fetches a whole fragment with one coalesced 1 KiB load.  `rows` is
+// the output of split_weight_rows_kernel (rows already permuted, hi / lo per 32-element K group); one thread per 16 bytes.
+__global__ void weight_frags_kernel(const uint4* __restrict__ rows, uint4* __restrict__ out, int n, int k) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // destination 16-byte piece
+    const int nk = k >> 5;
+    if (i >= (size_t)n * nk * 8) return;
+    const int lane = i & 63, hl = (i >> 6) & 1;
+    const size_t f = i >> 7;  // (n tile, K-step)
+    const int ks = (int)(f % nk), nt = (int)(f / nk);
+    const int row = nt * 16 + (lane & 15), chunk = lane >> 4;
+    // source: row-major sp32, 128 bytes per (row, K-step): 64 hi then 64 lo, 16-byte chunks
+    out[i] = rows[((size_t)row * nk + ks) * 8 + hl * 4 + chunk];
+}
+
 __global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = f2bf(x[i]);
@@ -1472,6 +1488,13 @@ int k_split_weight_rows(avcer_ctx* ctx, const float* w, bf16_t* out, int n, int 
     if (n % 32 || k % 32) return set_err(ctx, AVCER_EINVAL, "split_weight_rows: n=%d and k=%d must be multiples of 32", n, k);
     split_weight_rows_kernel<<<cdiv((long)n * k, 256), 256, 0, st>>>(w, out, n, k);
     CHECK_LAUNCH(ctx, "split_weight_rows");
+    return AVCER_OK;
+}
+
+int k_weight_frags(avcer_ctx* ctx, const bf16_t* rows, bf16_t* out, int n, int k, hipStream_t st) {
+    if (n % 16 || k % 32) return set_err(ctx, AVCER_EINVAL, "weight_frags: n=%d must be a multiple of 16, k=%d of 32", n, k);
+    weight_frags_kernel<<<cdiv((long)n * (k / 32) * 8, 256), 256, 0, st>>>((const uint4*)rows, (uint4*)out, n, k);
+    CHECK_LAUNCH(ctx, "weight_frags");
     return AVCER_OK;
 }
 

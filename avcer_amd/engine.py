@@ -284,6 +284,14 @@ class Engine:
         self._check(self.lib.avcer_split_weight_rows(self.ctx, _ptr(w), _ptr(out), int(w.shape[0]), int(w.shape[1]), self._stream()))
         return out
 
+    def weight_frags(self, w):
+        """f32 [N,K] weight matrix -> the fragment-order split layout of conv_gemm dtypes 7 / 8 (int16 tensor of 2*N*K entries)."""
+        w = self._dev(w, torch.float32)
+        rows = self.split_weight_rows(w)
+        out = torch.empty_like(rows)
+        self._check(self.lib.avcer_weight_frags(self.ctx, _ptr(rows), _ptr(out), int(w.shape[0]), int(w.shape[1]), self._stream()))
+        return out
+
     def conv_gemm_dual(self, desc: ConvDesc, dtype: int, x, x2, w, scale, bias, residual, y):
         self._check(self.lib.avcer_conv_gemm_dual(self.ctx, C.byref(desc), dtype, _ptr(x), _ptr(x2), _ptr(w), _ptr(scale),
                                                   _ptr(bias), _ptr(residual), _ptr(y), self._stream()))

@@ -182,7 +182,9 @@ int avcer_fuse(avcer_ctx* ctx, const float* stat, const float* dyn_logits, const
  * parity tests and micro-benchmarks:  Y[m, n] = act(scale[n] * sum_k A[m,k] * W[n,k] + bias[n] (+ R[m,n]))
  * where A is gathered from an NHWC tensor.  See avcer_conv_desc. dtype: 0 = f32 in/out, 1 = bf16 in/out,
  * 2 = bf16 in / f32 out; split-bf16 arithmetic with w pre-split by avcer_split_weight_rows: 3 = f32 in / f32 out,
- * 4 = f32 in / sp32 out, 5 = sp32 in / sp32 out (+ sp32 residual), 6 = sp32 in / f32 out (+ f32 residual).
+ * 4 = f32 in / sp32 out, 5 = sp32 in / sp32 out (+ sp32 residual), 6 = sp32 in / f32 out (+ f32 residual);
+ * 7 / 8 = 5 / 6 with w in fragment order (avcer_weight_frags): the weights-direct form of the kernel, bit-identical results,
+ * for n % 256 == 0, an even number of 32-element K-steps and groups <= 1 (anything else is AVCER_EINVAL: use 5 / 6).
  * "sp32" storage = per aligned group of 32 channels, 32 bf16 hi values then 32 bf16 lo values (x = hi + lo), i.e. the
  * layout avcer_split_weights produces; 4 bytes per element. */
 typedef struct avcer_conv_desc {
@@ -205,8 +207,8 @@ typedef struct avcer_conv_desc {
      * K elements [kh*kw*cin, kh*kw*cin + x2_cin) of every row come from x2 at position (oy*x2_stride, ox*x2_stride). */
     int32_t x2_cin, x2_coff, x2_stride;
     int64_t x2_stride_b, x2_stride_h, x2_stride_w;
-    int32_t tile_n;                  /* output-channel width of the block tile: 0 = chosen by the library, 64 or 128 (128 needs
-                                        n % 128 == 0).  A tuning knob: results do not depend on it. */
+    int32_t tile_n;                  /* output-channel width of the block tile: 0 = chosen by the library, 64 or 128 (n % 128 == 0);
+                                        dtypes 7 / 8 always use 256 (0 or 256).  A tuning knob: results do not depend on it. */
 } avcer_conv_desc;
 
 int avcer_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, const void* x, const void* w,
@@ -252,6 +254,12 @@ int avcer_split_weights(avcer_ctx* ctx, const float* w, void* out, size_t numel,
  * With weights as the MFMA A operand this leaves each lane with 8 consecutive output channels, i.e. 16-byte pieces of
  * the output row (direct whole-line stores).  scale / bias / residual / output stay in natural channel order. */
 int avcer_split_weight_rows(avcer_ctx* ctx, const float* w, void* out, int n, int k, avcer_stream_t stream);
+
+/* The output of avcer_split_weight_rows once more in MFMA fragment order, the weight layout of avcer_conv_gemm dtypes 7 / 8
+ * (conv_gemm_wd_kernel: weight fragments go straight from global memory to the registers, only the activation tile passes
+ * through LDS): [n/16][k/32][hi, lo][64 lanes][16 bytes], lane l = stored row 16 t + (l & 15), K elements 8 (l >> 4) .. + 8.
+ * rows, out: device pointers, n * k * 4 bytes each; n a multiple of 16, k of 32. */
+int avcer_weight_frags(avcer_ctx* ctx, const void* rows, void* out, int n, int k, avcer_stream_t stream);
 
 /* Measured ceilings of the GPU this context lives on (about 0.2 s): dense bf16 MFMA issue rate of a register-only
  * v_mfma_f32_16x16x32_bf16 loop in TFLOP/s, and the bandwidth of a 1 GiB -> 1 GiB 16-byte-per-lane copy in TB/s (bytes read

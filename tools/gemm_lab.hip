@@ -57,6 +57,15 @@ __device__ __forceinline__ void tile_of_block(const P& p, int& tile_m, int& tile
 
 template <int NFN, int NFM>
 __device__ __forceinline__ void store_acc(const P& p, f32x4_t (&acc)[NFN][NFM], int m0, int n0, int lane) {
+#ifdef LAB_NOEPI
+    float sacc = 0.f;
+#pragma unroll
+    for (int a = 0; a < NFN; ++a)
+#pragma unroll
+        for (int b = 0; b < NFM; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (sacc == 12345.678f) p.Y[0] = sacc;
+    return;
+#endif
 #pragma unroll
     for (int fn = 0; fn < NFN; ++fn)
 #pragma unroll
@@ -139,35 +148,25 @@ __global__ void __launch_bounds__(256, 2) gemm_base(const P p) {
 }
 
 // ------------------------------------------------------------------------------------------------ wdirect
-// WMW x WNW waves (4 in all); STAGES-deep ring for the A tile; W fragments of step s+1 are requested at the top of step s.
-// Vector-memory operations of a wave, in issue order:  prologue A(0) W(0) A(1);  step s: W(s+1) [2 NFN loads]  A(s+2) [4 DMA].
+// One 128 x BN output tile, 4 waves side by side along n (each 128 x BN/4); 3-stage ring for the A tile; W fragments of step
+// s+1 are requested at the top of step s.  Vector-memory operations of a wave, in issue order:
+//   prologue A(0) W(0) A(1);   step s: W(s+1) [2 NFN loads]  A(s+2) [4 DMA pieces].
 // The wait that ends step s is s_waitcnt vmcnt(4): everything up to W(s+1) -- hence also A(s+1), issued one step earlier --
 // has landed, the four DMA pieces of A(s+2) stay in flight across the barrier.  Past the end of K the same operations are
 // issued with a clamped step index (harmless re-loads into a free slot / dead registers), so the count is exact.
-template <int WMW, int WNW, int STAGES, int BN = 128>
-__global__ void __launch_bounds__(256, 2) gemm_wdirect(const P p) {
+constexpr int WD_STAGES = 3, WD_ABYTES = 128 * ROWB;
+
+#define LAB_WREGS2(H, L) "+v"(H[0]), "+v"(L[0]), "+v"(H[1]), "+v"(L[1])
+#define LAB_WREGS4(H, L) "+v"(H[0]), "+v"(L[0]), "+v"(H[1]), "+v"(L[1]), "+v"(H[2]), "+v"(L[2]), "+v"(H[3]), "+v"(L[3])
+
+template <int BN, int VAR, typename XRS>  // VAR bit 0: quarter ping-pong of the A fragment reads (BN = 256); bit 1: s_setprio around MFMAs
+__device__ __forceinline__ void wd_tile(const P& p, char* smem, const XRS xrs, const i32x4_t wfrs, int m_base, int n_base, int wave,
+                                        int lane) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the asm statements below only parse for the device target
-    constexpr int BMT = 128, ABYTES = BMT * ROWB;
-    constexpr int NFM = BMT / WMW / 16, NFN = BN / WNW / 16;
-    constexpr int MH = NFM > 4 && NFN > 2 ? 4 : NFM;  // A fragments held at a time (the wide tile reads them in two halves)
-    static_assert(WMW * WNW == 4 && STAGES == 3, "4 waves; the counted wait below is written for a 3-stage ring");
-    __shared__ __attribute__((aligned(16))) char smem[STAGES * ABYTES];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WNW, wn = wave % WNW;
-    int tile_m, tile_n;
-    tile_of_block(p, tile_m, tile_n);
-    const int m_base = tile_m * BMT, n_base = tile_n * BN;
-    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), (short)0, (int)p.a_bytes, 0x00020000);
-    i32x4_t wfrs;
-    {
-        const uint64_t a = (uint64_t)p.WF;
-        wfrs[0] = (int)(a & 0xffffffffu);
-        wfrs[1] = (int)((a >> 32) & 0xffffu);
-        wfrs[2] = (int)p.w_bytes;
-        wfrs[3] = 0x00020000;
-    }
-    const int lrow8 = lane >> 3, slot = lane & 7;
+    constexpr int BMT = 128, NFM = 8, NFN = BN / 64;
+    constexpr int MH = NFN > 2 ? 4 : NFM;  // A fragments held at a time (the wide tile reads them in two halves)
+    static_assert(NFN == 2 || NFN == 4, "BN = 128 or 256");
+    const int lrow8 = lane >> 3, slot = lane & 7, g = lane >> 4;
     const int nk = p.K / 32;
     unsigned a_off[4];
 #pragma unroll
@@ -178,7 +177,7 @@ __global__ void __launch_bounds__(256, 2) gemm_wdirect(const P p) {
     }
     unsigned wv[NFN];  // byte offset of this lane's 16 bytes of fragment (n tile, K-step 0, hi)
 #pragma unroll
-    for (int fn = 0; fn < NFN; ++fn) wv[fn] = (unsigned)(((long)(n_base / 16 + wn * NFN + fn) * nk) * 2048 + lane * 16);
+    for (int fn = 0; fn < NFN; ++fn) wv[fn] = (unsigned)(((long)(n_base / 16 + wave * NFN + fn) * nk) * 2048 + lane * 16);
     f32x4_t acc[NFN][NFM];
 #pragma unroll
     for (int a = 0; a < NFN; ++a)
@@ -196,22 +195,56 @@ __global__ void __launch_bounds__(256, 2) gemm_wdirect(const P p) {
     } while (0)
 #define LAB_ISSUE_A(KS)                                                                                                 \
     do {                                                                                                                \
-        char* sa_ = smem + ((KS) % STAGES) * ABYTES + wave * 4096;                                                      \
+        char* sa_ = smem + ((KS) % WD_STAGES) * WD_ABYTES + wave * 4096;                                                \
         const unsigned so_ = (unsigned)(min((KS), nk - 1) * ROWB);                                                       \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) dma16(xrs, sa_ + j * 1024, a_off[j], so_);                         \
     } while (0)
+#define LAB_WAIT(N, H, L)                                                                                               \
+    do {                                                                                                                \
+        if constexpr (NFN == 2) asm volatile("s_waitcnt vmcnt(" #N ")" : LAB_WREGS2(H, L)::"memory");                    \
+        else asm volatile("s_waitcnt vmcnt(" #N ")" : LAB_WREGS4(H, L)::"memory");                                      \
+    } while (0)
+#define LAB_READQ(Q, AH, AL)                                                                                            \
+    _Pragma("unroll") for (int fm = 0; fm < 2; ++fm) {                                                                   \
+        const int row = ((Q) * 2 + fm) * 16 + (lane & 15);                                                              \
+        AH[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, g));                                                  \
+        AL[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, 4 + g));                                              \
+    }
+#define LAB_MFMAQ(Q, AH, AL, WH, WL)                                                                                    \
+    _Pragma("unroll") for (int fn = 0; fn < NFN; ++fn) {                                                                 \
+        const bf16x8_t whi = __builtin_bit_cast(bf16x8_t, WH[fn]), wlo = __builtin_bit_cast(bf16x8_t, WL[fn]);          \
+        _Pragma("unroll") for (int fm = 0; fm < 2; ++fm) {                                                               \
+            f32x4_t& c_ = acc[fn][(Q) * 2 + fm];                                                                        \
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, AH[fm], c_, 0, 0, 0);                                     \
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, AL[fm], c_, 0, 0, 0);                                     \
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, AH[fm], c_, 0, 0, 0);                                     \
+        }                                                                                                               \
+    }
 #define LAB_STEP(S, WH, WL, WHN, WLN)                                                                                   \
     do {                                                                                                                \
         LAB_LOAD_W((S) + 1, WHN, WLN);                                                                                  \
         asm volatile("" ::: "memory");                                                                                  \
         LAB_ISSUE_A((S) + 2);                                                                                           \
         asm volatile("" ::: "memory");                                                                                  \
-        const char* sa = smem + ((S) % STAGES) * ABYTES;                                                                \
+        const char* sa = smem + ((S) % WD_STAGES) * WD_ABYTES;                                                          \
+        if constexpr ((VAR & 2) != 0) __builtin_amdgcn_s_setprio(1);                                                    \
+        if constexpr (NFN == 4 && (VAR & 1) != 0) {                                                                     \
+            bf16x8_t a0h[2], a0l[2], a1h[2], a1l[2];                                                                    \
+            LAB_READQ(0, a0h, a0l);                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            LAB_READQ(1, a1h, a1l); LAB_MFMAQ(0, a0h, a0l, WH, WL);                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            LAB_READQ(2, a0h, a0l); LAB_MFMAQ(1, a1h, a1l, WH, WL);                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            LAB_READQ(3, a1h, a1l); LAB_MFMAQ(2, a0h, a0l, WH, WL);                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+            LAB_MFMAQ(3, a1h, a1l, WH, WL);                                                                             \
+        } else {                                                                                                        \
         _Pragma("unroll") for (int h = 0; h < NFM / MH; ++h) {                                                           \
             if (MH < NFM) __builtin_amdgcn_sched_barrier(0); /* keep the halves apart: hipcc would hoist all 16 reads */  \
             bf16x8_t ahi[MH], alo[MH];                                                                                  \
             _Pragma("unroll") for (int fm = 0; fm < MH; ++fm) {                                                          \
-                const int row = wm * (BMT / WMW) + (h * MH + fm) * 16 + (lane & 15);                                    \
+                const int row = (h * MH + fm) * 16 + (lane & 15);                                                       \
                 ahi[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, g));                                         \
                 alo[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, 4 + g));                                     \
             }                                                                                                           \
@@ -225,52 +258,78 @@ __global__ void __launch_bounds__(256, 2) gemm_wdirect(const P p) {
                 }                                                                                                       \
             }                                                                                                           \
         }                                                                                                               \
+        }                                                                                                               \
+        if constexpr ((VAR & 2) != 0) __builtin_amdgcn_s_setprio(0);                                                    \
         _Pragma("unroll") for (int a = 0; a < NFN; ++a) _Pragma("unroll") for (int b = 0; b < NFM; ++b)                   \
             asm volatile("" : "+v"(acc[a][b]));                                                                         \
-        LAB_WAIT4(WHN, WLN);                                                                                            \
+        LAB_WAIT(4, WHN, WLN);                                                                                          \
         __builtin_amdgcn_s_barrier();                                                                                   \
         asm volatile("" ::: "memory");                                                                                  \
     } while (0)
 
-    const int g = lane >> 4;
     LAB_ISSUE_A(0);
     asm volatile("" ::: "memory");
     LAB_LOAD_W(0, wh0, wl0);
     asm volatile("" ::: "memory");
     LAB_ISSUE_A(1);
     asm volatile("" ::: "memory");
-    if constexpr (NFN == 2) {
-#define LAB_WAIT4(H, L) asm volatile("s_waitcnt vmcnt(4)" : "+v"(H[0]), "+v"(L[0]), "+v"(H[1]), "+v"(L[1])::"memory")
-        LAB_WAIT4(wh0, wl0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        for (int s = 0; s < nk; s += 2) {
-            LAB_STEP(s, wh0, wl0, wh1, wl1);
-            LAB_STEP(s + 1, wh1, wl1, wh0, wl0);
-        }
-#undef LAB_WAIT4
-    } else {
-#define LAB_WAIT4(H, L)                                                                                                 \
-    asm volatile("s_waitcnt vmcnt(4)" : "+v"(H[0]), "+v"(L[0]), "+v"(H[1]), "+v"(L[1]), "+v"(H[2]), "+v"(L[2]), "+v"(H[3]), "+v"(L[3])::"memory")
-        LAB_WAIT4(wh0, wl0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        for (int s = 0; s < nk; s += 2) {
-            LAB_STEP(s, wh0, wl0, wh1, wl1);
-            LAB_STEP(s + 1, wh1, wl1, wh0, wl0);
-        }
-#undef LAB_WAIT4
+    LAB_WAIT(4, wh0, wl0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int s = 0; s < nk; s += 2) {
+        LAB_STEP(s, wh0, wl0, wh1, wl1);
+        LAB_STEP(s + 1, wh1, wl1, wh0, wl0);
     }
-    // the clamped operations issued by the last steps are still in flight: drain them before the wave ends
-    if constexpr (NFN == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wh0[0]), "+v"(wl0[0]), "+v"(wh0[1]), "+v"(wl0[1]), "+v"(wh1[0]), "+v"(wl1[0]), "+v"(wh1[1]), "+v"(wl1[1])::"memory");
-    else
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(wh0[0]), "+v"(wl0[0]), "+v"(wh0[1]), "+v"(wl0[1]), "+v"(wh0[2]), "+v"(wl0[2]), "+v"(wh0[3]), "+v"(wl0[3]),
-                     "+v"(wh1[0]), "+v"(wl1[0]), "+v"(wh1[1]), "+v"(wl1[1]), "+v"(wh1[2]), "+v"(wl1[2]), "+v"(wh1[3]), "+v"(wl1[3])::"memory");
-    store_acc<NFN, NFM>(p, acc, m_base + wm * (BMT / WMW), n_base + wn * (BN / WNW), lane);
+    // the clamped operations issued by the last steps are still in flight: drain them before the epilogue / the next tile
+    LAB_WAIT(0, wh0, wl0);
+    LAB_WAIT(0, wh1, wl1);
+    store_acc<NFN, NFM>(p, acc, m_base, n_base + wave * (BN / 4), lane);
 #undef LAB_STEP
+#undef LAB_MFMAQ
+#undef LAB_READQ
+#undef LAB_WAIT
 #undef LAB_ISSUE_A
 #undef LAB_LOAD_W
 #endif
+}
+
+__device__ __forceinline__ i32x4_t make_rsrc(const void* ptr, unsigned bytes) {
+    const uint64_t a = (uint64_t)ptr;
+    i32x4_t r;
+    r[0] = (int)(a & 0xffffffffu);
+    r[1] = (int)((a >> 32) & 0xffffu);
+    r[2] = (int)bytes;
+    r[3] = 0x00020000;
+    return r;
+}
+
+template <int BN, int BPC, int VAR = 0>
+__global__ void __launch_bounds__(256, BPC) gemm_wdirect(const P p) {
+    __shared__ __attribute__((aligned(16))) char smem[WD_STAGES * WD_ABYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile_m, tile_n;
+    tile_of_block(p, tile_m, tile_n);
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), (short)0, (int)p.a_bytes, 0x00020000);
+    wd_tile<BN, VAR>(p, smem, xrs, make_rsrc(p.WF, p.w_bytes), tile_m * 128, tile_n * BN, wave, lane);
+}
+
+// Persistent form: 2 resident blocks per CU walk a host-built item list (item = tile kind | m tile | n tile in units of 128
+// columns), big 128 x 256 tiles first, then 128 x 128 tiles for the remainder rows, so that the last partial round of the
+// grid is made of half-size pieces.  The tile shape does not change any element's accumulation order: results stay
+// bit-identical to every other form.
+__global__ void __launch_bounds__(256, 2) gemm_persist(const P p, const int* __restrict__ items, int n_items) {
+    __shared__ __attribute__((aligned(16))) char smem[WD_STAGES * WD_ABYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.A), (short)0, (int)p.a_bytes, 0x00020000);
+    const i32x4_t wfrs = make_rsrc(p.WF, p.w_bytes);
+    for (int j = blockIdx.x; j < n_items; j += gridDim.x) {
+        const int it = __builtin_amdgcn_readfirstlane(items[j]);
+        const int tm = (it >> 12) & 0x3ffff, tn = it & 0xfff;
+        if (it < 0) wd_tile<256, 0>(p, smem, xrs, wfrs, tm * 128, tn * 128, wave, lane);
+        else wd_tile<128, 0>(p, smem, xrs, wfrs, tm * 128, tn * 128, wave, lane);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -358,11 +417,60 @@ int main(int argc, char** argv) {
     auto run_base = [&] { gemm_base<<<p.nwg, 256>>>(p); };
     P q = p;
     q.Y = dY1;
-    auto run_w22 = [&] { gemm_wdirect<2, 2, 3><<<q.nwg, 256>>>(q); };
-    auto run_w14 = [&] { gemm_wdirect<1, 4, 3><<<q.nwg, 256>>>(q); };
     P q2 = q;
     q2.ntn = N / 256; q2.nwg = q2.ntm * q2.ntn;
-    auto run_w256 = [&] { gemm_wdirect<1, 4, 3, 256><<<q2.nwg, 256>>>(q2); };
+    auto run_w128 = [&] { gemm_wdirect<128, 2><<<q.nwg, 256>>>(q); };
+    auto run_w128x3 = [&] { gemm_wdirect<128, 3><<<q.nwg, 256>>>(q); };
+    auto run_w256 = [&] { gemm_wdirect<256, 2><<<q2.nwg, 256>>>(q2); };
+    auto run_w256pp = [&] { gemm_wdirect<256, 2, 1><<<q2.nwg, 256>>>(q2); };
+    auto run_w256prio = [&] { gemm_wdirect<256, 2, 2><<<q2.nwg, 256>>>(q2); };
+    auto run_w256both = [&] { gemm_wdirect<256, 2, 3><<<q2.nwg, 256>>>(q2); };
+    // persistent schedule: m tiles [0, mb) as 128 x 256 tiles, the rest as 128 x 128 tiles; mb by a round-robin makespan model
+    const int G = 512, ntm = p.ntm, nt256 = N / 256, nt128 = N / 128;
+    const double t_big = 1.84, t_mid = 1.0;  // relative tile times measured above (a 128 x 256 tile = 1.84 tiles of 128 x 128)
+    int best_mb = 0;
+    double best = 1e30;
+    for (int mb = 0; mb <= ntm; ++mb) {
+        const long nb = (long)mb * nt256, nm = (long)(ntm - mb) * nt128;
+        std::vector<double> load(G, 0.0);
+        for (long j = 0; j < nb + nm; ++j) load[j % G] += j < nb ? t_big : t_mid;
+        // two blocks share a CU: pair slots (b, b + 256 run on different CUs; use the max over slots as the makespan proxy)
+        const double mk = *std::max_element(load.begin(), load.end());
+        if (mk < best - 1e-9) { best = mk; best_mb = mb; }
+    }
+    std::vector<int> items;
+    auto push_region = [&](int m0, int m1, int ntn, int step128, int kindbit) {
+        // grouped order inside the region: 8 m tiles x all n tiles per group, n-major inside a group
+        std::vector<int> logical;
+        for (int gm0 = m0; gm0 < m1; gm0 += 8) {
+            const int gs = std::min(8, m1 - gm0);
+            for (int tn = 0; tn < ntn; ++tn)
+                for (int i = 0; i < gs; ++i) logical.push_back((int)((unsigned)kindbit << 31) | ((gm0 + i) << 12) | (tn * step128));
+        }
+        // XCD-aware placement: position j of the list is run by block j % G; blocks with equal (b % 8) share an XCD and get
+        // consecutive logical tiles of each round
+        const size_t base = items.size(), n = logical.size();
+        items.resize(base + n);
+        for (size_t r0 = 0; r0 < n; r0 += G) {
+            const size_t cnt = std::min((size_t)G, n - r0);
+            const size_t qd = cnt / 8, rm = cnt % 8;
+            for (size_t j = 0; j < cnt; ++j) {
+                const size_t xcd = j % 8, idx = j / 8;
+                const size_t lg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+                items[base + r0 + j] = logical[r0 + lg];
+            }
+        }
+    };
+    if (N % 256 == 0) push_region(0, best_mb, nt256, 2, 1);
+    push_region(N % 256 == 0 ? best_mb : 0, ntm, nt128, 1, 0);
+    int* dItems;
+    hipMalloc(&dItems, items.size() * 4);
+    hipMemcpy(dItems, items.data(), items.size() * 4, hipMemcpyHostToDevice);
+    const int n_items = (int)items.size();
+    auto run_pers = [&] { gemm_persist<<<std::min(G, n_items), 256>>>(q, dItems, n_items); };
+    printf("persistent schedule: %d of %d m tiles as 128x256 (%ld big + %ld mid items, model makespan %.2f vs %.2f all-mid, %.2f all-big)\n",
+           best_mb, ntm, (long)best_mb * nt256, (long)(ntm - best_mb) * nt128, best, std::ceil((double)ntm * nt128 / G) * t_mid,
+           std::ceil((double)ntm * nt256 / G) * t_big);
     std::vector<float> y0((size_t)M * N), y1((size_t)M * N);
     run_base();
     hipMemcpy(y0.data(), dY0, y0.size() * 4, hipMemcpyDeviceToHost);
@@ -370,9 +478,9 @@ int main(int argc, char** argv) {
     double worst = 0;
     for (int t = 0; t < 64; ++t) {
         const long m = (long)rand() % M, n = rand() % N;
-        double s = 0;
-        for (int k = 0; k < K; ++k) s += (double)x[m * K + k] * w[(size_t)n * K + k];
-        worst = std::max(worst, std::fabs(s - y0[m * N + n]) / (std::fabs(s) + 1e-3));
+        double sum = 0;
+        for (int k = 0; k < K; ++k) sum += (double)x[m * K + k] * w[(size_t)n * K + k];
+        worst = std::max(worst, std::fabs(sum - y0[m * N + n]) / (std::fabs(sum) + 1e-3));
     }
     printf("M %d N %d K %d  blocks %d (%.2f rounds of 512)  base vs f64 spot check: max rel err %.2e\n", M, N, K, p.nwg, p.nwg / 512.0, worst);
     auto check = [&](const char* name, auto f) {
@@ -385,14 +493,20 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < y0.size(); ++i) bad += memcmp(&y0[i], &y1[i], 4) != 0;
         printf("%-14s %s, %zu of %zu values differ from base\n", name, hipGetErrorString(e), bad, y0.size());
     };
-    check("wdirect 2x2", run_w22);
-    check("wdirect 1x4", run_w14);
-    if (N % 256 == 0) check("wdirect 1x4 BN256", run_w256);
+    check("wdirect128", run_w128);
+    check("wdirect128x3", run_w128x3);
+    if (N % 256 == 0) check("wdirect256", run_w256);
+    if (N % 256 == 0) check("wd256 pingpong", run_w256pp);
+    if (N % 256 == 0) check("wd256 prio", run_w256prio);
+    if (N % 256 == 0) check("wd256 pp+prio", run_w256both);
+    check("persistent", run_pers);
     for (int round = 0; round < 3; ++round) {
-        const float t0 = time_ms(run_base, iters), t1 = time_ms(run_w22, iters), t2 = time_ms(run_w14, iters);
-        const float t3 = N % 256 == 0 ? time_ms(run_w256, iters) : 0.f;
-        printf("round %d   base %8.1f us %6.1f TF   wdirect2x2 %8.1f us %6.1f TF   wdirect1x4 %8.1f us %6.1f TF   1x4/BN256 %8.1f us %6.1f TF\n",
-               round, t0 * 1e3, flop / t0 / 1e9, t1 * 1e3, flop / t1 / 1e9, t2 * 1e3, flop / t2 / 1e9, t3 * 1e3, t3 > 0 ? flop / t3 / 1e9 : 0.0);
+        const float t0 = time_ms(run_base, iters), t1 = time_ms(run_w128, iters);
+        if (N % 256) { printf("round %d   base %7.1f us %5.1f TF | wd128 %7.1f us %5.1f TF\n", round, t0 * 1e3, flop / t0 / 1e9, t1 * 1e3, flop / t1 / 1e9); continue; }
+        const float t3 = time_ms(run_w256, iters), t4 = time_ms(run_w256pp, iters), t5 = time_ms(run_w256prio, iters), t6 = time_ms(run_w256both, iters);
+        printf("round %d   base %7.1f us %5.1f TF | wd128 %7.1f %5.1f | wd256 %7.1f %5.1f | pingpong %7.1f %5.1f | prio %7.1f %5.1f | pp+prio %7.1f %5.1f\n",
+               round, t0 * 1e3, flop / t0 / 1e9, t1 * 1e3, flop / t1 / 1e9, t3 * 1e3, flop / t3 / 1e9, t4 * 1e3, flop / t4 / 1e9, t5 * 1e3, flop / t5 / 1e9,
+               t6 * 1e3, flop / t6 / 1e9);
     }
     return 0;
 }

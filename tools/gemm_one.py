@@ -23,4 +23,4 @@ if __name__ == "__main__":
     shape = sys.argv[1] if len(sys.argv) > 1 else "l3c2"
     which = sys.argv[2] if len(sys.argv) > 2 else "x3s"
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-    run(Engine(0), [SHAPES[shape]()], {"f32": 0, "bf16": 1, "x3": 3, "x3s": 5}[which], iters, f"{shape} {which}")
+    run(Engine(0), [SHAPES[shape]()], {"f32": 0, "bf16": 1, "x3": 3, "x3s": 5, "x3w": 7}[which], iters, f"{shape} {which}")

@@ -94,18 +94,24 @@ def run(engine, layers, dtype, iters, title, tile_n=0):
     print(f"--- {title}")
     for L in layers:
         d = L["d"]
-        d.tile_n = tile_n if (tile_n != 128 or d.n % 128 == 0) else 0
+        d.tile_n = tile_n if ((tile_n != 128 or d.n % 128 == 0) and (tile_n != 256 or d.n % 256 == 0)) else 0
         ldt = dtype
-        if dtype == 5 and (d.x_stride_w % 32 or d.cin % 32):
+        if dtype in (5, 7) and (d.x_stride_w % 32 or d.cin % 32):
             ldt = 4  # stem: f32 image in, sp32 out
         m = d.batch * d.out_h * d.out_w
         k = d.kh * d.kw * d.cin
         x = torch.randn(max(L["in_elems"], d.x_stride_b * d.batch) + 64, device=engine.device).to(tin)
         g = L.get("groups", 1)
         w = (torch.randn(g * d.n * k, device=engine.device) / k ** 0.5).to(tin)
-        if dtype >= 3:
+        if dtype == 7:  # "x3w": the weights-direct form wherever the shape allows it, else the staged form (as the library does)
+            if ldt == 7 and g == 1 and d.n % 256 == 0 and (k // 32) % 2 == 0:
+                w = engine.weight_frags(w.reshape(d.n, k))
+            else:
+                ldt = 5 if ldt == 7 else ldt
+                w = engine.split_weight_rows(w.reshape(g * d.n, k))
+        elif dtype >= 3:
             w = engine.split_weight_rows(w.reshape(g * d.n, k))
-        if dtype in (4, 5) and d.y_ld % 32:
+        if dtype in (4, 5, 7) and d.y_ld % 32:
             continue
         ylen = m * max(d.y_ld, d.n) + 64
         y = torch.empty(ylen, device=engine.device, dtype=tin)
@@ -140,7 +146,7 @@ if __name__ == "__main__":
     ap.add_argument("--no-audio", action="store_true")
     a = ap.parse_args()
     eng = Engine(0)
-    for name, dt in (("f32", 0), ("bf16", 1), ("x3", 3), ("x3s", 5)):
+    for name, dt in (("f32", 0), ("bf16", 1), ("x3", 3), ("x3s", 5), ("x3w", 7)):
         if a.dtype in ("both", name):
             run(eng, static_layers(a.frames), dt, a.iters, f"static CNN, {a.frames} frames, {name}, tile_n={a.tile_n}", a.tile_n)
             if not a.no_audio:
