@@ -544,7 +544,9 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
             // layer of 32 tiles that takes the same 50 us either way.
             const int x3_saved = net.x3;
             net.x3 = 0;
-            net.gemm(linear_desc(nb, 2048, 512, 0), "fc1.w", nullptr, net.F("fc1.b"), pooled, nullptr, fo, 0, 0);
+            avcer_conv_desc fd = linear_desc(nb, 2048, 512, 0);
+            fd.tile_n = 64;  // 128 x 64 tiles: twice the blocks of a grid that does not fill the chip anyway
+            net.gemm(fd, "fc1.w", nullptr, net.F("fc1.b"), pooled, nullptr, fo, 0, 0);
             net.x3 = x3_saved;
         }
         if (logits || probs)

@@ -579,14 +579,16 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
 //   * the WEIGHT fragments never touch LDS.  The weights are stored once more in MFMA fragment order -- [N/16][K/32][hi, lo]
 //     [64 lanes][16 B], rows permuted like every split weight -- so a wave gets a whole fragment with ONE coalesced 1 KiB
 //     load straight into the registers the MFMA reads (inline asm: hipcc would otherwise drain the LDS-DMA queue for it);
-//   * only the activation tile goes through LDS (16 KiB per K-step instead of 32): a THREE-stage ring fits twice per CU
-//     (48 KiB per block), the tile of step s+2 stays in flight across the barrier behind a counted s_waitcnt vmcnt(4);
+//   * only the activation tile goes through LDS (16 KiB per K-step instead of 32): a FOUR-slot ring fits twice per CU
+//     (64 KiB per block); the tile of step s+2 is requested at the top of step s and stays in flight across the barrier;
 //   * 128 x 256 tiles, the four waves side by side along n, each owning all 128 positions x 64 channels: nobody loads a
 //     weight fragment twice and one LDS fragment read feeds 12 MFMAs (the 2 x 2 form: 6); the fragments of 16 positions are
-//     read while the 12 MFMAs of the previous 16 run (two register pairs, ping-pong).
+//     read while the 12 MFMAs of the previous 16 run (two register pairs, ping-pong) -- across K-steps too: the step's one
+//     barrier sits in the MIDDLE of its MFMA work, so the step boundary is seamless (no wait, no exposed LDS latency).
 // Same product order per output element as conv_gemm_kernel<3, *, *>: bit-identical results (tests/test_gpu_gemm_wd.py).
 // Vector-memory operations of a wave, in issue order: prologue A(0) W(0) A(1); step s: W(s+1) [8 loads], A(s+2) [4 DMA
-// pieces].  The wait that ends step s is vmcnt(4): everything up to W(s+1), hence also A(s+1), has landed.  Past the end of
+// pieces].  Two counted waits per step: vmcnt(12) in front of the mid-step barrier (A(s+1), issued a step earlier, has
+// landed; this step's 12 operations may still fly) and vmcnt(4) at the end (W(s+1) is in its registers).  Past the end of
 // K the same operations are issued on dummy targets (out-of-range DMA = zeros into a free slot, a repeated weight load into
 // dead registers), so the count is exact.  The K position is a handful of scalars advanced by additions; GATHER selects the
 // activation addressing at compile time: 0 = plain matrix (every Linear and 1x1 convolution: one tap, no padding), 1 = the
@@ -628,7 +630,7 @@ __device__ __forceinline__ void wd_epilogue(const GemmParams& p, f32x4_t (&acc)[
 template <int OUT, int GATHER>
 __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the asm statements below only parse for the device target
-    constexpr int BMT = 128, BN = 256, NFM = 8, NFN = 4, STAGES = 3, ABYTES = BMT * ROWB;
+    constexpr int BMT = 128, BN = 256, NFM = 8, NFN = 4, STAGES = 4, ABYTES = BMT * ROWB;
     __shared__ __attribute__((aligned(16))) char smem[STAGES * ABYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -769,11 +771,11 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
         }                                                                                                               \
     } while (0)
 #define AVCER_WD_WAIT(N, H, L) asm volatile("s_waitcnt vmcnt(" #N ")" : AVCER_WREGS4(H, L)::"memory")
-#define AVCER_WD_READ(R, AH, AL)                                                                                        \
+#define AVCER_WD_READ(BASE, R, AH, AL)                                                                                  \
     do {                                                                                                                \
         const int row = (R) * 16 + (lane & 15);                                                                         \
-        AH = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, g));                                                      \
-        AL = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, 4 + g));                                                  \
+        AH = *reinterpret_cast<const bf16x8_t*>((BASE) + swz(row, g));                                                  \
+        AL = *reinterpret_cast<const bf16x8_t*>((BASE) + swz(row, 4 + g));                                              \
     } while (0)
 #define AVCER_WD_MFMA(R, AH, AL, WH, WL)                                                                                \
     _Pragma("unroll") for (int fn = 0; fn < NFN; ++fn) {                                                                 \
@@ -791,29 +793,38 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
         asm volatile("" ::: "memory");                                                                                  \
         const char* sa = smem + rslot * ABYTES;                                                                         \
         rslot = rslot == STAGES - 1 ? 0 : rslot + 1;                                                                    \
+        const char* sa_next = smem + rslot * ABYTES;                                                                    \
         /* one 16-position tile at a time: the two fragment reads of tile t+1 are issued in front of the 12 MFMAs of */ \
-        /* tile t (two register pairs, ping-pong).  The scheduling fences pin that order: left alone, hipcc either   */ \
-        /* hoists all sixteen reads (no registers left for them) or sinks each pair behind the MFMAs it should cover */ \
-        bf16x8_t a0h, a0l, a1h, a1l;                                                                                    \
-        AVCER_WD_READ(0, a0h, a0l);                                                                                     \
+        /* tile t (two register pairs, ping-pong), and the last tile's partner is tile 0 of the NEXT step: the loop   */ \
+        /* has no seam.  The scheduling fences pin that order: left alone, hipcc either hoists all sixteen reads (no  */ \
+        /* registers left for them) or sinks each pair behind the MFMAs it should cover.                              */ \
         _Pragma("unroll") for (int t = 0; t < NFM; t += 2) {                                                             \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
-            AVCER_WD_READ(t + 1, a1h, a1l);                                                                             \
+            AVCER_WD_READ(sa, t + 1, a1h, a1l);                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
             AVCER_WD_MFMA(t, a0h, a0l, WH, WL);                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
-            if (t + 2 < NFM) AVCER_WD_READ(t + 2, a0h, a0l);                                                            \
+            if (t + 2 < NFM) AVCER_WD_READ(sa, t + 2, a0h, a0l);                                                        \
+            else AVCER_WD_READ(sa_next, 0, a0h, a0l);                                                                   \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
             AVCER_WD_MFMA(t + 1, a1h, a1l, WH, WL);                                                                     \
+            if (t == 2) {                                                                                               \
+                /* the step's one barrier, in the MIDDLE of its MFMA work: behind it the tile of step S+1 (issued a   */ \
+                /* step ago; still allowed in flight: the 8 weight loads and 4 DMA pieces issued at the top of this   */ \
+                /* step) is complete for every wave, and every wave has finished reading the slot of step S-1, which  */ \
+                /* the next issue overwrites (four slots: the one being read, the two in flight, the one just freed)  */ \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                                       \
+                __builtin_amdgcn_s_barrier();                                                                           \
+                asm volatile("" ::: "memory");                                                                          \
+            }                                                                                                           \
         }                                                                                                               \
-        _Pragma("unroll") for (int a = 0; a < NFN; ++a) _Pragma("unroll") for (int b = 0; b < NFM; ++b)                   \
-            asm volatile("" : "+v"(acc[a][b]));                                                                         \
-        AVCER_WD_WAIT(4, WHN, WLN);                                                                                     \
-        __builtin_amdgcn_s_barrier();                                                                                   \
-        asm volatile("" ::: "memory");                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        AVCER_WD_WAIT(4, WHN, WLN); /* the weight fragments of step S+1 are in their registers */                       \
     } while (0)
 
     int rslot = 0;  // ring slot the current step reads
+    bf16x8_t a0h, a0l, a1h, a1l;
     AVCER_WD_ISSUE_A(0);
     asm volatile("" ::: "memory");
     AVCER_WD_LOAD_W(wh0, wl0);
@@ -823,10 +834,12 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
     AVCER_WD_WAIT(4, wh0, wl0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    AVCER_WD_READ(smem, 0, a0h, a0l);
     for (int s = 0; s < nk; s += 2) {  // nk is even (checked by the launcher)
         AVCER_WD_STEP(s, wh0, wl0, wh1, wl1);
         AVCER_WD_STEP(s + 1, wh1, wl1, wh0, wl0);
     }
+    asm volatile("" : "+v"(a0h), "+v"(a0l));  // the last step's look-ahead read (a free slot): consumed by nobody
     // the dummy operations of the last steps are still in flight: drain them before the registers are reused
     AVCER_WD_WAIT(0, wh0, wl0);
     AVCER_WD_WAIT(0, wh1, wl1);
