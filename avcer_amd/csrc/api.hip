@@ -180,13 +180,13 @@ int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
 // (128 x 256 tiles, dtype 7 / 8) or the LDS-staged one (128 x 128, dtype 5 / 6).  Results are bit-identical, so this is
 // speed only.  Model, calibrated on tools/ab_layers.py (profiles/r03_ab_layers.txt): a 128 x 256 tile costs 1.84 tiles of
 // 128 x 128 (1.95 where K <= 1024: the tile's prologue and epilogue weigh more), 512 blocks run at a time, a partial last
-// round of fraction f costs min(1, 0.3 + f) of a round, and a grid of at most one block per CU runs at 0.65 of a round.
+// round of fraction f costs min(1, 0.45 + f) of a round, and a grid of at most one block per CU runs at 0.65 of a round.
 bool prefer_weights_direct(long M, int N, long K) {
     auto rounds = [](long tiles) {
         if (tiles <= 256) return 0.65;
         if (tiles <= 512) return 1.0;
         const double r = (double)tiles / 512.0, whole = std::floor(r), f = r - whole;
-        return whole + (f > 0.0 ? std::min(1.0, 0.3 + f) : 0.0);
+        return whole + (f > 0.0 ? std::min(1.0, 0.45 + f) : 0.0);
     };
     const long mt = (M + 127) / 128;
     return rounds(mt * (N / 256)) * (K <= 1024 ? 1.95 : 1.84) < rounds(mt * (N / 128));
