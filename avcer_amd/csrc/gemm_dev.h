@@ -32,7 +32,10 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((c
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-__device__ __forceinline__ float relu_nan(float v) { return v > 0.f ? v : (v != v ? v : 0.f); }  // keeps NaN like torch
+// ReLU that keeps a NaN a NaN like torch (any sign, any payload: the comparison is false for it), in TWO vector instructions
+// (v_cmp_lt + v_cndmask) -- the (v > 0 ? v : (v != v ? v : 0)) form costs four, and the fused bottleneck kernels run this
+// on every element they store.  -0.0 stays -0.0, which no consumer can tell from +0.0.
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
 
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }

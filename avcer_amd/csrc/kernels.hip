@@ -10,7 +10,7 @@ namespace {
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float relu_nan(float v) { return v > 0.f ? v : (v != v ? v : 0.f); }
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }  // keeps NaN like torch; two instructions (gemm_dev.h)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1,6 +1,9 @@
 import sys, os, torch
 sys.path.insert(0, os.getcwd())
 from avcer_amd.engine import Engine
+if len(sys.argv) > 1:  # a one-off experiment build of the library
+    from avcer_amd import _lib  # AVCER_LIB_OVERRIDE (argument, not environment)
+    _lib.LIB = os.path.abspath(sys.argv[1])
 eng = Engine(0)
 dev = eng.device
 def run(planes, nb, hw, nxt, iters=5):

@@ -52,6 +52,38 @@ __global__ void copy_persistent(const u4* __restrict__ src, u4* __restrict__ dst
     }
 }
 
+// The access shape of the fused bottleneck kernels' residual loads and output stores: a wave covers 16 rows of 1024 B, lane
+// l = (row l & 15, 16-byte piece l >> 4) -- four lanes give 64 contiguous bytes of a row, the second access the other half of
+// the 128-byte line.  GROUPS = how many consecutive 128-byte groups of its rows a wave walks (8 = a whole 1024-byte row).
+template <int GROUPS>
+__global__ void copy_fragment(const char* __restrict__ src, char* __restrict__ dst, size_t rows) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t row = wave * 16 + (lane & 15);
+    if (row >= rows) return;
+    const size_t off = row * 1024 + (size_t)(lane >> 4) * 16;
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) {
+        const u4 h = *reinterpret_cast<const u4*>(src + off + g * 128), l = *reinterpret_cast<const u4*>(src + off + g * 128 + 64);
+        *reinterpret_cast<u4*>(dst + off + g * 128) = h;
+        *reinterpret_cast<u4*>(dst + off + g * 128 + 64) = l;
+    }
+}
+// the same bytes with a wave covering 8 rows x 128 B per access (lane l = row l >> 3, piece l & 7): whole lines per row
+template <int GROUPS>
+__global__ void copy_lines(const char* __restrict__ src, char* __restrict__ dst, size_t rows) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const size_t row = wave * 16 + half * 8 + (lane >> 3);
+        if (row >= rows) return;
+        const size_t off = row * 1024 + (size_t)(lane & 7) * 16;
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) *reinterpret_cast<u4*>(dst + off + g * 128) = *reinterpret_cast<const u4*>(src + off + g * 128);
+    }
+}
+
 template <typename F>
 double bench(const char* name, F launch, size_t bytes) {
     hipEvent_t e0, e1;
@@ -108,6 +140,12 @@ int main() {
     PERS(4, false, 512, 1024);
     PERS(4, false, 1024, 512);
     PERS(2, false, 256, 8192);
+    {
+        const size_t rows = bytes / 1024;
+        const unsigned grid = (unsigned)(rows / 16 / 4);  // 4 waves per block, 16 rows per wave
+        bench("fragment shape 16 rows x 64 B, 8 groups", [&] { copy_fragment<8><<<grid, 256>>>(a, b, rows); }, bytes);
+        bench("line shape 8 rows x 128 B, 8 groups", [&] { copy_lines<8><<<grid, 256>>>(a, b, rows); }, bytes);
+    }
     hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0);
     bench("hipMemcpyAsync D2D", [&] { hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0); }, bytes);
     hipFree(a);

@@ -26,7 +26,7 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     p1 = AVPipeline(device=0, seed=42, mode=MODE_BF16X3)
-    p2 = AVPipeline(device=0, seed=42, mode=MODE_BF16X3, audio=False)
+    p2 = AVPipeline(device=0, seed=42, mode=MODE_BF16X3)
     frames = torch.from_numpy(synth.face_frames(1234, a.clips * 16)).reshape(a.clips, 16, 224, 224, 3).to(dev)
     wav = torch.from_numpy(synth.waveforms(5678, a.clips, 32000)).to(dev)
     present = np.ones((a.clips, 16), bool)
@@ -54,9 +54,23 @@ def main():
         main_s.wait_stream(s_v2)
         return torch.cat([st1, st2]), torch.cat([dy1, dy2]), aud
 
+    def audio_halves():
+        main_s = torch.cuda.current_stream(dev)
+        s_aud.wait_stream(main_s)
+        s_v2.wait_stream(main_s)
+        with torch.cuda.stream(s_aud):
+            a1 = p1.engine.audio_forward(wav[:h], normalize=True, mode=MODE_BF16X3)
+        with torch.cuda.stream(s_v2):
+            a2 = p2.engine.audio_forward(wav[h:], normalize=True, mode=MODE_BF16X3)
+        st, dy = visual_forward(p1.engine, frames, present, 25, MODE_BF16X3)
+        main_s.wait_stream(s_aud)
+        main_s.wait_stream(s_v2)
+        return st, dy, torch.cat([a1, a2])
+
     ref = [t.cpu() for t in one_stream()]
     for name, fn in (("1 stream", one_stream), ("2 streams (audio | visual)", two_streams),
-                     ("3 streams (audio | visual half | visual half)", three_streams)) * 2:
+                     ("3 streams (audio | visual half | visual half)", three_streams),
+                     ("3 streams (audio half | audio half | visual)", audio_halves)) * 2:
         out = [t.cpu() for t in fn()]
         same = all(torch.equal(x, y) for x, y in zip(ref, out))
         for _ in range(2):
