@@ -27,6 +27,7 @@ class ConvDesc(C.Structure):
         ("x2_cin", C.c_int32), ("x2_coff", C.c_int32), ("x2_stride", C.c_int32),
         ("x2_stride_b", C.c_int64), ("x2_stride_h", C.c_int64), ("x2_stride_w", C.c_int64),
         ("tile_n", C.c_int32),
+        ("r_sub", C.c_int32), ("r_h", C.c_int32), ("r_w", C.c_int32),
     ]
 
 
@@ -72,7 +73,7 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
     "avcer_face_nms": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float,
                                  C.c_void_p, C.c_void_p, c_stream]),
-    "avcer_bneck_chain": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 +
+    "avcer_bneck_chain": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8 +
                           [c_stream]),
     "avcer_stem_pool": (C.c_int, [c_ctx, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_stream]),
     "avcer_measure_ceilings": (C.c_int, [c_ctx, C.POINTER(C.c_double), C.POINTER(C.c_double), c_stream]),

@@ -90,9 +90,9 @@ int launch_stem_pool(avcer_ctx* ctx, const void* planes, size_t plane_bytes, con
 // conv2 + conv3 (+ residual) of one bottleneck and conv1 of the next block (t1n / w1n null when there is none);
 // ds_cin = 0: x [M][4 planes] is the residual; ds_cin = 64: x [M][64] is the downsample operand and w3 is [4 planes][planes + 64];
 // all activations sp32, weights split-bf16 (row-permuted) with the BN scale folded in (packing.py: *.wf, c3d.w)
-int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, void* out, void* t1n,
-                 const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n, const float* b1n,
-                 hipStream_t st);
+int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, int out_step,
+                 void* out, void* t1n, const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n,
+                 const float* b1n, hipStream_t st);
 
 // conv3 + residual + ReLU of a planes-256 bottleneck and conv1 of the next block in one launch (t2 = conv2 output [M][256])
 int launch_bneck_tail(avcer_ctx* ctx, int planes, long M, const void* t2, const void* x, void* out, void* t1n, const void* w3,

@@ -241,7 +241,8 @@ struct BneckParams {
     const char* W1N;    // [P][4P] split, rows permuted, BN scale folded (next block's conv1)
     const float *b2, *b3, *b1n;  // folded BN shifts, natural channel order
     unsigned t1_bytes;
-    int M, H, Wd;       // M = nb * H * Wd positions
+    int M, H, Wd;       // M = nb * H * Wd positions (SUB > 1: nb * OH * OW, see bneck_kernel)
+    int OH, OW;         // SUB > 1: the output grid, position (oy, ox) <-> input position (SUB oy, SUB ox)
 };
 
 // BM positions per block, 4 waves, each wave owns BM/4 positions and ALL channels (so that a position's whole T2 /
@@ -258,8 +259,16 @@ struct BneckParams {
 // two images are zero rows / slots supplied by the DMA's bounds check).  A tap is then a constant slot offset
 // (dy * (W + 2) + dx) on the fragment reads, and only the weight tile streams per K-step (L2 -> LDS bytes of the phase
 // -37 % at planes 128).  Used at planes 128; see launch_bneck for why not at planes 64.
-template <int P, int BM, bool NEXT, int NQX, bool PATCH>
+//
+// SUB = 2: the LAST block of a stage.  Its output is read by the next stage's conv1 and downsample convolution only, both
+// 1x1 with stride 2 and no padding (video.py:12-19,140-149), i.e. at positions (2 oy, 2 ox): the block is evaluated at
+// those positions alone -- M counts them, OUT is the compact [nb][OH][OW][4P] tensor, T1 and X keep their [nb][H][Wd]
+// grids (the 3x3 taps of an even position touch odd ones; the residual is picked at the even position).  A quarter of the
+// conv2 / conv3 products, of the residual reads and of the output bytes; every value written is the one the full-
+// resolution evaluation would have put at that position.
+template <int P, int BM, bool NEXT, int NQX, bool PATCH, int SUB = 1>
 __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
+    static_assert(SUB == 1 || (SUB == 2 && !NEXT && NQX == 0 && !PATCH), "the strided form is the plain last block of a stage");
     constexpr int NQ = P / 32;            // K-steps of a P-channel contraction
     constexpr int NQT = NQ + NQX;         // K-steps of conv3 (+ downsample)
     constexpr int PSLOTS = PATCH ? (P == 64 ? 456 : 304) : 0;  // patch slots (x 128 B): 10 rows x 30 (28x28); 8 x 57 would serve 55x55
@@ -374,10 +383,21 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
         const int m = m_base + row;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        const int x = mm % p.Wd, y = (mm / p.Wd) % p.H;
+        int x, y;
+        long src = mm;  // T1 row of the centre tap
+        if constexpr (SUB == 1) {
+            x = mm % p.Wd;
+            y = (mm / p.Wd) % p.H;
+        } else {
+            const int ox = mm % p.OW, yb = mm / p.OW;
+            const int oy = yb % p.OH, b = yb / p.OH;
+            x = SUB * ox;
+            y = SUB * oy;
+            src = ((long)b * p.H + y) * p.Wd + x;
+        }
         a_y[j] = ok ? y : -(1 << 28);
         a_x[j] = x;
-        a_off[j] = (unsigned)((long)mm * (P * 4) + ((slot ^ swz_key(row)) << 4));
+        a_off[j] = (unsigned)(src * (P * 4) + ((slot ^ swz_key(row)) << 4));
     }
     {
         int ky = 0, kx = 0, kq = 0;
@@ -451,7 +471,8 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
     issue_group(0);  // the tile buffers are free: phase A ended on a barrier
 
     // residual rows of this lane: position m_t = m_base + wave*BM/4 + 16 t + (lane & 15); 16 bytes hi + 16 bytes lo per group
-    long x_row[NT];  // byte offset of this lane's piece of the block-output row (and of the residual row: same shape)
+    long x_row[NT];  // byte offset of this lane's piece of the residual row (SUB == 1: and of the block-output row, same shape)
+    long o_row[SUB > 1 ? NT : 1];  // SUB > 1: byte offset of the piece of the (compact) output row
     long m_row[NT];  // position (clamped to 0 past M: loads stay in bounds, stores are predicated)
     bool m_ok[NT];
 #pragma unroll
@@ -459,7 +480,15 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
         const long m = (long)m_base + wave * (BM / 4) + t * 16 + l15;
         m_ok[t] = m < p.M;
         m_row[t] = m_ok[t] ? m : 0;
-        x_row[t] = m_row[t] * (4L * P * 4) + 16 * g;
+        if constexpr (SUB == 1) {
+            x_row[t] = m_row[t] * (4L * P * 4) + 16 * g;
+        } else {
+            const int mm = (int)m_row[t];
+            const int ox = mm % p.OW, yb = mm / p.OW;
+            const int oy = yb % p.OH, b = yb / p.OH;
+            x_row[t] = (((long)b * p.H + SUB * oy) * p.Wd + SUB * ox) * (4L * P * 4) + 16 * g;
+            o_row[t] = m_row[t] * (4L * P * 4) + 16 * g;
+        }
     }
     // downsample operand: the NQX K-steps of this lane's positions as B fragments, straight from global memory
     bf16x8_t xh[NQX > 0 ? NQX : 1][NT], xl[NQX > 0 ? NQX : 1][NT];
@@ -554,7 +583,7 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
                                 relu_nan(hi4[2] + b1.z + r[6]), relu_nan(hi4[3] + b1.w + r[7])};
             split8v(v, oh[t], ol[t]);
             if (m_ok[t]) {
-                char* yp = p.OUT + x_row[t] + G * 128;
+                char* yp = p.OUT + (SUB == 1 ? x_row[t] : o_row[SUB > 1 ? t : 0]) + G * 128;
                 *reinterpret_cast<bf16x8_t*>(yp) = oh[t];
                 *reinterpret_cast<bf16x8_t*>(yp + 64) = ol[t];
             }
@@ -810,10 +839,13 @@ int launch_stem_pool(avcer_ctx* ctx, const void* planes, size_t plane_bytes, con
     return AVCER_OK;
 }
 
-int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, void* out, void* t1n,
-                 const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n, const float* b1n,
-                 hipStream_t st) {
-    const long M = (long)nb * h * w;
+int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, int out_step,
+                 void* out, void* t1n, const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n,
+                 const float* b1n, hipStream_t st) {
+    if (out_step != 1 && out_step != 2) return set_err(ctx, AVCER_EINVAL, "bneck: out_step %d (1 or 2)", out_step);
+    if (out_step == 2 && (t1n || ds_cin)) return set_err(ctx, AVCER_EINVAL, "bneck: the strided form is the last block of a stage (no next conv1, no downsample)");
+    const int oh = (h - 1) / out_step + 1, ow = (w - 1) / out_step + 1;
+    const long M = (long)nb * oh * ow, M_in = (long)nb * h * w;
     if (!t1 || !x || !out || !w2 || !w3 || !b2 || !b3 || M <= 0)
         return set_err(ctx, AVCER_EINVAL, "bneck: bad arguments");
     if ((t1n != nullptr) != (w1n != nullptr) || (t1n && !b1n))
@@ -821,13 +853,13 @@ int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t
     if (planes != 64 && planes != 128) return set_err(ctx, AVCER_EINVAL, "bneck: planes %d (64 or 128)", planes);
     if (ds_cin != 0 && !(ds_cin == 64 && planes == 64 && t1n))
         return set_err(ctx, AVCER_EINVAL, "bneck: the downsample form exists for planes 64 with a 64-channel input and a next conv1");
-    if (M * planes * 4L >= (long)OOB) return set_err(ctx, AVCER_EINVAL, "bneck: M=%ld too large for one pass", M);
+    if (M_in * planes * 4L >= (long)OOB) return set_err(ctx, AVCER_EINVAL, "bneck: M=%ld too large for one pass", M_in);
     BneckParams p;
     p.T1 = (const char*)t1; p.X = (const char*)x; p.OUT = (char*)out; p.T1N = (char*)t1n;
     p.W2 = (const char*)w2; p.W3 = (const char*)w3; p.W1N = (const char*)w1n;
     p.b2 = b2; p.b3 = b3; p.b1n = b1n;
-    p.t1_bytes = (unsigned)(M * planes * 4);
-    p.M = (int)M; p.H = h; p.Wd = w;
+    p.t1_bytes = (unsigned)(M_in * planes * 4);
+    p.M = (int)M; p.H = h; p.Wd = w; p.OH = oh; p.OW = ow;
     constexpr int BM = 128;
     const int grid = (int)((M + BM - 1) / BM);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -838,7 +870,10 @@ int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t
     // image) + 2 halo rows, W + 2 slots each, must fit the kernel's LDS image.
     const int rows_worst = (w - 1 + BM + w - 1) / w + 2 + 2;
     const bool patch = planes == 128 && (long)h * w >= BM && rows_worst * (w + 2) <= 304;
-    if (ds_cin) {
+    if (out_step == 2) {
+        if (planes == 64) bneck_kernel<64, BM, false, 0, false, 2><<<dim3(grid), dim3(256), 0, st>>>(p);
+        else bneck_kernel<128, BM, false, 0, false, 2><<<dim3(grid), dim3(256), 0, st>>>(p);
+    } else if (ds_cin) {
         bneck_kernel<64, BM, true, 2, false><<<dim3(grid), dim3(256), 0, st>>>(p);
     } else if (planes == 64) {
         if (t1n) bneck_kernel<64, BM, true, 0, false><<<dim3(grid), dim3(256), 0, st>>>(p);

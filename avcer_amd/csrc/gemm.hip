@@ -66,6 +66,7 @@ struct GemmParams {
     int tap_inner;  // K-steps walk (channel chunk, ky, kx) instead of (ky, kx, channel chunk): see launch_conv_gemm
     const char* WF;  // dtype 7 / 8: the weights in MFMA fragment order (kernels.hip weight_frags_kernel), else null
     int tapH4, tapW4;  // byte steps of one filter tap down / right: dil_h * x_stride_h * 4, dil_w * x_stride_w * 4
+    int rsub, rH, rW;  // residual sub-sampling (avcer_conv_desc.r_sub): output (b, oy, ox) adds residual row (b, oy*rsub, ox*rsub)
 };
 
 // Epilogue, staged through LDS so that HBM sees whole 128-byte lines: every wave first parks its scaled/biased
@@ -80,6 +81,12 @@ struct GemmParams {
 // the DMA / MFMA phase instead of sitting in the epilogue.
 template <int OUT>
 __device__ __forceinline__ void res_load(const GemmParams& p, long m, int n0, uint4& r0, uint4& r1) {
+    if (p.rsub > 1) {  // the residual's own position grid is rsub x finer than the output's
+        const int ohw = p.OH * p.OW;
+        const int b = (int)(m / ohw), rem = (int)m - b * ohw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        m = ((long)b * p.rH + (long)oy * p.rsub) * p.rW + (long)ox * p.rsub;
+    }
     const long e = m * p.ldR + p.roff + n0;
     if constexpr (OUT == 0) {
         const char* rp = p.R + e * 4;
@@ -952,6 +959,10 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
     p.sB = d.x_stride_b; p.sH = d.x_stride_h; p.sW = d.x_stride_w; p.coff = d.x_coff;
     p.ldY = d.y_ld; p.yoff = d.y_coff; p.ldR = d.r_ld; p.roff = d.r_coff;
     p.act = d.act; p.res_after = d.res_after_act;
+    p.rsub = d.r_sub > 1 ? d.r_sub : 1; p.rH = d.r_h; p.rW = d.r_w;
+    if (residual && d.r_sub > 1 && ((long)(d.out_h - 1) * d.r_sub >= d.r_h || (long)(d.out_w - 1) * d.r_sub >= d.r_w))
+        return set_err(ctx, AVCER_EINVAL, "conv_gemm: residual grid %d x %d too small for %d x %d outputs at step %d", d.r_h, d.r_w,
+                       d.out_h, d.out_w, d.r_sub);
     const int groups = d.groups > 1 ? d.groups : 1;
     const long x_extent = ((long)(d.batch - 1) * d.x_stride_b + (long)(d.in_h - 1) * d.x_stride_h +
                            (long)(d.in_w - 1) * d.x_stride_w + d.x_coff + (long)groups * d.cin) * es;

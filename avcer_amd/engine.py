@@ -296,10 +296,12 @@ class Engine:
         self._check(self.lib.avcer_conv_gemm_dual(self.ctx, C.byref(desc), dtype, _ptr(x), _ptr(x2), _ptr(w), _ptr(scale),
                                                   _ptr(bias), _ptr(residual), _ptr(y), self._stream()))
 
-    def bneck_chain(self, planes: int, nb: int, h: int, w: int, t1, x, out, t1n, w2, b2, w3, b3, w1n=None, b1n=None, ds_cin: int = 0):
-        """Kernel-level entry of the fused bottleneck chain (csrc/fused.hip); all tensors already on the device."""
-        self._check(self.lib.avcer_bneck_chain(self.ctx, planes, nb, h, w, _ptr(t1), _ptr(x), int(ds_cin), _ptr(out), _ptr(t1n), _ptr(w2),
-                                               _ptr(b2), _ptr(w3), _ptr(b3), _ptr(w1n), _ptr(b1n), self._stream()))
+    def bneck_chain(self, planes: int, nb: int, h: int, w: int, t1, x, out, t1n, w2, b2, w3, b3, w1n=None, b1n=None, ds_cin: int = 0,
+                    out_step: int = 1):
+        """Kernel-level entry of the fused bottleneck chain (csrc/fused.hip); all tensors already on the device.
+        out_step = 2: the last block of a stage, evaluated at the even positions only (out is the compact grid)."""
+        self._check(self.lib.avcer_bneck_chain(self.ctx, planes, nb, h, w, _ptr(t1), _ptr(x), int(ds_cin), int(out_step), _ptr(out),
+                                               _ptr(t1n), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), _ptr(w1n), _ptr(b1n), self._stream()))
 
     def measure_ceilings(self):
         """(bf16 MFMA TFLOP/s of a register-only MFMA loop, TB/s of a 1 GiB streaming copy) measured on this GPU."""

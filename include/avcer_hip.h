@@ -209,6 +209,10 @@ typedef struct avcer_conv_desc {
     int64_t x2_stride_b, x2_stride_h, x2_stride_w;
     int32_t tile_n;                  /* output-channel width of the block tile: 0 = chosen by the library, 64 or 128 (n % 128 == 0);
                                         dtypes 7 / 8 always use 256 (0 or 256).  A tuning knob: results do not depend on it. */
+    /* Sub-sampled residual (r_sub > 1): the residual tensor lives on a [batch, r_h, r_w] grid of rows of r_ld elements and
+     * output position (b, oy, ox) adds its row (b, oy * r_sub, ox * r_sub) -- the last bottleneck of a ResNet stage computed
+     * only at the positions the next stage's stride-2 1x1 convolutions read.  0 / 1: one residual row per output row. */
+    int32_t r_sub, r_h, r_w;
 } avcer_conv_desc;
 
 int avcer_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, const void* x, const void* w,
@@ -230,14 +234,17 @@ int avcer_conv_gemm_dual(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, co
  *   ds_cin = 64 (planes 64 only, t1n required): the FIRST block of a stage without spatial stride (video.py:43-60 with
  *   i_downsample): x is the 64-channel block input sp32 [nb,h,w,64], w3 is [4*planes][planes + 64] = conv3 and the
  *   downsample convolution concatenated along K (both BN scales folded, shifts summed into b3), and nothing is added.
+ *   out_step = 2 (t1n NULL, ds_cin 0): the LAST block of a stage, whose output only the next stage's stride-2 1x1
+ *   convolutions read (video.py:12-19,140-149): T2 and OUT are evaluated at positions (2 oy, 2 ox) alone and out is the compact
+ *   sp32 [nb, (h+1)/2, (w+1)/2, 4*planes]; t1 and x keep their [nb,h,w] grids.  out_step = 1: every position.
  *
  * avcer_stem_pool: conv 7x7/2 (TF-"same" padding) + BN + ReLU + max-pool 3x3/2 in one launch,
  *   ref: architectures/video.py:63-90,98-103,116-117.  planes_hi_lo: two bf16 planes [n,230,230,4] (hi, then lo plane_bytes
  *   later) of the zero-bordered preprocessed image as avcer_static_forward builds it; w split [64][7*32] (tap rows of
  *   8 pixels x 4 channels); scale / bias f32 [64]; y sp32 [n,55,55,64]. */
-int avcer_bneck_chain(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, void* out, void* t1n,
-                      const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n, const float* b1n,
-                      avcer_stream_t stream);
+int avcer_bneck_chain(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, int out_step,
+                      void* out, void* t1n, const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n,
+                      const float* b1n, avcer_stream_t stream);
 int avcer_stem_pool(avcer_ctx* ctx, const void* planes_hi_lo, size_t plane_bytes, const void* w, const float* scale,
                     const float* bias, void* y, int n, avcer_stream_t stream);
 

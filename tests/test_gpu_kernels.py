@@ -293,6 +293,86 @@ def test_bneck_chain_vs_float64(engine, planes, nb, hw, nxt):
         assert err1 < 2e-5 * max(1.0, t1n.abs().max().item())
 
 
+@pytest.mark.parametrize("planes,nb,hw", [(64, 3, 55), (64, 2, 9), (128, 5, 28), (128, 3, 7)])
+def test_bneck_chain_last_block_even_positions(engine, planes, nb, hw):
+    """out_step = 2, the last block of a stage: only the positions (2 oy, 2 ox) that the next stage's stride-2 1x1
+    convolutions read (video.py:12-19,140-149) are evaluated.  Every value must be BIT-IDENTICAL to what the full-resolution
+    launch puts at that position (same taps, same K order) -- except where the full launch takes the resident-patch form of
+    the conv2 phase (planes 128 on images of >= 128 positions), which walks K as (channel chunk, tap) instead of (tap,
+    channel chunk): there the two agree to one step of the sp32 encoding.  Both are also checked against float64 convolutions."""
+    g = torch.Generator().manual_seed(planes + hw + 1)
+    p4 = 4 * planes
+    t1 = torch.rand(nb, hw, hw, planes, generator=g) * 2
+    x = torch.rand(nb, hw, hw, p4, generator=g) * 2
+    w2 = torch.randn(planes, 9 * planes, generator=g) / (3 * planes ** 0.5)
+    w3 = torch.randn(p4, planes, generator=g) / planes ** 0.5
+    b2, b3 = (torch.randn(n, generator=g) * 0.3 for n in (planes, p4))
+    dev = engine.device
+    oh = (hw + 1) // 2
+    args = (to_sp32(t1).to(dev), to_sp32(x).to(dev))
+    w = (engine.split_weight_rows(w2), b2.to(dev), engine.split_weight_rows(w3), b3.to(dev))
+    full = torch.full((nb, hw, hw, 2 * p4), 0x7fc0, dtype=torch.int16, device=dev)
+    even = torch.full((nb, oh, oh, 2 * p4), 0x7fc0, dtype=torch.int16, device=dev)
+    engine.bneck_chain(planes, nb, hw, hw, *args, full, None, *w)
+    engine.bneck_chain(planes, nb, hw, hw, *args, even, None, *w, out_step=2)
+    torch.cuda.synchronize()
+    got, ref_full = from_sp32(even.cpu()), from_sp32(full.cpu()[:, ::2, ::2])
+    if planes == 128 and hw * hw >= 128:
+        assert (got - ref_full).abs().max() < 2e-5 * ref_full.abs().max()  # one step of the sp32 encoding (2^-16) at most
+    else:
+        assert torch.equal(even.cpu(), full.cpu()[:, ::2, ::2])
+    t2 = F.relu(F.conv2d(t1.permute(0, 3, 1, 2).double(), w2.reshape(planes, 3, 3, planes).permute(0, 3, 1, 2).double(), b2.double(),
+                         padding=1))
+    out = F.relu(F.conv2d(t2, w3.double()[:, :, None, None], b3.double()) + x.permute(0, 3, 1, 2).double())[:, :, ::2, ::2]
+    err = (got.permute(0, 3, 1, 2).double() - out).abs().max().item()
+    print(f"bneck last block planes={planes} {nb}x{hw}x{hw} -> {oh}x{oh}: max|out err| {err:.2e} (max|out| {out.abs().max().item():.1f})")
+    assert err < 2e-5 * max(1.0, out.abs().max().item())
+
+
+def test_bneck_chain_strided_form_refuses_a_next_conv1(engine):
+    from avcer_amd._lib import AvcerError
+
+    dev = engine.device
+    z = torch.zeros(1, 8, 8, 128, dtype=torch.int16, device=dev)
+    o = torch.zeros(1, 4, 4, 512, dtype=torch.int16, device=dev)
+    w = torch.zeros(64 * 576 * 2, dtype=torch.int16, device=dev)
+    b = torch.zeros(256, device=dev)
+    with pytest.raises(AvcerError, match="last block of a stage"):
+        engine.bneck_chain(64, 1, 8, 8, z, o, o, z, w, b, w, b, w, b, out_step=2)
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 5, 7])
+def test_sub_sampled_residual(engine, dtype):
+    """avcer_conv_desc.r_sub = 2: conv3 of a stage's last block evaluated on the compact even grid, the residual row taken
+    from position (2 oy, 2 ox) of the full-resolution block input (video.py:49-58 at the positions video.py:12-19 reads)."""
+    b, h, k, n = 3, 13, 64, 256
+    oh = (h + 1) // 2
+    g = torch.Generator().manual_seed(31 + dtype)
+    t2 = torch.randn(b, oh, oh, k, generator=g)
+    x = torch.randn(b, h, h, n, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    scale, bias = torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g)
+    d = _desc(batch=b, in_h=oh, in_w=oh, out_h=oh, out_w=oh, cin=k, x_stride_b=oh * oh * k, x_stride_h=oh * k, x_stride_w=k,
+              n=n, y_ld=n, r_ld=n, act=1, r_sub=2, r_h=h, r_w=h)
+    dev = engine.device
+    base = {7: 5}.get(dtype, dtype)
+    ak, ok = A_KIND[base], O_KIND[base]
+    td, rd = _enc(t2, ak, dev), _enc(x, ok, dev)
+    wdv = w.to(dev, torch.bfloat16 if ak == "bf16" else torch.float32).contiguous()
+    w_arg = wdv if dtype < 3 else (engine.weight_frags(wdv) if dtype == 7 else engine.split_weight_rows(wdv))
+    yd = _enc(torch.zeros(b, oh, oh, n), ok, dev)
+    engine.conv_gemm(d, dtype, td, w_arg, scale.to(dev), bias.to(dev), rd, yd)
+    torch.cuda.synchronize()
+    ref = F.relu((_dec(td, ak).double() @ wdv.double().cpu().t()) * scale.double() + bias.double() + _dec(rd, ok).double()[:, ::2, ::2])
+    got = _dec(yd, ok).double()
+    assert (got - ref).abs().max() < _tol(base, ref)
+    # too small a residual grid is refused
+    from avcer_amd._lib import AvcerError
+    d.r_h = 2 * oh - 2
+    with pytest.raises(AvcerError, match="residual grid"):
+        engine.conv_gemm(d, dtype, td, w_arg, scale.to(dev), bias.to(dev), rd, yd)
+
+
 def test_split_weight_rows_layout(engine):
     """avcer_split_weight_rows: hi/lo per 32-element K group + the row order of packing.permute_rows_for_mfma."""
     from avcer_amd.packing import permute_rows_for_mfma

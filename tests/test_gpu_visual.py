@@ -16,6 +16,13 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
+def _stage_out(taps, name):
+    """What the library holds as the output of a stage: stages 1-3 only at the positions (2 oy, 2 ox) that the next stage's
+    stride-2 1x1 convolutions read (video.py:12-19,140-149) -- the other positions of the reference's tensor are never used."""
+    t = _nhwc(taps[name])
+    return t if name == "layer4" else t[:, ::2, ::2].contiguous()
+
+
 def test_static_stage_taps_fp32(engine_static, sd_static):
     frames = synth.face_frames(1234, 8)
     taps = {}
@@ -24,8 +31,8 @@ def test_static_stage_taps_fp32(engine_static, sd_static):
         ov.resnet50_forward(sd_static, x, taps)
         p = "layer1.0"
         c1 = torch.relu(ov._bn(torch.nn.functional.conv2d(taps["stem"], sd_static[p + ".conv1.weight"]), sd_static, p + ".batch_norm1"))
-    refs = {"stem": _nhwc(taps["stem"]), "l1b0_c1": _nhwc(c1), "layer1": _nhwc(taps["layer1"]),
-            "layer2": _nhwc(taps["layer2"]), "layer3": _nhwc(taps["layer3"]), "layer4": _nhwc(taps["layer4"]),
+    refs = {"stem": _nhwc(taps["stem"]), "l1b0_c1": _nhwc(c1), "layer1": _stage_out(taps, "layer1"),
+            "layer2": _stage_out(taps, "layer2"), "layer3": _stage_out(taps, "layer3"), "layer4": _stage_out(taps, "layer4"),
             "avgpool": taps["avgpool"]}
     pre = torch.zeros(8, 230, 230, 4)
     pre[:, 2:226, 2:226, :3] = _nhwc(x)
@@ -61,7 +68,7 @@ def test_static_stage_taps_x3(engine_static, sd_static):
         ov.resnet50_forward(sd_static, ov.pth_processing(frames), taps)
     report = []
     for name in ("stem", "layer1", "layer2", "layer3", "layer4"):
-        ref = _nhwc(taps[name])
+        ref = _nhwc(taps[name]) if name == "stem" else _stage_out(taps, name)
         dst = engine_static.debug_tap(name, ref.numel() * 2, dtype=torch.int16)
         engine_static.static_forward(torch.from_numpy(frames), MODE_BF16X3)
         torch.cuda.synchronize()

@@ -46,6 +46,8 @@ def main():
             rel = []
             for t in TAPS:
                 ref = taps[t].permute(0, 2, 3, 1).contiguous()
+                if t in ("layer1", "layer2", "layer3"):
+                    ref = ref[:, ::2, ::2].contiguous()  # the library evaluates a stage's last block where the next stage reads it
                 if mode == MODE_BF16X3:
                     dst = eng.debug_tap(t, ref.numel() * 2, dtype=torch.int16)
                 else:
