@@ -28,6 +28,7 @@ class ConvDesc(C.Structure):
         ("x2_stride_b", C.c_int64), ("x2_stride_h", C.c_int64), ("x2_stride_w", C.c_int64),
         ("tile_n", C.c_int32),
         ("r_sub", C.c_int32), ("r_h", C.c_int32), ("r_w", C.c_int32),
+        ("tile_m", C.c_int32),
     ]
 
 

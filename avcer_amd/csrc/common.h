@@ -90,6 +90,18 @@ int launch_stem_pool(avcer_ctx* ctx, const void* planes, size_t plane_bytes, con
 // conv2 + conv3 (+ residual) of one bottleneck and conv1 of the next block (t1n / w1n null when there is none);
 // ds_cin = 0: x [M][4 planes] is the residual; ds_cin = 64: x [M][64] is the downsample operand and w3 is [4 planes][planes + 64];
 // all activations sp32, weights split-bf16 (row-permuted) with the BN scale folded in (packing.py: *.wf, c3d.w)
+// Rounds a grid of 256-thread blocks takes on the 512 block slots (two per CU), as the form / tile choices model them.
+// Calibrated on tools/ab_layers.py (profiles/r03_ab_layers*.txt, 128- against 112-row tiles of the same layer): a grid of
+// at most one block per CU runs in 0.62 of a round (a block alone on its CU is that much faster); behind whole rounds, a
+// partial round that still fits one block per CU (fraction f <= 0.5) costs 0.25 + 0.7 f -- the whole rounds end ragged and
+// absorb part of it --, a larger one a whole round (some CU runs two blocks from start to end).
+inline double grid_rounds(long tiles) {
+    const long whole = tiles / 512, rest = tiles % 512;
+    if (whole == 0) return tiles <= 256 ? 0.62 : 1.0;
+    const double f = (double)rest / 512.0;
+    return (double)whole + (rest == 0 ? 0.0 : (rest <= 256 ? 0.25 + 0.7 * f : 1.0));
+}
+
 int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, int out_step,
                  void* out, void* t1n, const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n,
                  const float* b1n, hipStream_t st);

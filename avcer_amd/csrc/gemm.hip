@@ -63,6 +63,7 @@ struct GemmParams {
     int KH;
     int fast;  // pad-free gather with a scalar K / tap advance (see AVCER_ISSUE_TILES)
     int tile_n;  // 0 = choose, 64, 128
+    int tile_m;  // dtype 7 / 8: 0 = choose, 112, 128
     int tap_inner;  // K-steps walk (channel chunk, ky, kx) instead of (ky, kx, channel chunk): see launch_conv_gemm
     const char* WF;  // dtype 7 / 8: the weights in MFMA fragment order (kernels.hip weight_frags_kernel), else null
     int tapH4, tapW4;  // byte steps of one filter tap down / right: dil_h * x_stride_h * 4, dil_w * x_stride_w * 4
@@ -621,12 +622,12 @@ __device__ __forceinline__ void wd_epilogue(const GemmParams& p, f32x4_t (&acc)[
                 rr[f][0] = make_uint4(0u, 0u, 0u, 0u);
                 rr[f][1] = make_uint4(0u, 0u, 0u, 0u);
                 const long m = (long)m_base + (h + f) * 16 + (lane & 15);
-                if (p.R && m < p.M) res_load<OUT>(p, m, ch, rr[f][0], rr[f][1]);
+                if (h + f < NFM && p.R && m < p.M) res_load<OUT>(p, m, ch, rr[f][0], rr[f][1]);
             }
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 const long m = (long)m_base + (h + f) * 16 + (lane & 15);
-                if (m >= p.M) continue;
+                if (h + f >= NFM || m >= p.M) continue;
                 finish8<OUT, ACT>(p, m, ch, scale_bias4(acc[2 * j][h + f], s0, b0), scale_bias4(acc[2 * j + 1][h + f], s1, b1), rr[f][0],
                                   rr[f][1]);
             }
@@ -634,10 +635,13 @@ __device__ __forceinline__ void wd_epilogue(const GemmParams& p, f32x4_t (&acc)[
     }
 }
 
-template <int OUT, int GATHER>
+template <int OUT, int GATHER, int NFM>
 __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the asm statements below only parse for the device target
-    constexpr int BMT = 128, BN = 256, NFM = 8, NFN = 4, STAGES = 4, ABYTES = BMT * ROWB;
+    // NFM = 8: 128 positions per tile.  NFM = 7: 112 -- the ring slots keep 128 rows, the DMA pieces of rows 112..127 are
+    // out-of-range (zeros, no fetch) and the eighth fragment row is never read.  Which of the two leaves the smaller last
+    // round on the 512 block slots is the launcher's choice (launch_wd); an element's K order does not depend on it.
+    constexpr int BMT = 16 * NFM, BN = 256, NFN = 4, STAGES = 4, ABYTES = 128 * ROWB;
     __shared__ __attribute__((aligned(16))) char smem[STAGES * ABYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -680,7 +684,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
     for (int j = 0; j < 4; ++j) {
         const int lrow = wave * 32 + j * 8 + lrow8;
         const int m = m_base + lrow;
-        const bool ok = m < p.M;
+        const bool ok = m < p.M && lrow < BMT;
         const int mm = ok ? m : 0;
         const int ox = mm % p.OW;
         const int t = mm / p.OW;
@@ -792,7 +796,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
         c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, AL, c_, 0, 0, 0);                                             \
         c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, AH, c_, 0, 0, 0);                                             \
     }
-#define AVCER_WD_STEP(S, WH, WL, WHN, WLN)                                                                              \
+#define AVCER_WD_STEP(S, PH, WH, WL, WHN, WLN)                                                                          \
     do {                                                                                                                \
         AVCER_WD_LOAD_W(WHN, WLN);                                                                                      \
         asm volatile("" ::: "memory");                                                                                  \
@@ -803,19 +807,17 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
         const char* sa_next = smem + rslot * ABYTES;                                                                    \
         /* one 16-position tile at a time: the two fragment reads of tile t+1 are issued in front of the 12 MFMAs of */ \
         /* tile t (two register pairs, ping-pong), and the last tile's partner is tile 0 of the NEXT step: the loop   */ \
-        /* has no seam.  The scheduling fences pin that order: left alone, hipcc either hoists all sixteen reads (no  */ \
-        /* registers left for them) or sinks each pair behind the MFMAs it should cover.                              */ \
-        _Pragma("unroll") for (int t = 0; t < NFM; t += 2) {                                                             \
+        /* has no seam (PH = which pair holds tile 0 of this step; with an odd tile count it alternates by step).     */ \
+        /* The scheduling fences pin that order: left alone, hipcc either hoists all sixteen reads (no registers left */ \
+        /* for them) or sinks each pair behind the MFMAs it should cover.                                             */ \
+        _Pragma("unroll") for (int t = 0; t < NFM; ++t) {                                                                \
+            const int cur_ = ((PH) + t) & 1, nxt_ = cur_ ^ 1;                                                           \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
-            AVCER_WD_READ(sa, t + 1, a1h, a1l);                                                                         \
+            if (t + 1 < NFM) AVCER_WD_READ(sa, t + 1, ah[nxt_], al[nxt_]);                                              \
+            else AVCER_WD_READ(sa_next, 0, ah[nxt_], al[nxt_]);                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
-            AVCER_WD_MFMA(t, a0h, a0l, WH, WL);                                                                         \
-            __builtin_amdgcn_sched_barrier(0);                                                                          \
-            if (t + 2 < NFM) AVCER_WD_READ(sa, t + 2, a0h, a0l);                                                        \
-            else AVCER_WD_READ(sa_next, 0, a0h, a0l);                                                                   \
-            __builtin_amdgcn_sched_barrier(0);                                                                          \
-            AVCER_WD_MFMA(t + 1, a1h, a1l, WH, WL);                                                                     \
-            if (t == 2) {                                                                                               \
+            AVCER_WD_MFMA(t, ah[cur_], al[cur_], WH, WL);                                                               \
+            if (t == 3) {                                                                                               \
                 /* the step's one barrier, in the MIDDLE of its MFMA work: behind it the tile of step S+1 (issued a   */ \
                 /* step ago; still allowed in flight: the 8 weight loads and 4 DMA pieces issued at the top of this   */ \
                 /* step) is complete for every wave, and every wave has finished reading the slot of step S-1, which  */ \
@@ -831,7 +833,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
     } while (0)
 
     int rslot = 0;  // ring slot the current step reads
-    bf16x8_t a0h, a0l, a1h, a1l;
+    bf16x8_t ah[2], al[2];
     AVCER_WD_ISSUE_A(0);
     asm volatile("" ::: "memory");
     AVCER_WD_LOAD_W(wh0, wl0);
@@ -841,12 +843,12 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
     AVCER_WD_WAIT(4, wh0, wl0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    AVCER_WD_READ(smem, 0, a0h, a0l);
-    for (int s = 0; s < nk; s += 2) {  // nk is even (checked by the launcher)
-        AVCER_WD_STEP(s, wh0, wl0, wh1, wl1);
-        AVCER_WD_STEP(s + 1, wh1, wl1, wh0, wl0);
+    AVCER_WD_READ(smem, 0, ah[0], al[0]);
+    for (int s = 0; s < nk; s += 2) {  // nk is even (checked by the launcher): after two steps tile 0 is back in pair 0
+        AVCER_WD_STEP(s, 0, wh0, wl0, wh1, wl1);
+        AVCER_WD_STEP(s + 1, NFM & 1, wh1, wl1, wh0, wl0);
     }
-    asm volatile("" : "+v"(a0h), "+v"(a0l));  // the last step's look-ahead read (a free slot): consumed by nobody
+    asm volatile("" : "+v"(ah[0]), "+v"(al[0]));  // the last step's look-ahead read (a free slot): consumed by nobody
     // the dummy operations of the last steps are still in flight: drain them before the registers are reused
     AVCER_WD_WAIT(0, wh0, wl0);
     AVCER_WD_WAIT(0, wh1, wl1);
@@ -863,17 +865,27 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
 #endif
 }
 
-template <int OUT>
-void launch_wd(const GemmParams& p0, hipStream_t st) {
-    GemmParams p = p0;
-    p.ntm = (p.M + 127) / 128;
+template <int OUT, int NFM>
+void launch_wd_t(GemmParams& p, hipStream_t st) {
+    p.ntm = (p.M + 16 * NFM - 1) / (16 * NFM);
     p.gm = 8;
     p.ntn = p.N / 256;
     p.nwg = p.ntm * p.ntn;
-    if (p.X2) conv_gemm_wd_kernel<OUT, 1><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
-    else if (p.fast && p.KH * p.KW == 1) conv_gemm_wd_kernel<OUT, 0><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
-    else if (p.fast) conv_gemm_wd_kernel<OUT, 2><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
-    else conv_gemm_wd_kernel<OUT, 3><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
+    if (p.X2) conv_gemm_wd_kernel<OUT, 1, NFM><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
+    else if (p.fast && p.KH * p.KW == 1) conv_gemm_wd_kernel<OUT, 0, NFM><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
+    else if (p.fast) conv_gemm_wd_kernel<OUT, 2, NFM><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
+    else conv_gemm_wd_kernel<OUT, 3, NFM><<<dim3(p.nwg), dim3(256), 0, st>>>(p);
+}
+
+// 128 or 112 positions per tile: whichever grid costs fewer (rounds x rows per tile); avcer_conv_desc.tile_m overrides.
+template <int OUT>
+void launch_wd(const GemmParams& p0, hipStream_t st) {
+    GemmParams p = p0;
+    const long ntn = p.N / 256;
+    const double c128 = grid_rounds((p.M + 127L) / 128 * ntn) * 128, c112 = grid_rounds((p.M + 111L) / 112 * ntn) * 112;
+    const bool m112 = p.tile_m == 112 || (p.tile_m == 0 && c112 < 0.97 * c128);
+    if (m112) launch_wd_t<OUT, 7>(p, st);
+    else launch_wd_t<OUT, 8>(p, st);
 }
 
 // Tile width by shape.  K <= 128: bandwidth-bound 1x1 convolutions, the 48 KiB BN = 64 tile lets three blocks share a CU.
@@ -983,6 +995,9 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
     if (d.tile_n != 0 && d.tile_n != 64 && d.tile_n != 128 && d.tile_n != 256)
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: tile_n %d (0, 64, 128 or 256)", d.tile_n);
     p.tile_n = d.tile_n;
+    if (d.tile_m != 0 && d.tile_m != 112 && d.tile_m != 128)
+        return set_err(ctx, AVCER_EINVAL, "conv_gemm: tile_m %d (0, 112 or 128)", d.tile_m);
+    p.tile_m = d.tile_m;
     p.WF = wdirect ? (const char*)w : nullptr;
     if (wdirect && (d.n % 256 || (K / bk) % 2 || groups != 1 || d.tile_n == 64 || d.tile_n == 128))
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d needs N %% 256 == 0, an even number of K-steps, one group (N=%d, K=%ld)",

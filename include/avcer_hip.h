@@ -213,6 +213,9 @@ typedef struct avcer_conv_desc {
      * output position (b, oy, ox) adds its row (b, oy * r_sub, ox * r_sub) -- the last bottleneck of a ResNet stage computed
      * only at the positions the next stage's stride-2 1x1 convolutions read.  0 / 1: one residual row per output row. */
     int32_t r_sub, r_h, r_w;
+    int32_t tile_m;                  /* dtypes 7 / 8: positions per block tile, 0 = chosen by the library (whichever of 112 / 128
+                                        leaves the cheaper last round on the 512 block slots), 112 or 128.  A tuning knob like
+                                        tile_n: an element's accumulation order, hence the result, does not depend on it. */
 } avcer_conv_desc;
 
 int avcer_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, const void* x, const void* w,

@@ -12,8 +12,9 @@ from test_gpu_kernels import _desc, from_sp32, to_sp32
 pytestmark = pytest.mark.gpu
 
 
-def _both(engine, d, x, w, scale, bias, res, out_sp32, x2=None):
+def _both(engine, d, x, w, scale, bias, res, out_sp32, x2=None, tile_m=0):
     """Run dtype 5 / 6 and 7 / 8 on the same device tensors; returns the two raw output tensors."""
+    d.tile_m = tile_m
     dev = engine.device
     xd = to_sp32(x).to(dev)
     x2d = None if x2 is None else to_sp32(x2).to(dev)
@@ -37,13 +38,14 @@ def _both(engine, d, x, w, scale, bias, res, out_sp32, x2=None):
 
 @pytest.mark.parametrize("m,k,n,act,out_sp32", [(300, 128, 256, 1, True), (129, 64, 512, 2, False), (1, 256, 256, 0, True),
                                                 (5000, 1024, 768, 0, False), (40000, 64, 256, 1, True)])
-def test_linear_bit_identical(engine, m, k, n, act, out_sp32):
+@pytest.mark.parametrize("tile_m", [0, 112, 128])
+def test_linear_bit_identical(engine, m, k, n, act, out_sp32, tile_m):
     g = torch.Generator().manual_seed(m + k + n)
     x, w = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5
     scale, bias = torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g)
     res = torch.randn(m, n, generator=g)
     d = _desc(batch=m, cin=k, x_stride_b=k, x_stride_h=k, x_stride_w=k, n=n, y_ld=n, r_ld=n, act=act, res_after_act=act == 2)
-    a, b = _both(engine, d, x, w, scale, bias, res, out_sp32)
+    a, b = _both(engine, d, x, w, scale, bias, res, out_sp32, tile_m=tile_m)
     assert torch.equal(a, b)
     got = from_sp32(b) if out_sp32 else b
     assert torch.isfinite(got).all() and got.abs().max() > 0.1
@@ -61,9 +63,10 @@ CONVS = [
 ]
 
 
+@pytest.mark.parametrize("tile_m", [112, 128])
 @pytest.mark.parametrize("out_sp32", [True, False])
 @pytest.mark.parametrize("cfg", CONVS)
-def test_conv_bit_identical(engine, cfg, out_sp32):
+def test_conv_bit_identical(engine, cfg, out_sp32, tile_m):
     b, h, w_, c, kh, kw, s, p, dil, n, act = cfg
     g = torch.Generator().manual_seed(sum(cfg))
     x = torch.randn(b, h, w_, c, generator=g)
@@ -75,11 +78,12 @@ def test_conv_bit_identical(engine, cfg, out_sp32):
     res = torch.randn(b * oh * ow, n, generator=g)
     d = _desc(batch=b, in_h=h, in_w=w_, out_h=oh, out_w=ow, cin=c, kh=kh, kw=kw, stride_h=s, stride_w=sw, pad_h=p, pad_w=pw,
               dil_h=dil, dil_w=dw, x_stride_b=h * w_ * c, x_stride_h=w_ * c, x_stride_w=c, n=n, y_ld=n, r_ld=n, act=act)
-    a, bb = _both(engine, d, x.reshape(-1, c), w, scale, bias, res, out_sp32)
+    a, bb = _both(engine, d, x.reshape(-1, c), w, scale, bias, res, out_sp32, tile_m=tile_m)
     assert torch.equal(a, bb)
 
 
-def test_dual_source_bit_identical(engine):
+@pytest.mark.parametrize("tile_m", [112, 128])
+def test_dual_source_bit_identical(engine, tile_m):
     """conv3 + downsample of a stage's first block in one contraction: K = [T2 (planes) | X at stride 2 (cin)]."""
     b, oh, planes, cin, n = 3, 14, 256, 512, 1024
     g = torch.Generator().manual_seed(7)
@@ -90,7 +94,7 @@ def test_dual_source_bit_identical(engine):
     d = _desc(batch=b, in_h=oh, in_w=oh, out_h=oh, out_w=oh, cin=planes, x_stride_b=oh * oh * planes, x_stride_h=oh * planes,
               x_stride_w=planes, n=n, y_ld=n, r_ld=n, act=1, x2_cin=cin, x2_stride=2, x2_stride_b=4 * oh * oh * cin,
               x2_stride_h=2 * oh * cin, x2_stride_w=cin)
-    a, bb = _both(engine, d, t2.reshape(-1, planes), w, None, bias, None, True, x2=xin.reshape(-1, cin))
+    a, bb = _both(engine, d, t2.reshape(-1, planes), w, None, bias, None, True, x2=xin.reshape(-1, cin), tile_m=tile_m)
     assert torch.equal(a, bb)
 
 
@@ -106,4 +110,7 @@ def test_shapes_outside_the_form_are_refused(engine):
         engine.conv_gemm(d, 8, x, w, None, None, None, y)
     d = _desc(batch=64, cin=64, x_stride_b=64, x_stride_h=64, x_stride_w=64, n=128, y_ld=128, r_ld=128)   # N = 128
     with pytest.raises(AvcerError, match="N % 256"):
+        engine.conv_gemm(d, 8, x, w, None, None, None, y)
+    d = _desc(batch=64, cin=64, x_stride_b=64, x_stride_h=64, x_stride_w=64, n=256, y_ld=256, r_ld=256, tile_m=96)
+    with pytest.raises(AvcerError, match="tile_m"):
         engine.conv_gemm(d, 8, x, w, None, None, None, y)

@@ -3,7 +3,8 @@
 (rule: never compare timings taken in different processes or on different boxes):
 
     staged   avcer_conv_gemm dtype 5 / 6  (A and W tiles through LDS, conv_gemm_kernel<3, *, *>)
-    direct   avcer_conv_gemm dtype 7 / 8  (W fragments straight to registers, conv_gemm_wd_kernel, 128 x 256 tiles)
+    direct   avcer_conv_gemm dtype 7 / 8  (W fragments straight to registers, conv_gemm_wd_kernel, 128 x 256 tiles and
+             112 x 256 tiles: avcer_conv_desc.tile_m)
 
 Inputs are real sp32 encodings of random activations (post-ReLU-like), not reinterpreted f32 bits.  Every arm gets the same
 warm-up; each round times `iters` back-to-back launches per arm; the median over rounds is printed.
@@ -41,7 +42,7 @@ def main():
     dev = eng.device
     layers = [L for L in static_layers(a.frames) + audio_layers(a.chunks, 32000) if a.only in L["name"]]
     tot = {"staged": 0.0, "best": 0.0}
-    print(f"{'layer':38s} {'x':>3s} {'staged us':>10s} {'direct256':>10s} {'best/staged':>11s}")
+    print(f"{'layer':38s} {'x':>3s} {'staged us':>10s} {'direct128':>10s} {'direct112':>10s} {'library':>10s} {'best/staged':>11s}")
     for L in layers:
         d = L["d"]
         m, k, n = d.batch * d.out_h * d.out_w, d.kh * d.kw * d.cin, d.n
@@ -64,10 +65,10 @@ def main():
         if a.f32out:
             y = torch.empty(ylen, device=dev)
             res = torch.randn(ylen, device=dev) if L["res"] else None
-        arms = [("staged", ds, rows, 0), ("direct256", dd, frags, 0)]
+        arms = [("staged", ds, rows, 0), ("direct128", dd, frags, 128), ("direct112", dd, frags, 112), ("library", dd, frags, 0)]
 
-        def launch(dt, wt, tn, cnt):
-            d.tile_n = tn
+        def launch(dt, wt, tm, cnt):
+            d.tile_m = tm
             for _ in range(cnt):
                 eng.conv_gemm(d, dt, x, wt, sc, bi, res, y)
 
@@ -87,8 +88,9 @@ def main():
         best = min(med.values())
         tot["staged"] += med["staged"] * L["count"]
         tot["best"] += best * L["count"]
-        print(f"{L['name']:38s} {L['count']:3d} {med['staged']:10.1f} {med['direct256']:10.1f} {best / med['staged']:11.3f}")
-        d.tile_n = 0
+        print(f"{L['name']:38s} {L['count']:3d} {med['staged']:10.1f} {med['direct128']:10.1f} {med['direct112']:10.1f} "
+              f"{med['library']:10.1f} {best / med['staged']:11.3f}")
+        d.tile_m = 0
         del x, w, rows, frags, y, res
     print(f"sum over the layers above (x count): staged {tot['staged'] / 1e3:.2f} ms, best arm per layer {tot['best'] / 1e3:.2f} ms")
 
