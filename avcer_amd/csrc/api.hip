@@ -889,6 +889,9 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
 
     Net net{ctx, ctx->aud, bf, st, mode == AVCER_MODE_BF16X3};
     // LN whose output is an MFMA operand: f32 in the f32 mode, else a bf16 / sp32 tensor
+    // GELU: the library erff in the f32 mode; the short Abramowitz-Stegun erf (gemm_dev.h gelu_fast, same 5e-7 bound as
+    // the exact form's own f32 rounding) where the contractions around it are bf16 or split-bf16
+    const int gelu = act ? 3 : 2;
     auto ln_act = [&](const void* x, int x_kind, const std::string& p, void* y, long r, int c, int fn) {
         net.chk(k_layernorm(ctx, x, nullptr, net.F(p + ".g"), net.F(p + ".b"), act ? nullptr : y, act ? y : nullptr, r, c,
                             1e-5f, fn, x_kind, act, st));
@@ -912,7 +915,7 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
             const std::string p = "fe" + std::to_string(i);
             net.gemm(conv1d_desc(nb, len[i], C, ck[i], cs[i], 0, 1, len[i + 1], C, 0), p + ".w", nullptr, net.F(p + ".cb"),
                      cur, nullptr, TMP, act, plain);
-            ln_act(TMP, plain, p + ".ln", nxt, (long)nb * len[i + 1], C, 2);
+            ln_act(TMP, plain, p + ".ln", nxt, (long)nb * len[i + 1], C, gelu);
             std::swap(cur, nxt);
             if (i == 1) nxt = EA;  // EA (largest) is free once layer 1 has consumed it
         }
@@ -931,7 +934,7 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
             pin = Xb;
         }
         {  // 16 groups of 64 channels in ONE launch (grid.y = group)
-            avcer_conv_desc d = conv1d_desc(nb, S, 64, 128, 1, 64, 1, S, 64, 2);
+            avcer_conv_desc d = conv1d_desc(nb, S, 64, 128, 1, 64, 1, S, 64, gelu);
             d.x_stride_b = (int64_t)S * E; d.x_stride_h = E; d.x_stride_w = E;
             d.y_ld = E; d.r_ld = E;
             d.res_after_act = 1;
@@ -948,7 +951,7 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
             net.chk(k_attention(ctx, QKV, ATT, nb, S, 16, 64, 0.125f, plain, act, st));
             net.gemm(linear_desc(r, E, E, 0), p + ".o.w", nullptr, net.F(p + ".o.b"), ATT, h, h, act, 0);
             ln_act(h, 0, p + ".ln2", TMP, r, E, 0);
-            net.gemm(linear_desc(r, E, FF, 2), p + ".ff1.w", nullptr, net.F(p + ".ff1.b"), TMP, nullptr, FFB, act, act);
+            net.gemm(linear_desc(r, E, FF, gelu), p + ".ff1.w", nullptr, net.F(p + ".ff1.b"), TMP, nullptr, FFB, act, act);
             net.gemm(linear_desc(r, FF, E, 0), p + ".ff2.w", nullptr, net.F(p + ".ff2.b"), FFB, h, h, act, 0);
             net.tap(("layer" + std::to_string(l)).c_str(), h, (size_t)r * E * 4);
         }

@@ -130,6 +130,7 @@ __device__ __forceinline__ void finish8(const GemmParams& p, long m, int n0, con
         float x = p.res_after ? v[j] : v[j] + r[j];
         if constexpr (ACT == 1) x = relu_nan(x);
         if constexpr (ACT == 2) x = gelu_erf(x);
+        if constexpr (ACT == 3) x = gelu_fast(x);
         v[j] = p.res_after ? x + r[j] : x;
     }
     const long e = m * p.ldY + p.yoff + n0;
@@ -569,14 +570,16 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
 #undef AVCER_DMA_SETUP
 
     if constexpr (DIRECT) {
-        if (p.act == 2) epilogue_direct<OUT, 2, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir);
+        if (p.act == 3) epilogue_direct<OUT, 3, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir);
+        else if (p.act == 2) epilogue_direct<OUT, 2, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir);
         else if (p.act == 1) epilogue_direct<OUT, 1, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir);
         else epilogue_direct<OUT, 0, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir);
     } else {
         // epilogue through LDS (the tile buffers are free: the loop ended on a barrier)
         stage_acc<MODE, BN>(p, smem, acc, n_base, wm * WM, wn, lane);
         __syncthreads();
-        if (p.act == 2) drain_stage<OUT, BMT, BN, 2>(p, smem, m_base, n_base, tid, rres);
+        if (p.act == 3) drain_stage<OUT, BMT, BN, 3>(p, smem, m_base, n_base, tid, rres);
+        else if (p.act == 2) drain_stage<OUT, BMT, BN, 2>(p, smem, m_base, n_base, tid, rres);
         else if (p.act == 1) drain_stage<OUT, BMT, BN, 1>(p, smem, m_base, n_base, tid, rres);
         else drain_stage<OUT, BMT, BN, 0>(p, smem, m_base, n_base, tid, rres);
     }
@@ -859,7 +862,8 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
 #undef AVCER_WD_ISSUE_A
 #undef AVCER_WD_LOAD_W
     const int c0 = n_base + wave * (BN / 4);
-    if (p.act == 2) wd_epilogue<OUT, 2, NFN, NFM>(p, acc, m_base, c0, lane);
+    if (p.act == 3) wd_epilogue<OUT, 3, NFN, NFM>(p, acc, m_base, c0, lane);
+    else if (p.act == 2) wd_epilogue<OUT, 2, NFN, NFM>(p, acc, m_base, c0, lane);
     else if (p.act == 1) wd_epilogue<OUT, 1, NFN, NFM>(p, acc, m_base, c0, lane);
     else wd_epilogue<OUT, 0, NFN, NFM>(p, acc, m_base, c0, lane);
 #endif
@@ -955,6 +959,7 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
     if (a_split && (d.cin % 32 || d.x_coff % 32 || d.x_stride_b % 32 || d.x_stride_h % 32 || d.x_stride_w % 32))
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: sp32 activations need cin/coff/strides in whole groups of 32");
     if (!x || !w || !y) return set_err(ctx, AVCER_EINVAL, "conv_gemm: null pointer");
+    if (d.act < 0 || d.act > 3) return set_err(ctx, AVCER_EINVAL, "conv_gemm: act %d (0 none, 1 relu, 2 gelu, 3 gelu with the short erf)", d.act);
     GemmParams p;
     p.X = (const char*)x; p.W = (const char*)w; p.scale = scale; p.bias = bias; p.R = (const char*)residual;
     p.Y = (char*)y;

@@ -32,6 +32,24 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((c
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// The same function with erf from Abramowitz & Stegun 7.1.26 (1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p |z|)):
+// 14 vector instructions, no branch, against ~45 for the library erff (two divergent branches, a two-step exp).  Against
+// float64, |gelu_fast - gelu| <= 4.7e-7 over [-8, 8] -- the same bound the exact form has from rounding its own f32 result
+// (4.5e-7) --, with up to 5e-7 absolute on erf itself near 0.  Used where the arithmetic around it is the split-bf16 or
+// bf16 one (4.5e-6 relative per contraction); the f32 mode keeps erff.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = x * 0.70710678118654752440f, a = __builtin_fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, a, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * a * a);
+    const float erfz = __builtin_copysignf(__builtin_fmaf(-p, e, 1.0f), z);
+    return 0.5f * x * (1.0f + erfz);
+}
+
 // ReLU that keeps a NaN a NaN like torch (any sign, any payload: the comparison is false for it), in TWO vector instructions
 // (v_cmp_lt + v_cndmask) -- the (v > 0 ? v : (v != v ? v : 0)) form costs four, and the fused bottleneck kernels run this
 // on every element they store.  -0.0 stays -0.0, which no consumer can tell from +0.0.

@@ -4,12 +4,26 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf from Abramowitz & Stegun 7.1.26: see gemm_dev.h gelu_fast (same code; |gelu_fast - gelu| <= 4.7e-7 on [-8, 8])
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = x * 0.70710678118654752440f, a = __builtin_fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, a, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * a * a);
+    const float erfz = __builtin_copysignf(__builtin_fmaf(-p, e, 1.0f), z);
+    return 0.5f * x * (1.0f + erfz);
+}
 __device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }  // keeps NaN like torch; two instructions (gemm_dev.h)
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -669,7 +683,11 @@ __global__ void __launch_bounds__(256) conv0_ln_gelu_kernel(const float* __restr
         for (int j = 0; j < 8; ++j) { const float d = v[j] - mean; q += d * d; }
         const float rstd = rsqrtf(wave_sum(q) * (1.f / 512.f) + 1e-5f);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gelu_erf((v[j] - mean) * rstd * gr[j] + ber[j]);
+        for (int j = 0; j < 8; ++j) {
+            const float u = (v[j] - mean) * rstd * gr[j] + ber[j];
+            if constexpr (std::is_same<T, float>::value) v[j] = gelu_erf(u);  // f32 mode: the library erff
+            else v[j] = gelu_fast(u);
+        }
         const long o = ((long)row * t_out + t) * 512 + c0;
         st4<T>(y, o, v);
         st4<T>(y, o + 4, v + 4);
@@ -718,6 +736,9 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const TI* __restrict__ x
     if (act == 2) {
 #pragma unroll
         for (int i = 0; i < PER; ++i) v[i] = gelu_erf(v[i]);
+    } else if (act == 3) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) v[i] = gelu_fast(v[i]);
     }
 #pragma unroll
     for (int i = 0; i < PER; i += 4) {

@@ -198,7 +198,9 @@ typedef struct avcer_conv_desc {
     int32_t n;                       /* output channels (multiple of 64) */
     int64_t y_ld; int32_t y_coff;    /* output row stride (elements) and channel offset */
     int64_t r_ld; int32_t r_coff;    /* residual row stride / offset (if residual != NULL) */
-    int32_t act;                     /* 0 none, 1 relu, 2 gelu(erf) */
+    int32_t act;                     /* 0 none, 1 relu, 2 gelu(erf), 3 gelu with the Abramowitz-Stegun 7.1.26 erf: within 4.7e-7 of
+                                        the exact function (the f32 rounding of the exact form itself), a third of the
+                                        instructions; what the library uses around bf16 / split-bf16 contractions */
     int32_t res_after_act;           /* 0: act(v + r), 1: act(v) + r */
     int32_t groups;                  /* 0/1 = plain; G > 1 = grouped convolution in ONE launch: group g reads input
                                         channels x_coff + g*cin, uses weight rows [g*n, (g+1)*n) of w (and scale/bias
