@@ -51,7 +51,7 @@ enum {
  *   AVCER_MODE_FP32    |dlogit| <= 1.6e-5, |dprob| <= 1.6e-5 up to 8 x sharper heads than the synthetic generator's;
  *   AVCER_MODE_BF16X3  static CNN |dlogit| <= 7.5e-5 absolute, whatever the head (each contraction carries 4.5e-6 relative
  *                      error; the 7x7 average pool and the f32 fc1 / fc2 keep 4.6e-6 of the trunk's 1.3e-5), so
- *                      |dprob| <= 1.7e-5 / 4.2e-5 / 6.6e-5 at 1 x / 4 x / 8 x the generator's logit scale: inside the 1e-4
+ *                      |dprob| <= 1.5e-5 / 5.3e-5 / 8.4e-5 at 1 x / 4 x / 8 x the generator's logit scale: inside the 1e-4
  *                      gate for every head tried.  A checkpoint whose logits are sharper still (|logit| differences of
  *                      several tens) should be run in AVCER_MODE_FP32, the default of the host mirrors. */
 

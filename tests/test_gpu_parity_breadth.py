@@ -10,7 +10,8 @@ owner of that error was found with tools/x3_error_probe.py / tools/x3_stage_erro
 4.5e-6 relative (split rounding 3.5e-6 + the dropped lo x lo product 2.8e-6; MFMA accumulation 0.1-0.7e-6, unbiased),
 the 7 x 7 average pool removes its position-independent two thirds (1.3e-5 at layer4 -> 4.6e-6 pooled), and a split-bf16
 fc1 then put 40 % back on top.  fc1 now runs on the exact f32 MFMA in the x3 mode as well (free: 32 tiles, 50 us either
-way): worst x3 |dprob| 1.7e-5 / 4.2e-5 at scale 1 / 4 (was 2.5e-5 / 8.9e-5..1.0e-4)."""
+way): worst x3 |dprob| 1.5e-5 / 5.3e-5 / 8.4e-5 at scale 1 / 4 / 8 (was 2.5e-5 / 8.9e-5..1.0e-4 at 1 / 4; the figures move by
++-25 % with any change of a K order upstream -- another draw of the same rounding noise)."""
 import numpy as np
 import pytest
 import torch
