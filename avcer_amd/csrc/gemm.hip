@@ -899,6 +899,8 @@ template <int MODE, int OUT>
 void launch_t(const GemmParams& p0, hipStream_t st) {
     GemmParams p = p0;
     bool bn128 = p.N % 128 == 0 && choose_bn128(p);
+    // a grid of at most one block per two CUs (the LSTM's recurrent GEMMs, fc1, single-frame calls): twice the blocks at half the width
+    if (bn128 && (long)((p.M + 127) / 128) * (p.N / 128) <= 128) bn128 = false;
     if (p.tile_n == 64) bn128 = false;
     if (p.tile_n == 128 && p.N % 128 == 0) bn128 = true;
     p.ntm = (p.M + 127) / 128;
