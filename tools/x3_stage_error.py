@@ -29,7 +29,12 @@ def sp32_to_f32(raw_i16, shape):
 
 
 def main():
-    seeds = [int(a) for a in sys.argv[1:]] or [42, 43, 44, 45, 46]
+    args = sys.argv[1:]
+    if args and args[0] == "--lib":  # a one-off experiment build of the library
+        from avcer_amd import _lib
+        _lib.LIB = os.path.abspath(args[1])
+        args = args[2:]
+    seeds = [int(a) for a in args] or [42, 43, 44, 45, 46]
     eng = Engine(0)
     frames = synth.face_frames(2468, 8)
     ft = torch.from_numpy(frames)
