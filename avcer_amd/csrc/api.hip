@@ -179,13 +179,13 @@ int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
 // Which form of the split-bf16 contraction serves a layer of M positions, N channels, K inputs: the weights-direct kernel
 // (128 x 256 tiles, dtype 7 / 8) or the LDS-staged one (128 x 128, dtype 5 / 6).  Results are bit-identical, so this is
 // speed only.  Model, calibrated on tools/ab_layers.py (profiles/r03_ab_layers*.txt): a 128 x 256 tile costs 1.84 tiles of
-// 128 x 128 (1.95 where K <= 1024: the tile's prologue and epilogue weigh more), a 112 x 256 tile 7/8 of that, and the
+// 128 x 128 (1.90 where K <= 1024: the tile's prologue and epilogue weigh more), a 112 x 256 tile 7/8 of that, and the
 // grid takes common.h grid_rounds() rounds of 512 blocks.
 bool prefer_weights_direct(long M, int N, long K) {
     const long mt = (M + 127) / 128, mt112 = (M + 111) / 112;
     // the direct form also has a 112-row tile (gemm.hip launch_wd picks it by the same model)
     const double wd = std::min(grid_rounds(mt * (N / 256)), grid_rounds(mt112 * (N / 256)) * 112.0 / 128.0);
-    return wd * (K <= 1024 ? 1.95 : 1.84) < grid_rounds(mt * (N / 128));
+    return wd * (K <= 1024 ? 1.90 : 1.84) < grid_rounds(mt * (N / 128));
 }
 
 struct Net {

@@ -22,7 +22,7 @@ def _desc(**kw):
 
 
 def _act(v, act):
-    return F.relu(v) if act == 1 else (F.gelu(v) if act == 2 else v)
+    return F.relu(v) if act == 1 else (F.gelu(v) if act in (2, 3) else v)
 
 
 def to_sp32(x):
@@ -253,6 +253,35 @@ def test_dual_source_fused_1x1(engine, dtype):
     ref = F.relu(_dec(td, ak).double() @ wdv.double().cpu()[:, :p_].t() + xs @ wdv.double().cpu()[:, p_:].t() + bias.double())
     got = _dec(yd, ok).double()
     assert (got - ref).abs().max() < _tol(dtype, ref)
+
+
+@pytest.mark.parametrize("dtype", [0, 5, 7])
+def test_gelu_with_the_short_erf(engine, dtype):
+    """act = 3: GELU with the Abramowitz-Stegun 7.1.26 erf (gemm_dev.h gelu_fast).  An identity contraction turns the epilogue
+    into a function evaluator: 64 k arguments across [-8, 8] against float64 GELU (audio_8_cl.py / wav2vec2's nn.GELU, erf
+    form).  Bound: 5e-7 absolute (the exact form's own f32 rounding reaches 4.5e-7), plus the sp32 encoding step where
+    the output is sp32."""
+    n = 256
+    m = 256
+    g = torch.Generator().manual_seed(5)
+    xs = torch.cat([torch.linspace(-8, 8, m * n - 4096), torch.randn(4096, generator=g) * 0.01]).reshape(m, n)
+    w = torch.eye(n)
+    d = _desc(batch=m, cin=n, x_stride_b=n, x_stride_h=n, x_stride_w=n, n=n, y_ld=n, r_ld=n, act=3)
+    dev = engine.device
+    ak, ok = ("f32", "f32") if dtype == 0 else ("sp32", "sp32")
+    xd = _enc(xs, ak, dev)
+    wd = w.to(dev)
+    w_arg = wd if dtype == 0 else (engine.weight_frags(wd) if dtype == 7 else engine.split_weight_rows(wd))
+    yd = _enc(torch.zeros(m, n), ok, dev)
+    engine.conv_gemm(d, dtype, xd, w_arg, None, None, None, yd)
+    torch.cuda.synchronize()
+    arg = _dec(xd, ak).double()                       # what the kernel saw (sp32 rounds the arguments to 2^-17)
+    ref = 0.5 * arg * (1.0 + torch.erf(arg / 2 ** 0.5))
+    got = _dec(yd, ok).double()
+    err = (got - ref).abs()
+    tol = 5e-7 + (0 if dtype == 0 else 2.0 ** -16 * ref.abs().max().item())
+    print(f"gelu act=3 dtype {dtype}: max abs err {err.max().item():.2e}")
+    assert err.max().item() < tol
 
 
 # ----------------------------------------------------------------------------- fused bottleneck chain (csrc/fused.hip)

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
     ap.add_argument("--f32out", action="store_true", help="f32 output (dtype 6 / 8) instead of sp32 (5 / 7)")
+    ap.add_argument("--act", type=int, default=-1, help="override the layers' activation (0 none, 1 relu, 2 gelu, 3 gelu with the short erf)")
     ap.add_argument("--lib", default="", help="a one-off experiment build of libavcer_hip.so to load instead of the in-tree one")
     a = ap.parse_args()
     if a.lib:
@@ -45,6 +46,8 @@ def main():
     print(f"{'layer':38s} {'x':>3s} {'staged us':>10s} {'direct128':>10s} {'direct112':>10s} {'library':>10s} {'best/staged':>11s}")
     for L in layers:
         d = L["d"]
+        if a.act >= 0:
+            d.act = a.act
         m, k, n = d.batch * d.out_h * d.out_w, d.kh * d.kw * d.cin, d.n
         g = L.get("groups", 1)
         if d.x_stride_w % 32 or d.cin % 32 or g != 1 or n % 256 or (k // 32) % 2 or d.y_ld % 32:
