@@ -857,8 +857,9 @@ __device__ __forceinline__ int att_swz(int row, int chunk) {
     return row * 128 + ((chunk ^ (int)((0x32765410u >> (((row >> 1) & 7) * 4)) & 7u)) << 4);
 }
 
+constexpr int ATTM_WAVES = 8;  // one query tile per wave at 99 tokens (7 tiles): the four-wave form ran two rounds of 2 / 2 / 2 / 1
 template <typename T, typename TO, int NKT, int X3, int D>
-__global__ void __launch_bounds__(256) attention_mfma_kernel(const T* __restrict__ qkv, TO* __restrict__ out, int s, int heads,
+__global__ void __launch_bounds__(64 * ATTM_WAVES) attention_mfma_kernel(const T* __restrict__ qkv, TO* __restrict__ out, int s, int heads,
                                                            float scale) {
     static_assert(D == 64 || D == 32, "head dimension 64 (wav2vec2 layers, tl2) or 32 (tl1)");
     constexpr int KS = D / 32;               // 32-wide K-steps of Q.K^T
@@ -879,14 +880,15 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const T* __restrict
 
     // Every global load of the block is issued before the first one is needed: a block is a chain of HBM round trips
     // otherwise (four staging passes, then one per query tile: ~6 x 2.5 us against ~4 us of arithmetic -- the launch ran at
-    // a third of its present speed).  First the query rows of this wave's tiles (tile wv, wv + 4, ...), raw; then K / V in
+    // a third of its present speed).  First the query rows of this wave's tiles (tile wv, wv + 8, ...), raw; then K / V in
     // batches of up to four staging passes.
     const int nqt = (s + 15) >> 4;
-    constexpr int QI = NKT / 4;              // query tiles per wave
+    constexpr int NTHR = 64 * ATTM_WAVES;
+    constexpr int QI = NKT / ATTM_WAVES;     // query tiles per wave
     float qraw[QI][KS][8];
 #pragma unroll
     for (int qi = 0; qi < QI; ++qi) {
-        const int qrow = (wv + 4 * qi) * 16 + q16;
+        const int qrow = (wv + ATTM_WAVES * qi) * 16 + q16;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (qrow < s) {
@@ -899,13 +901,13 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const T* __restrict
         }
     }
     // ---- stage K (row-major) and V (transposed + permuted) as bf16 planes
-    constexpr int ITEMS = SP * (D / 8), PASSES = ITEMS / 256, UB = PASSES < 4 ? PASSES : 4;
-    static_assert(ITEMS % 256 == 0 && PASSES % UB == 0, "whole staging passes, whole batches");
+    constexpr int ITEMS = SP * (D / 8), PASSES = ITEMS / NTHR, UB = PASSES < 4 ? PASSES : 4;
+    static_assert(ITEMS % NTHR == 0 && PASSES % UB == 0 && NKT % ATTM_WAVES == 0, "whole staging passes, whole batches");
     for (int p0 = 0; p0 < PASSES; p0 += UB) {
     float kvb[UB][8], vvb[UB][8];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-        const int it = (p0 + u) * 256 + tid;
+        const int it = (p0 + u) * NTHR + tid;
         const int r = it / (D / 8), c = it % (D / 8);
         if (r < s) {
             ld4<T>(base, (long)r * rowstride + e + 8 * c, kvb[u]);
@@ -919,7 +921,7 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const T* __restrict
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-        const int it = (p0 + u) * 256 + tid;
+        const int it = (p0 + u) * NTHR + tid;
         const int r = it / (D / 8), c = it % (D / 8);   // key row, chunk of 8 head-dim elements (K rows keep a 128-byte pitch)
         const float (&kv)[8] = kvb[u];
         const float (&vv)[8] = vvb[u];
@@ -946,7 +948,7 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(const T* __restrict
 
 #pragma unroll
     for (int qi = 0; qi < QI; ++qi) {
-        const int tq = wv + 4 * qi;
+        const int tq = wv + ATTM_WAVES * qi;
         if (tq >= nqt) break;
         const int qrow = tq * 16 + q16;
         // ---- Q fragments (B operand): this lane's query row, head-dim 32ks + 8g .. +7, pre-scaled
@@ -1365,7 +1367,7 @@ int k_attention(avcer_ctx* ctx, const void* qkv, void* out, int n, int s, int he
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));               \
             attr_dev |= 1ull << (ctx->device & 63);                                                                   \
         }                                                                                                             \
-        attention_mfma_kernel<T, TO, NKT, X3, D><<<grid, 256, lds_m, st>>>((const T*)qkv, (TO*)out, s, heads, scale); \
+        attention_mfma_kernel<T, TO, NKT, X3, D><<<grid, 64 * ATTM_WAVES, lds_m, st>>>((const T*)qkv, (TO*)out, s, heads, scale); \
     } while (0)
 #define ATTM_D(T, TO, NKT, X3) do { if (d == 64) ATTM(T, TO, NKT, X3, 64); else ATTM(T, TO, NKT, X3, 32); } while (0)
         if (x3) { if (nkt == 8) ATTM_D(float, sp32_t, 8, 1); else ATTM_D(float, sp32_t, 16, 1); }
