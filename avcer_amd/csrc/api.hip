@@ -399,12 +399,19 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     // stem + max-pool of `nb` frames starting at frame f0 of the call: -> B[1] (55x55x64), B[0] is scratch
     auto run_stem = [&](int f0, int nb, void** B) {
         if (net.x3) {
-            // x3 mode: planar bf16 hi / lo image -> ONE kernel for conv 7x7/2 + BN + ReLU + max-pool 3x3/2 (fused.hip)
-            if (frames) net.chk(k_preprocess(ctx, frames + (size_t)f0 * in_h * in_w * 3, nb, in_h, in_w, P, 3, st));
-            else net.chk(k_pack_nchw(ctx, nchw + (size_t)f0 * 3 * 224 * 224, nb, P, 3, st));
+            // x3 mode: ONE kernel for conv 7x7/2 + BN + ReLU + max-pool 3x3/2 (fused.hip).  From u8 frames it also does the
+            // preprocessing (raw pixels are exact in bf16: two MFMAs per product, the mean lives in the shift table stem.b9);
+            // the preprocessed-tensor entry point carries arbitrary floats and goes through the planar bf16 hi / lo image.
             const Tensor* w = net.T("stem7.w");
             if (net.err != AVCER_OK) return;
             if (!w->x3) { net.err = set_err(ctx, AVCER_ESTATE, "stem7.w: split weights not prepared"); return; }
+            if (frames) {
+                net.chk(launch_stem_pool_u8(ctx, frames + (size_t)f0 * in_h * in_w * 3, in_h, in_w, w->x3, net.F("stem.s"),
+                                            net.F("stem.b9"), B[1], nb, st));
+                net.tap("stem", B[1], (size_t)nb * 55 * 55 * 64 * es);
+                return;
+            }
+            net.chk(k_pack_nchw(ctx, nchw + (size_t)f0 * 3 * 224 * 224, nb, P, 3, st));
             net.chk(launch_stem_pool(ctx, P, (size_t)nb * 230 * 230 * 4 * 2, w->x3, net.F("stem.s"), net.F("stem.b"), B[1], nb, st));
             net.tap("stem", B[1], (size_t)nb * 55 * 55 * 64 * es);
             return;
@@ -1128,6 +1135,13 @@ extern "C" int avcer_stem_pool(avcer_ctx* ctx, const void* planes_hi_lo, size_t 
     if (plane_bytes != (size_t)n * 230 * 230 * 4 * 2) return set_err(ctx, AVCER_EINVAL, "stem_pool: plane_bytes != n*230*230*4*2");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return launch_stem_pool(ctx, planes_hi_lo, plane_bytes, w, scale, bias, y, n, (hipStream_t)stream);
+}
+
+extern "C" int avcer_stem_pool_u8(avcer_ctx* ctx, const uint8_t* frames, int n, int in_h, int in_w, const void* w, const float* scale,
+                                  const float* shifts9, void* y, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_stem_pool_u8(ctx, frames, in_h, in_w, w, scale, shifts9, y, n, (hipStream_t)stream);
 }
 
 extern "C" int avcer_split_weights(avcer_ctx* ctx, const float* w, void* out, size_t numel, avcer_stream_t stream) {

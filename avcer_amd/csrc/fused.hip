@@ -83,6 +83,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // ------------------------------------------------------------------------------------------------ stem + max-pool
 struct StemParams {
     const char* P;         // bf16 hi plane [n][230][230][4]; the lo plane starts plane_bytes later
+    const uint8_t* F;      // U8 form: the frames themselves, u8 [n][in_h][in_w][3] RGB (data/utils.py:19-39 happens in the kernel)
+    int in_h, in_w;
+    const float* bias9;    // U8 form: [9 border classes][64]: BN shift - BN scale * sum over the VALID taps of w * channel mean
     unsigned p_bytes;      // extent of both planes (hardware bounds check)
     unsigned plane_bytes;
     const char* W;         // split weights [64][7 tap rows x 32] (sp32 groups of 32 K-elements, rows permuted)
@@ -109,12 +112,22 @@ __device__ __forceinline__ int stage64(int row, int chunk) { return row * 256 + 
 // All seven weight tiles (56 KiB) arrive with the same burst, so the K loop has no barrier and no wait in it; the second
 // block of the CU computes while this one waits for its burst.  Rows of positions outside the 112 x 112 map read whatever
 // follows in memory (or zeros past the planes): each output row depends on its own A row only, and the pool never reads them.
+//
+// U8 = true: the block builds its patch from the u8 frames (BGR flip, PIL NEAREST resize when the frame is not 224 x 224,
+// zeros outside the image) as RAW PIXEL VALUES -- integers 0..255 are exact in bf16, so the activation has no lo half: two
+// MFMAs per product instead of three, one plane instead of two, no preprocessing launch and no 846 KB-per-frame image in
+// HBM.  The mean subtraction of data/utils.py:36-38 moves into the shift: sum_valid w (p - mu) = sum_valid w p - sum_valid w mu,
+// where "valid" are the taps inside the image (Conv2dSame pads the NORMALISED image with zeros, video.py:68-80), i.e. a constant
+// per output channel and BORDER CLASS of the stem position (first row / interior / row 110, same for columns: 9 classes;
+// avcer_amd/packing.py stem.b9, folded with the BatchNorm shift in float64).
+template <bool U8>
 __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
     constexpr int BN = 64, NK = 7;
     constexpr int PROWS = 2 * (ST_RH - 1) + NK, PCH = (2 * (ST_RW - 1) + 8) / 2;  // 39 patch rows of 18 16-byte chunks (36 pixels)
     constexpr int PLANE = PROWS * PCH * 16;                                       // 11 232 B per plane
-    constexpr int NCH = 2 * PROWS * PCH;                                          // 1 404 chunks
-    constexpr int WOFF = ((2 * PLANE + 1023) / 1024) * 1024;                      // weights behind the patch
+    constexpr int NPL = U8 ? 1 : 2;                                               // planes of the patch
+    constexpr int NCH = NPL * PROWS * PCH;                                        // 702 / 1 404 chunks
+    constexpr int WOFF = ((NPL * PLANE + 1023) / 1024) * 1024;                    // weights behind the patch
     constexpr int WT = BN * ROWB;                                                 // one tap row's weight tile, 8 KiB
     constexpr int LDS_BYTES = WOFF + NK * WT > 256 * 256 ? WOFF + NK * WT : 256 * 256;
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
@@ -124,8 +137,38 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
     const int b = blk / (ST_TY * ST_TX), t = blk % (ST_TY * ST_TX);
     const int ty = t / ST_TX, tx = t % ST_TX;
 
-    const auto prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.P), (short)0, (int)p.p_bytes, 0x00020000);
     const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W), (short)0, 64 * NK * ROWB, 0x00020000);
+    if constexpr (U8) {
+        // patch chunk ci = patch row ci / 18, pixels 2 (ci % 18), + 1 of the zero-bordered 230 x 230 image: [B G R 0] x 2 as bf16
+        const uint8_t* fr = p.F + (long)b * p.in_h * p.in_w * 3;
+        const bool resize = p.in_h != 224 || p.in_w != 224;
+#pragma unroll
+        for (int j = 0; j < (NCH + 255) / 256; ++j) {
+            const int ci = j * 256 + tid;
+            if (ci >= NCH) break;
+            const int prow = ci / PCH, pc = ci - prow * PCH;
+            const int iy = 4 * ST_TH * ty + prow - 2;
+            uint32_t wds[4] = {0u, 0u, 0u, 0u};
+            if ((unsigned)iy < 224u) {
+                int sy = iy;
+                if (resize) sy = min((int)(((double)iy + 0.5) * ((double)p.in_h / 224.0)), p.in_h - 1);  // PIL NEAREST
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    const int ix = 4 * ST_TW * tx + 2 * pc + px - 2;
+                    if ((unsigned)ix < 224u) {
+                        int sx = ix;
+                        if (resize) sx = min((int)(((double)ix + 0.5) * ((double)p.in_w / 224.0)), p.in_w - 1);
+                        const uint8_t* q = fr + ((long)sy * p.in_w + sx) * 3;
+                        // integers up to 255 need 8 significant bits: the bf16 is exact
+                        wds[2 * px] = (uint32_t)f2bf((float)q[2]) | ((uint32_t)f2bf((float)q[1]) << 16);
+                        wds[2 * px + 1] = (uint32_t)f2bf((float)q[0]);
+                    }
+                }
+            }
+            *reinterpret_cast<uint4*>(smem + ci * 16) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+        }
+    } else {
+    const auto prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.P), (short)0, (int)p.p_bytes, 0x00020000);
     // patch: chunk c of the LDS image = chunk (c % 702) of plane c / 702; one DMA instruction copies 64 consecutive chunks
     const unsigned origin = (unsigned)((((long)b * 230 + 4 * ST_TH * ty) * 230 + 4 * ST_TW * tx) * 8);
 #pragma unroll
@@ -136,6 +179,7 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
         const int prow = ci / PCH, pc = ci - prow * PCH;
         const unsigned off = c < NCH ? origin + (unsigned)(prow * (230 * 8) + pc * 16) + plane * p.plane_bytes : OOB;
         if (piece * 64 < NCH) dma16(prs, smem + piece * 1024, off);
+    }
     }
     // weights: tap row ky = rows [64][32 K] of p.W at column block ky, 8 DMA instructions of 8 rows each, swizzled like every tile
     {
@@ -169,13 +213,20 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
 #pragma unroll
         for (int fm = 0; fm < 4; ++fm) {
             ah[fm] = *reinterpret_cast<const bf16x8_t*>(smem + abase[fm] + ky * (PCH * 16));
-            al[fm] = *reinterpret_cast<const bf16x8_t*>(smem + PLANE + abase[fm] + ky * (PCH * 16));
+            if constexpr (!U8) al[fm] = *reinterpret_cast<const bf16x8_t*>(smem + PLANE + abase[fm] + ky * (PCH * 16));
         }
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) {
             const bf16x8_t wh = ldfrag(sb, fn * 16 + l15, g), wl = ldfrag(sb, fn * 16 + l15, 4 + g);
 #pragma unroll
-            for (int fm = 0; fm < 4; ++fm) mfma3(acc[fn][fm], wh, wl, ah[fm], al[fm]);
+            for (int fm = 0; fm < 4; ++fm) {
+                if constexpr (U8) {  // a = ah exactly: a.w = ah.wl + ah.wh (same order as mfma3 without its al term)
+                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[fm], acc[fn][fm], 0, 0, 0);
+                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[fm], acc[fn][fm], 0, 0, 0);
+                } else {
+                    mfma3(acc[fn][fm], wh, wl, ah[fm], al[fm]);
+                }
+            }
         }
     }
     pin(acc);
@@ -184,10 +235,20 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
 #pragma unroll
     for (int fn = 0; fn < 4; ++fn) {
         const int ch = 32 * (fn >> 1) + 8 * g + 4 * (fn & 1);  // weight rows are stored permuted (split_weight_rows_kernel)
-        const float4 sc = *reinterpret_cast<const float4*>(p.scale + ch), bi = *reinterpret_cast<const float4*>(p.bias + ch);
+        const float4 sc = *reinterpret_cast<const float4*>(p.scale + ch);
+        float4 bi = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (!U8) bi = *reinterpret_cast<const float4*>(p.bias + ch);
 #pragma unroll
         for (int fm = 0; fm < 4; ++fm) {
             const int row = wave * 64 + fm * 16 + l15;
+            if constexpr (U8) {
+                // border class of stem position (cy, cx): taps above / left of the image at 0, below / right of it at 110
+                // (111 is computed but never pooled)
+                const int ry = row / ST_RW, rx = row - ry * ST_RW;
+                const int cy = 2 * ST_TH * ty + ry, cx = 2 * ST_TW * tx + rx;
+                const int cls = 3 * (cy == 0 ? 0 : (cy >= 110 ? 2 : 1)) + (cx == 0 ? 0 : (cx >= 110 ? 2 : 1));
+                bi = *reinterpret_cast<const float4*>(p.bias9 + cls * 64 + ch);
+            }
             *reinterpret_cast<float4*>(smem + stage64(row, ch >> 2)) =
                 make_float4(relu_nan(acc[fn][fm][0] * sc.x + bi.x), relu_nan(acc[fn][fm][1] * sc.y + bi.y),
                             relu_nan(acc[fn][fm][2] * sc.z + bi.z), relu_nan(acc[fn][fm][3] * sc.w + bi.w));
@@ -826,11 +887,12 @@ int launch_stem_pool(avcer_ctx* ctx, const void* planes, size_t plane_bytes, con
     if (!planes || !w_x3 || !scale || !bias || !y || n <= 0) return set_err(ctx, AVCER_EINVAL, "stem_pool: bad arguments");
     if (2 * plane_bytes >= (size_t)OOB) return set_err(ctx, AVCER_EINVAL, "stem_pool: %d frames exceed the 4 GiB descriptor", n);
     StemParams p;
+    memset(&p, 0, sizeof(p));
     p.P = (const char*)planes; p.plane_bytes = (unsigned)plane_bytes; p.p_bytes = (unsigned)(2 * plane_bytes);
     p.W = (const char*)w_x3; p.scale = scale; p.bias = bias; p.Y = (char*)y; p.n = n;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     TRY(prof_begin(ctx, st, &ev0, &ev1));
-    stem_pool_kernel<<<dim3(n * ST_TY * ST_TX), dim3(256), 0, st>>>(p);
+    stem_pool_kernel<false><<<dim3(n * ST_TY * ST_TX), dim3(256), 0, st>>>(p);
     if (ev1) (void)hipEventRecord(ev1, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "stem_pool launch: %s", hipGetErrorString(e));
@@ -950,4 +1012,24 @@ int measure_ceilings(avcer_ctx* ctx, double* mfma_bf16_tflops, double* hbm_copy_
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "measure_ceilings: %s", hipGetErrorString(e));
     return AVCER_OK;
+}// The same launch from the u8 frames themselves (stem_pool_kernel<true>): no preprocessing pass, two MFMAs per product.
+int launch_stem_pool_u8(avcer_ctx* ctx, const uint8_t* frames, int in_h, int in_w, const void* w_x3, const float* scale,
+                        const float* bias9, void* y, int n, hipStream_t st) {
+    if (!frames || !w_x3 || !scale || !bias9 || !y || n <= 0 || in_h <= 0 || in_w <= 0)
+        return set_err(ctx, AVCER_EINVAL, "stem_pool_u8: bad arguments");
+    StemParams p;
+    memset(&p, 0, sizeof(p));
+    p.F = frames; p.in_h = in_h; p.in_w = in_w; p.bias9 = bias9;
+    p.W = (const char*)w_x3; p.scale = scale; p.Y = (char*)y; p.n = n;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    TRY(prof_begin(ctx, st, &ev0, &ev1));
+    stem_pool_kernel<true><<<dim3(n * ST_TY * ST_TX), dim3(256), 0, st>>>(p);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "stem_pool_u8 launch: %s", hipGetErrorString(e));
+    ctx->gemm_launches += 1;
+    ctx->gemm_flops += 2.0 * n * 112.0 * 112.0 * 64 * 147;
+    return AVCER_OK;
 }
+
+

@@ -320,6 +320,16 @@ class Engine:
                                              _ptr(y), n, self._stream()))
         return y
 
+    def stem_pool_u8(self, frames_u8, w_split, scale, shifts9):
+        """The fused stem fed with u8 frames [n, h, w, 3] RGB (preprocessing inside, raw pixels as exact bf16 operands);
+        shifts9 f32 [9, 64] from packing.stem_border_shifts.  -> sp32 [n, 55, 55, 64] as int16 [n, 55, 55, 128]."""
+        fr = self._dev(frames_u8, torch.uint8)
+        n, h, w = int(fr.shape[0]), int(fr.shape[1]), int(fr.shape[2])
+        y = torch.empty(n, 55, 55, 128, dtype=torch.int16, device=self.device)
+        self._check(self.lib.avcer_stem_pool_u8(self.ctx, _ptr(fr), n, h, w, _ptr(w_split), _ptr(scale), _ptr(shifts9), _ptr(y),
+                                                self._stream()))
+        return y
+
     def gemm_stats(self, reset: bool = True):
         n, f = C.c_int64(0), C.c_double(0.0)
         self._check(self.lib.avcer_gemm_stats(self.ctx, C.byref(n), C.byref(f), int(reset)))

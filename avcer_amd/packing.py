@@ -65,6 +65,28 @@ def _conv1d_w(w) -> np.ndarray:
     return np.ascontiguousarray(w.transpose(0, 2, 1)).reshape(w.shape[0], -1)
 
 
+PIXEL_MEANS = (91.4953, 103.8827, 131.0912)  # data/utils.py:36-38, in the channel order the network is fed (B, G, R)
+
+
+def stem_border_shifts(w, scale, shift) -> np.ndarray:
+    """Shifts of the fused stem when it contracts RAW pixel values (fused.hip stem_pool_kernel<true>).
+
+    The reference convolves the normalised image p - mu, zero-padded 2 before / 3 after (video.py:68-80), so a stem position sums
+    w (p - mu) over the taps INSIDE the image: sum_valid w p - sum_valid w mu.  The second term depends on the output channel and
+    on which taps are valid -- rows: position 0 loses taps 0, 1; position 110 loses tap 6 (position 111 is never pooled);
+    columns alike -- i.e. on one of 9 border classes 3 * row_class + col_class (0 first, 1 interior, 2 last).  Returns f32
+    [9, 64]: BN shift - BN scale * sum_valid w mu, accumulated in float64."""
+    w = np.asarray(w, np.float64)                      # [64, 3, 7, 7]
+    mu = np.asarray(PIXEL_MEANS, np.float64)
+    valid = (slice(2, 7), slice(0, 7), slice(0, 6))
+    out = np.empty((9, w.shape[0]), np.float64)
+    for ry, vy in enumerate(valid):
+        for rx, vx in enumerate(valid):
+            c = np.einsum("ocyx,c->o", w[:, :, vy, vx], mu)
+            out[3 * ry + rx] = np.asarray(shift, np.float64) - np.asarray(scale, np.float64) * c
+    return out.astype(np.float32)
+
+
 def pack_static(sd) -> "OrderedDict[str, np.ndarray]":
     """ResNet50(7) state_dict (architectures/video.py:93-166)."""
     sd = _unwrap(sd)
@@ -75,6 +97,7 @@ def pack_static(sd) -> "OrderedDict[str, np.ndarray]":
     out["stem.w"] = stem.reshape(64, 256)
     out["stem7.w"] = np.ascontiguousarray(stem[:, :7].reshape(64, 224))  # 7 tap rows only: stem_pool_kernel (x3 mode)
     out["stem.s"], out["stem.b"] = _bn_fold(sd, "batch_norm1", STATIC_BN_EPS)
+    out["stem.b9"] = stem_border_shifts(w, out["stem.s"], out["stem.b"])
     for li, (planes, blocks, _) in enumerate(RESNET_STAGES, start=1):
         for b in range(blocks):
             src, dst = f"layer{li}.{b}", f"l{li}.{b}"

@@ -51,9 +51,10 @@ enum {
  *   AVCER_MODE_FP32    |dlogit| <= 1.6e-5, |dprob| <= 1.6e-5 up to 8 x sharper heads than the synthetic generator's;
  *   AVCER_MODE_BF16X3  static CNN |dlogit| <= 7.5e-5 absolute, whatever the head (each contraction carries 4.5e-6 relative
  *                      error; the 7x7 average pool and the f32 fc1 / fc2 keep 4.6e-6 of the trunk's 1.3e-5), so
- *                      |dprob| <= 1.5e-5 / 5.3e-5 / 8.4e-5 at 1 x / 4 x / 8 x the generator's logit scale: inside the 1e-4
- *                      gate for every head tried.  A checkpoint whose logits are sharper still (|logit| differences of
- *                      several tens) should be run in AVCER_MODE_FP32, the default of the host mirrors. */
+ *                      |dprob| <= 2.1e-5 / 6.6e-5 at 1 x / 4 x the generator's logit scale (inside the 1e-4 gate with
+ *                      a margin of 1.5 at 4 x) and 0.7-1.0e-4 at 8 x: AT the gate -- the figure moves by +-25 % with any
+ *                      re-ordering of a sum upstream.  A checkpoint whose softmax is that sharp (top logit margins of
+ *                      several tens) belongs in AVCER_MODE_FP32, the default of the host mirrors. */
 
 int avcer_abi_version(void);
 
@@ -252,6 +253,13 @@ int avcer_bneck_chain(avcer_ctx* ctx, int planes, int nb, int h, int w, const vo
                       const float* b1n, avcer_stream_t stream);
 int avcer_stem_pool(avcer_ctx* ctx, const void* planes_hi_lo, size_t plane_bytes, const void* w, const float* scale,
                     const float* bias, void* y, int n, avcer_stream_t stream);
+/* The same launch fed with the u8 frames themselves ([n,in_h,in_w,3] RGB; data/utils.py:19-39 -- NEAREST resize to 224, BGR flip,
+ * mean subtraction -- happens inside): raw pixel values are exact in bf16, so the stem runs two MFMAs per product, and the
+ * channel means move into shifts9 f32 [9][64] = BN shift - BN scale * (sum over the taps inside the image of w * mean), one
+ * row per border class 3 * row_class + col_class (0: first stem row / column, 1: interior, 2: row / column 110; see
+ * avcer_amd/packing.py stem_border_shifts).  What avcer_static_forward runs in AVCER_MODE_BF16X3. */
+int avcer_stem_pool_u8(avcer_ctx* ctx, const uint8_t* frames, int n, int in_h, int in_w, const void* w, const float* scale,
+                       const float* shifts9, void* y, avcer_stream_t stream);
 
 /* The sp32 split of an ACTIVATION tensor (what a producer's epilogue writes with dtype 4 / 5): for every group of 32
  * elements, 32 bf16 "hi" values then 32 bf16 "lo" values with x = hi + lo (+ O(2^-17 |x|)).  x f32 [numel] (a multiple

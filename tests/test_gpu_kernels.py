@@ -470,3 +470,38 @@ def test_stem_pool_vs_float64(engine):
     err = (got - ref).abs().max().item()
     print(f"stem_pool: max|err| {err:.2e} (max|ref| {ref.abs().max().item():.1f})")
     assert err < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("hw", [(224, 224), (180, 250)])
+def test_stem_pool_from_u8_frames_vs_float64(engine, hw):
+    """The stem fed with the u8 frames: NEAREST resize to 224 x 224 (PIL rule), BGR flip and mean subtraction
+    (data/utils.py:19-39) happen inside, the pixel values enter the MFMA as exact bf16 integers and the means live in the 9
+    border-class shifts of packing.stem_border_shifts.  Against float64: preprocessing as the reference does it, Conv2dSame's
+    padding of the NORMALISED image (video.py:68-80), BN, ReLU, max-pool."""
+    from avcer_amd.packing import PIXEL_MEANS, stem_border_shifts
+
+    h, w_ = hw
+    g = torch.Generator().manual_seed(13 + h)
+    n = 3
+    frames = torch.randint(0, 256, (n, h, w_, 3), generator=g, dtype=torch.uint8)
+    frames[0, : h // 3] = 255                                               # saturated and black regions reach the borders
+    frames[1, :, : w_ // 4] = 0
+    w = torch.randn(64, 3, 7, 7, generator=g) / (147 ** 0.5)
+    scale, bias = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    # reference preprocessing: PIL NEAREST = src index floor((dst + 0.5) * in / out), RGB -> BGR, minus the channel means
+    sy = torch.clamp(((torch.arange(224).double() + 0.5) * (h / 224.0)).floor().long(), max=h - 1)
+    sx = torch.clamp(((torch.arange(224).double() + 0.5) * (w_ / 224.0)).floor().long(), max=w_ - 1)
+    img = frames[:, sy][:, :, sx].double().flip(-1) - torch.tensor(PIXEL_MEANS, dtype=torch.float64)   # [n,224,224,3] BGR - mean
+    x = F.pad(img.permute(0, 3, 1, 2), (2, 3, 2, 3))
+    ref = F.max_pool2d(F.relu(F.conv2d(x, w.double(), stride=2) * scale.double()[None, :, None, None] + bias.double()[None, :, None, None]),
+                       3, 2)
+    w7 = torch.zeros(64, 7, 8, 4)
+    w7[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    dev = engine.device
+    shifts = torch.from_numpy(stem_border_shifts(w.numpy(), scale.numpy(), bias.numpy()))
+    y = engine.stem_pool_u8(frames.to(dev), engine.split_weight_rows(w7.reshape(64, 224)), scale.to(dev), shifts.to(dev))
+    torch.cuda.synchronize()
+    got = from_sp32(y.cpu()).permute(0, 3, 1, 2).double()
+    err = (got - ref).abs().max().item()
+    print(f"stem_pool_u8 {h}x{w_}: max|err| {err:.2e} (max|ref| {ref.abs().max().item():.1f})")
+    assert err < 2e-5 * max(1.0, ref.abs().max().item())

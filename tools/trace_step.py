@@ -31,8 +31,8 @@ def show(d):
     f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     names = [r["Kernel_Name"] for r in rows]
-    # the last step starts at the last preprocess launch but one (two front passes per step)
-    starts = [i for i, n in enumerate(names) if "preprocess_planar" in n]
+    # the last step starts at the last stem launch but one (two front passes per step)
+    starts = [i for i, n in enumerate(names) if "stem_pool_kernel" in n]
     first = starts[-2]
     t0 = int(rows[first]["Start_Timestamp"])
     total = 0.0
