@@ -83,9 +83,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // ------------------------------------------------------------------------------------------------ stem + max-pool
 struct StemParams {
     const char* P;         // bf16 hi plane [n][230][230][4]; the lo plane starts plane_bytes later
-    const uint8_t* F;      // U8 form: the frames themselves, u8 [n][in_h][in_w][3] RGB (data/utils.py:19-39 happens in the kernel)
+    const uint8_t* F;      // u8 form: the frames themselves, u8 [n][in_h][in_w][3] RGB (data/utils.py:19-39 happens in the kernel)
     int in_h, in_w;
-    const float* bias9;    // U8 form: [9 border classes][64]: BN shift - BN scale * sum over the VALID taps of w * channel mean
+    const float* bias9;    // u8 form: [9 border classes][64]: BN shift - BN scale * sum over the VALID taps of w * channel mean
     unsigned p_bytes;      // extent of both planes (hardware bounds check)
     unsigned plane_bytes;
     const char* W;         // split weights [64][7 tap rows x 32] (sp32 groups of 32 K-elements, rows permuted)
@@ -112,22 +112,12 @@ __device__ __forceinline__ int stage64(int row, int chunk) { return row * 256 + 
 // All seven weight tiles (56 KiB) arrive with the same burst, so the K loop has no barrier and no wait in it; the second
 // block of the CU computes while this one waits for its burst.  Rows of positions outside the 112 x 112 map read whatever
 // follows in memory (or zeros past the planes): each output row depends on its own A row only, and the pool never reads them.
-//
-// U8 = true: the block builds its patch from the u8 frames (BGR flip, PIL NEAREST resize when the frame is not 224 x 224,
-// zeros outside the image) as RAW PIXEL VALUES -- integers 0..255 are exact in bf16, so the activation has no lo half: two
-// MFMAs per product instead of three, one plane instead of two, no preprocessing launch and no 846 KB-per-frame image in
-// HBM.  The mean subtraction of data/utils.py:36-38 moves into the shift: sum_valid w (p - mu) = sum_valid w p - sum_valid w mu,
-// where "valid" are the taps inside the image (Conv2dSame pads the NORMALISED image with zeros, video.py:68-80), i.e. a constant
-// per output channel and BORDER CLASS of the stem position (first row / interior / row 110, same for columns: 9 classes;
-// avcer_amd/packing.py stem.b9, folded with the BatchNorm shift in float64).
-template <bool U8>
 __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
     constexpr int BN = 64, NK = 7;
     constexpr int PROWS = 2 * (ST_RH - 1) + NK, PCH = (2 * (ST_RW - 1) + 8) / 2;  // 39 patch rows of 18 16-byte chunks (36 pixels)
     constexpr int PLANE = PROWS * PCH * 16;                                       // 11 232 B per plane
-    constexpr int NPL = U8 ? 1 : 2;                                               // planes of the patch
-    constexpr int NCH = NPL * PROWS * PCH;                                        // 702 / 1 404 chunks
-    constexpr int WOFF = ((NPL * PLANE + 1023) / 1024) * 1024;                    // weights behind the patch
+    constexpr int NCH = 2 * PROWS * PCH;                                          // 1 404 chunks
+    constexpr int WOFF = ((2 * PLANE + 1023) / 1024) * 1024;                      // weights behind the patch
     constexpr int WT = BN * ROWB;                                                 // one tap row's weight tile, 8 KiB
     constexpr int LDS_BYTES = WOFF + NK * WT > 256 * 256 ? WOFF + NK * WT : 256 * 256;
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
@@ -137,38 +127,8 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
     const int b = blk / (ST_TY * ST_TX), t = blk % (ST_TY * ST_TX);
     const int ty = t / ST_TX, tx = t % ST_TX;
 
-    const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W), (short)0, 64 * NK * ROWB, 0x00020000);
-    if constexpr (U8) {
-        // patch chunk ci = patch row ci / 18, pixels 2 (ci % 18), + 1 of the zero-bordered 230 x 230 image: [B G R 0] x 2 as bf16
-        const uint8_t* fr = p.F + (long)b * p.in_h * p.in_w * 3;
-        const bool resize = p.in_h != 224 || p.in_w != 224;
-#pragma unroll
-        for (int j = 0; j < (NCH + 255) / 256; ++j) {
-            const int ci = j * 256 + tid;
-            if (ci >= NCH) break;
-            const int prow = ci / PCH, pc = ci - prow * PCH;
-            const int iy = 4 * ST_TH * ty + prow - 2;
-            uint32_t wds[4] = {0u, 0u, 0u, 0u};
-            if ((unsigned)iy < 224u) {
-                int sy = iy;
-                if (resize) sy = min((int)(((double)iy + 0.5) * ((double)p.in_h / 224.0)), p.in_h - 1);  // PIL NEAREST
-#pragma unroll
-                for (int px = 0; px < 2; ++px) {
-                    const int ix = 4 * ST_TW * tx + 2 * pc + px - 2;
-                    if ((unsigned)ix < 224u) {
-                        int sx = ix;
-                        if (resize) sx = min((int)(((double)ix + 0.5) * ((double)p.in_w / 224.0)), p.in_w - 1);
-                        const uint8_t* q = fr + ((long)sy * p.in_w + sx) * 3;
-                        // integers up to 255 need 8 significant bits: the bf16 is exact
-                        wds[2 * px] = (uint32_t)f2bf((float)q[2]) | ((uint32_t)f2bf((float)q[1]) << 16);
-                        wds[2 * px + 1] = (uint32_t)f2bf((float)q[0]);
-                    }
-                }
-            }
-            *reinterpret_cast<uint4*>(smem + ci * 16) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
-        }
-    } else {
     const auto prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.P), (short)0, (int)p.p_bytes, 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W), (short)0, 64 * NK * ROWB, 0x00020000);
     // patch: chunk c of the LDS image = chunk (c % 702) of plane c / 702; one DMA instruction copies 64 consecutive chunks
     const unsigned origin = (unsigned)((((long)b * 230 + 4 * ST_TH * ty) * 230 + 4 * ST_TW * tx) * 8);
 #pragma unroll
@@ -179,7 +139,6 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
         const int prow = ci / PCH, pc = ci - prow * PCH;
         const unsigned off = c < NCH ? origin + (unsigned)(prow * (230 * 8) + pc * 16) + plane * p.plane_bytes : OOB;
         if (piece * 64 < NCH) dma16(prs, smem + piece * 1024, off);
-    }
     }
     // weights: tap row ky = rows [64][32 K] of p.W at column block ky, 8 DMA instructions of 8 rows each, swizzled like every tile
     {
@@ -213,20 +172,13 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
 #pragma unroll
         for (int fm = 0; fm < 4; ++fm) {
             ah[fm] = *reinterpret_cast<const bf16x8_t*>(smem + abase[fm] + ky * (PCH * 16));
-            if constexpr (!U8) al[fm] = *reinterpret_cast<const bf16x8_t*>(smem + PLANE + abase[fm] + ky * (PCH * 16));
+            al[fm] = *reinterpret_cast<const bf16x8_t*>(smem + PLANE + abase[fm] + ky * (PCH * 16));
         }
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) {
             const bf16x8_t wh = ldfrag(sb, fn * 16 + l15, g), wl = ldfrag(sb, fn * 16 + l15, 4 + g);
 #pragma unroll
-            for (int fm = 0; fm < 4; ++fm) {
-                if constexpr (U8) {  // a = ah exactly: a.w = ah.wl + ah.wh (same order as mfma3 without its al term)
-                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[fm], acc[fn][fm], 0, 0, 0);
-                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[fm], acc[fn][fm], 0, 0, 0);
-                } else {
-                    mfma3(acc[fn][fm], wh, wl, ah[fm], al[fm]);
-                }
-            }
+            for (int fm = 0; fm < 4; ++fm) mfma3(acc[fn][fm], wh, wl, ah[fm], al[fm]);
         }
     }
     pin(acc);
@@ -235,20 +187,10 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
 #pragma unroll
     for (int fn = 0; fn < 4; ++fn) {
         const int ch = 32 * (fn >> 1) + 8 * g + 4 * (fn & 1);  // weight rows are stored permuted (split_weight_rows_kernel)
-        const float4 sc = *reinterpret_cast<const float4*>(p.scale + ch);
-        float4 bi = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (!U8) bi = *reinterpret_cast<const float4*>(p.bias + ch);
+        const float4 sc = *reinterpret_cast<const float4*>(p.scale + ch), bi = *reinterpret_cast<const float4*>(p.bias + ch);
 #pragma unroll
         for (int fm = 0; fm < 4; ++fm) {
             const int row = wave * 64 + fm * 16 + l15;
-            if constexpr (U8) {
-                // border class of stem position (cy, cx): taps above / left of the image at 0, below / right of it at 110
-                // (111 is computed but never pooled)
-                const int ry = row / ST_RW, rx = row - ry * ST_RW;
-                const int cy = 2 * ST_TH * ty + ry, cx = 2 * ST_TW * tx + rx;
-                const int cls = 3 * (cy == 0 ? 0 : (cy >= 110 ? 2 : 1)) + (cx == 0 ? 0 : (cx >= 110 ? 2 : 1));
-                bi = *reinterpret_cast<const float4*>(p.bias9 + cls * 64 + ch);
-            }
             *reinterpret_cast<float4*>(smem + stage64(row, ch >> 2)) =
                 make_float4(relu_nan(acc[fn][fm][0] * sc.x + bi.x), relu_nan(acc[fn][fm][1] * sc.y + bi.y),
                             relu_nan(acc[fn][fm][2] * sc.z + bi.z), relu_nan(acc[fn][fm][3] * sc.w + bi.w));
@@ -288,6 +230,191 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
         char* yp = p.Y + sp32_byte(e);
         *reinterpret_cast<bf16x8_t*>(yp) = hi;
         *reinterpret_cast<bf16x8_t*>(yp + 64) = lo;
+    }
+}
+
+// The stem of the x3 mode when the input is the u8 frames (avcer_static_forward): same tiling, but
+//  * the block builds its patch itself (BGR flip, PIL NEAREST resize when the frame is not 224 x 224, zeros outside the image)
+//    as RAW PIXEL VALUES: integers 0..255 are exact in bf16, so the activation has no lo half -- two MFMAs per product, one
+//    patch plane, no preprocessing launch and no 846 KB-per-frame image in HBM.  The mean subtraction of data/utils.py:36-38
+//    moves into the shift: sum_valid w (p - mu) = sum_valid w p - sum_valid w mu, "valid" = the taps inside the image
+//    (Conv2dSame pads the NORMALISED image with zeros, video.py:68-80): a constant per output channel and BORDER CLASS of the
+//    stem position (first row / interior / row 110, columns alike: 9 classes; avcer_amd/packing.py stem_border_shifts,
+//    folded with the BatchNorm shift in float64);
+//  * the block is small enough for THREE per CU (the planar form: two): the weight tiles stream through a three-slot ring,
+//    one tap row per step (counted wait: the tile requested at the top of a step may still be in flight at its barrier), and
+//    the BN + ReLU image is parked and pooled in two halves of 32 channels (32 KiB instead of 64).  The block is a serial
+//    chain -- patch, MFMAs, image, pool, store -- so what hides one block's latencies is the other blocks of its CU.
+__global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p) {
+    constexpr int NK = 7, WRING = 3;
+    constexpr int PROWS = 2 * (ST_RH - 1) + NK, PCH = (2 * (ST_RW - 1) + 8) / 2;  // 39 patch rows of 18 16-byte chunks (36 pixels)
+    constexpr int NCH = PROWS * PCH;                                              // 702 chunks, 11 232 B
+    constexpr int WOFF = ((NCH * 16 + 1023) / 1024) * 1024;                       // weight ring behind the patch
+    constexpr int WT = 64 * ROWB;                                                 // one tap row's weight tile, 8 KiB
+    constexpr int IMG = 256 * 128;                                                // f32 [256 positions][32 channels]
+    constexpr int LDS_BYTES = WOFF + WRING * WT > IMG ? WOFF + WRING * WT : IMG;
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = blk / (ST_TY * ST_TX), t = blk % (ST_TY * ST_TX);
+    const int ty = t / ST_TX, tx = t % ST_TX;
+    const int lrow8 = lane >> 3, slot = lane & 7;
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W), (short)0, 64 * NK * ROWB, 0x00020000);
+    // tap row ky = rows [64][32 K] of p.W at column block ky: 8 DMA pieces of 8 rows, two per wave, swizzled like every tile
+    unsigned w_off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 8 + lrow8;
+        w_off[j] = (unsigned)(row * (NK * ROWB) + ((slot ^ swz_key(row)) << 4));
+    }
+#define AVCER_STEM_W(KY)                                                                                              \
+    do {                                                                                                              \
+        char* dst_ = smem + WOFF + ((KY) % WRING) * WT + wave * 2048;                                                 \
+        dma16(wrs, dst_, w_off[0], (unsigned)((KY) * ROWB));                                                          \
+        dma16(wrs, dst_ + 1024, w_off[1], (unsigned)((KY) * ROWB));                                                   \
+    } while (0)
+    AVCER_STEM_W(0);
+    AVCER_STEM_W(1);
+    // patch chunk ci = patch row ci / 18, pixels 2 (ci % 18), + 1 of the zero-bordered 230 x 230 image: [B G R 0] x 2 as bf16
+    {
+        // every byte load of the thread is issued before the first one is used: the addresses are clamped into the frame
+        // (pixels outside the image and chunks past the patch load a valid byte and are zeroed afterwards), so nothing here
+        // branches around a load and the three passes cost one memory round trip, not six
+        const uint8_t* fr = p.F + (long)b * p.in_h * p.in_w * 3;
+        const bool resize = p.in_h != 224 || p.in_w != 224;
+        constexpr int PASSES = (NCH + 255) / 256;
+        uint8_t raw[PASSES][2][3];
+        bool ok[PASSES][2];
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j) {
+            const int ci = min(j * 256 + tid, NCH - 1);
+            const int prow = ci / PCH, pc = ci - prow * PCH;
+            const int iy = 4 * ST_TH * ty + prow - 2;
+            int sy = min(max(iy, 0), 223);
+            if (resize) sy = min((int)(((double)sy + 0.5) * ((double)p.in_h / 224.0)), p.in_h - 1);  // PIL NEAREST
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                const int ix = 4 * ST_TW * tx + 2 * pc + px - 2;
+                int sx = min(max(ix, 0), 223);
+                if (resize) sx = min((int)(((double)sx + 0.5) * ((double)p.in_w / 224.0)), p.in_w - 1);
+                ok[j][px] = (unsigned)iy < 224u && (unsigned)ix < 224u;
+                const uint8_t* q = fr + ((long)sy * p.in_w + sx) * 3;
+                raw[j][px][0] = q[0]; raw[j][px][1] = q[1]; raw[j][px][2] = q[2];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j) {
+            const int ci = j * 256 + tid;
+            uint32_t wds[4];
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                // [B G R 0]; integers up to 255 need 8 significant bits: the bf16 is exact
+                const uint32_t lo2 = (uint32_t)f2bf((float)raw[j][px][2]) | ((uint32_t)f2bf((float)raw[j][px][1]) << 16);
+                const uint32_t hi2 = (uint32_t)f2bf((float)raw[j][px][0]);
+                wds[2 * px] = ok[j][px] ? lo2 : 0u;
+                wds[2 * px + 1] = ok[j][px] ? hi2 : 0u;
+            }
+            if (ci < NCH) *reinterpret_cast<uint4*>(smem + ci * 16) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+        }
+    }
+    f32x4_t acc[4][4];  // [channel tile][position tile]: wave = 64 positions x 64 channels
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4_t{0};
+    const int g = lane >> 4, l15 = lane & 15;
+    int abase[4];  // byte offset of this lane's fragment in tap row 0 of the patch
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm) {
+        const int row = wave * 64 + fm * 16 + l15;
+        const int ry = row / ST_RW, rx = row - ry * ST_RW;
+        abase[fm] = row < ST_RH * ST_RW ? ((2 * ry) * PCH + rx + g) * 16 : 0;
+    }
+    __syncthreads();  // the patch is written, tap rows 0 and 1 have landed (this one drains everything)
+#pragma unroll
+    for (int ky = 0; ky < NK; ++ky) {
+        // slot (ky + 2) % 3 held tap row ky - 1: every wave left it at the barrier that ended the previous step
+        if (ky + 2 < NK) AVCER_STEM_W(ky + 2);
+        asm volatile("" ::: "memory");
+        const char* sb = smem + WOFF + (ky % WRING) * WT;
+        bf16x8_t ah[4];
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm) ah[fm] = *reinterpret_cast<const bf16x8_t*>(smem + abase[fm] + ky * (PCH * 16));
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+            const bf16x8_t wh = ldfrag(sb, fn * 16 + l15, g), wl = ldfrag(sb, fn * 16 + l15, 4 + g);
+#pragma unroll
+            for (int fm = 0; fm < 4; ++fm) {  // a = ah exactly: a.w = ah.wl + ah.wh (mfma3's order without its al term)
+                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[fm], acc[fn][fm], 0, 0, 0);
+                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[fm], acc[fn][fm], 0, 0, 0);
+            }
+        }
+        pin(acc);
+        // tap row ky + 1 (requested a step ago) must be in; the two pieces just requested may stay in flight
+        if (ky + 2 < NK) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+#undef AVCER_STEM_W
+    // BN + ReLU -> f32 [256 positions][32 channels] image (over the patch and the ring: every wave is past the last barrier),
+    // then the 3x3/2 max-pool (no padding: video.py:103) of those 32 channels; twice
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int fh = 0; fh < 2; ++fh) {
+            const int fn = 2 * half + fh;
+            const int ch = 32 * half + 8 * g + 4 * fh;  // weight rows are stored permuted (split_weight_rows_kernel)
+            const float4 sc = *reinterpret_cast<const float4*>(p.scale + ch);
+#pragma unroll
+            for (int fm = 0; fm < 4; ++fm) {
+                const int row = wave * 64 + fm * 16 + l15;
+                // border class of stem position (cy, cx): taps above / left of the image at 0, below / right of it at 110
+                // (111 is computed but never pooled)
+                const int ry = row / ST_RW, rx = row - ry * ST_RW;
+                const int cy = 2 * ST_TH * ty + ry, cx = 2 * ST_TW * tx + rx;
+                const int cls = 3 * (cy == 0 ? 0 : (cy >= 110 ? 2 : 1)) + (cx == 0 ? 0 : (cx >= 110 ? 2 : 1));
+                const float4 bi = *reinterpret_cast<const float4*>(p.bias9 + cls * 64 + ch);
+                const int chunk = 2 * g + fh;  // 16-byte chunk of the 32-channel row
+                *reinterpret_cast<float4*>(smem + row * 128 + ((chunk ^ (row & 7)) << 4)) =
+                    make_float4(relu_nan(acc[fn][fm][0] * sc.x + bi.x), relu_nan(acc[fn][fm][1] * sc.y + bi.y),
+                                relu_nan(acc[fn][fm][2] * sc.z + bi.z), relu_nan(acc[fn][fm][3] * sc.w + bi.w));
+            }
+        }
+        __syncthreads();
+        {
+            const int pp = tid >> 2, c8 = tid & 3;  // pooled position of the tile, group of 8 channels of this half
+            const int ppy = pp / ST_TW, ppx = pp - ppy * ST_TW;
+            const int py = ST_TH * ty + ppy, px = ST_TW * tx + ppx;
+            if (pp < ST_TH * ST_TW && py < 55 && px < 55) {
+                float m[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = 0.f;  // post-ReLU values are >= 0
+                bool anynan[8] = {false, false, false, false, false, false, false, false};
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int row = (2 * ppy + dy) * ST_RW + 2 * ppx + dx;
+                        const float4 u = *reinterpret_cast<const float4*>(smem + row * 128 + (((2 * c8) ^ (row & 7)) << 4));
+                        const float4 v = *reinterpret_cast<const float4*>(smem + row * 128 + (((2 * c8 + 1) ^ (row & 7)) << 4));
+                        const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { m[j] = fmaxf(m[j], x[j]); anynan[j] |= x[j] != x[j]; }
+                    }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (anynan[j]) m[j] = NAN;  // like torch's max-pool
+                bf16x8_t hi, lo;
+                split8v(m, hi, lo);
+                const long e = (((long)b * 55 + py) * 55 + px) * 64 + 32 * half + c8 * 8;
+                char* yp = p.Y + sp32_byte(e);
+                *reinterpret_cast<bf16x8_t*>(yp) = hi;
+                *reinterpret_cast<bf16x8_t*>(yp + 64) = lo;
+            }
+        }
+        if (half == 0) __syncthreads();  // the pool of the first half has read the image the second half overwrites
     }
 }
 
@@ -892,10 +1019,30 @@ int launch_stem_pool(avcer_ctx* ctx, const void* planes, size_t plane_bytes, con
     p.W = (const char*)w_x3; p.scale = scale; p.bias = bias; p.Y = (char*)y; p.n = n;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     TRY(prof_begin(ctx, st, &ev0, &ev1));
-    stem_pool_kernel<false><<<dim3(n * ST_TY * ST_TX), dim3(256), 0, st>>>(p);
+    stem_pool_kernel<<<dim3(n * ST_TY * ST_TX), dim3(256), 0, st>>>(p);
     if (ev1) (void)hipEventRecord(ev1, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "stem_pool launch: %s", hipGetErrorString(e));
+    ctx->gemm_launches += 1;
+    ctx->gemm_flops += 2.0 * n * 112.0 * 112.0 * 64 * 147;
+    return AVCER_OK;
+}
+
+// The same launch from the u8 frames themselves (stem_pool_u8_kernel): no preprocessing pass, two MFMAs per product.
+int launch_stem_pool_u8(avcer_ctx* ctx, const uint8_t* frames, int in_h, int in_w, const void* w_x3, const float* scale,
+                        const float* bias9, void* y, int n, hipStream_t st) {
+    if (!frames || !w_x3 || !scale || !bias9 || !y || n <= 0 || in_h <= 0 || in_w <= 0)
+        return set_err(ctx, AVCER_EINVAL, "stem_pool_u8: bad arguments");
+    StemParams p;
+    memset(&p, 0, sizeof(p));
+    p.F = frames; p.in_h = in_h; p.in_w = in_w; p.bias9 = bias9;
+    p.W = (const char*)w_x3; p.scale = scale; p.Y = (char*)y; p.n = n;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    TRY(prof_begin(ctx, st, &ev0, &ev1));
+    stem_pool_u8_kernel<<<dim3(n * ST_TY * ST_TX), dim3(256), 0, st>>>(p);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "stem_pool_u8 launch: %s", hipGetErrorString(e));
     ctx->gemm_launches += 1;
     ctx->gemm_flops += 2.0 * n * 112.0 * 112.0 * 64 * 147;
     return AVCER_OK;
@@ -1012,24 +1159,4 @@ int measure_ceilings(avcer_ctx* ctx, double* mfma_bf16_tflops, double* hbm_copy_
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "measure_ceilings: %s", hipGetErrorString(e));
     return AVCER_OK;
-}// The same launch from the u8 frames themselves (stem_pool_kernel<true>): no preprocessing pass, two MFMAs per product.
-int launch_stem_pool_u8(avcer_ctx* ctx, const uint8_t* frames, int in_h, int in_w, const void* w_x3, const float* scale,
-                        const float* bias9, void* y, int n, hipStream_t st) {
-    if (!frames || !w_x3 || !scale || !bias9 || !y || n <= 0 || in_h <= 0 || in_w <= 0)
-        return set_err(ctx, AVCER_EINVAL, "stem_pool_u8: bad arguments");
-    StemParams p;
-    memset(&p, 0, sizeof(p));
-    p.F = frames; p.in_h = in_h; p.in_w = in_w; p.bias9 = bias9;
-    p.W = (const char*)w_x3; p.scale = scale; p.Y = (char*)y; p.n = n;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    TRY(prof_begin(ctx, st, &ev0, &ev1));
-    stem_pool_kernel<true><<<dim3(n * ST_TY * ST_TX), dim3(256), 0, st>>>(p);
-    if (ev1) (void)hipEventRecord(ev1, st);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "stem_pool_u8 launch: %s", hipGetErrorString(e));
-    ctx->gemm_launches += 1;
-    ctx->gemm_flops += 2.0 * n * 112.0 * 112.0 * 64 * 147;
-    return AVCER_OK;
 }
-
-

@@ -21,7 +21,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MFMA_FAMILY = ("conv_gemm", "bneck_kernel", "bneck_tail2_kernel", "stem_pool_kernel")
+MFMA_FAMILY = ("conv_gemm", "bneck_kernel", "bneck_tail2_kernel", "stem_pool")
 
 
 def kernel_source_hash():
@@ -70,7 +70,7 @@ def main():
         commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
     except OSError:
         commit = None
-    res = {"kernel": "MFMA kernels: conv_gemm*, bneck_kernel, bneck_tail2_kernel, stem_pool_kernel (all instantiations)",
+    res = {"kernel": "MFMA kernels: conv_gemm*, bneck_kernel, bneck_tail2_kernel, stem_pool_kernel / stem_pool_u8_kernel (all instantiations)",
            "clips_per_gpu": clips, "commit": commit or None, "kernel_source_hash": kernel_source_hash(),
            "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-secondary --no-cpu --no-configs --no-events --no-overlap",
            "profiled_steps": steps, "hbm_gb_per_step_mfma_kernels": tot / steps / 1e9, "hbm_gb_per_step_all_kernels": everything / steps / 1e9,

@@ -32,7 +32,7 @@ def show(d):
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     names = [r["Kernel_Name"] for r in rows]
     # the last step starts at the last stem launch but one (two front passes per step)
-    starts = [i for i, n in enumerate(names) if "stem_pool_kernel" in n]
+    starts = [i for i, n in enumerate(names) if "stem_pool" in n]
     first = starts[-2]
     t0 = int(rows[first]["Start_Timestamp"])
     total = 0.0
