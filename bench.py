@@ -244,7 +244,7 @@ def gpu_outputs(pipe, frames, wav):
                                               "compound_argmax")}
 
 
-def cpu_baseline(n_clips, gpu_by_mode, n_parity):
+def cpu_baseline(n_clips, gpu_by_mode, n_parity, timed=True):
     """The ONLY leg that touches oracle/: the CPU restatement of the reference (kind = "port") is timed on this box's
     host cores on a bounded sample of the same workload (batched static CNN over a clip's 16 frames, 4 LSTM
     evaluations, one audio window), and its outputs for the first `n_parity` clips check the GPU outputs of every
@@ -282,6 +282,8 @@ def cpu_baseline(n_clips, gpu_by_mode, n_parity):
                         float(np.abs(g["compound_prob"][:, c] - prob).max()))
             same = same and bool(np.array_equal(g["compound_argmax"][:, c], am))
         parity[name] = (worst, same)
+    if not timed:  # N > 1: rank 0 keeps the parity check; the CPU baseline itself is an N = 1 figure
+        return None, parity
     # bounded sample: after the warm-up clips above, best of 3 passes over the same clips, each pass about 5 s of CPU work
     t0 = time.perf_counter()
     clip(0)
@@ -483,7 +485,7 @@ def main():
                 set_mode(name)
                 gpu_by_mode[name] = gpu_outputs(pipe, pf, pw)
         set_mode(args.mode)
-        base, par = cpu_baseline(args.cpu_clips, gpu_by_mode, args.parity_clips) if do_cpu else (None, {})
+        base, par = cpu_baseline(args.cpu_clips, gpu_by_mode, args.parity_clips, timed=world == 1) if do_cpu else (None, {})
         dprob, same = par.get(args.mode, (None, None))
         props = torch.cuda.get_device_properties(device)
         try:
