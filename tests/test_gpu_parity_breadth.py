@@ -17,7 +17,14 @@ Scale 8 is the characterisation of where the x3 mode ENDS, not a parity claim: i
 one block, the stem on exact pixel operands) -- each a new draw of the same rounding noise, +-25 %.  At 8 x the
 generator's logit scale the mode sits AT the gate; include/avcer_hip.h says so and points such heads at the f32 mode (1.5e-5
 here).  The test asserts 1e-4 for f32 at every scale and for x3 at 1 and 4, and bounds x3 at 8 by 2e-4 so that a real
-regression (round 2's split-bf16 fc1 would read 2.0e-4 there) still fails."""
+regression (round 2's split-bf16 fc1 would read 2.0e-4 there) still fails.
+
+Five seeds are a small sample.  tools/x3_margin_sweep.py runs the static CNN over 16 further draws
+(profiles/r03_x3_margin_sweep_16seeds.txt): x3 worst 2.9e-5 at scale 1 (none near the gate), but at scale 4 ONE draw in 16
+reads 1.1e-4 and at scale 8 one reads 1.9e-4 (medians 1e-7 and below: the error only shows on frames whose two leading
+classes are nearly tied).  So the honest domain of the x3 mode is the logit scale the generator produces (rms 1.7-7.9, already
+a confident softmax); the assertions at 4 hold for these five seeds and are kept as a regression tripwire, not as a
+guarantee for every checkpoint -- the header says the same and names the f32 mode for sharper heads."""
 import numpy as np
 import pytest
 import torch

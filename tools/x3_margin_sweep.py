@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""The probability-gate sweep of tests/test_gpu_parity_breadth.py over MORE weight draws than the test takes (default 16
+seeds x logit scales 1 / 4 / 8, static CNN, 8 frames): how far the split-bf16 mode sits from the 1e-4 gate is a statistic,
+and five seeds are a small sample of it.  Prints every case and the worst / median per scale.
+
+    python tools/x3_margin_sweep.py [first_seed] [n_seeds]
+"""
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from avcer_amd import synth  # noqa: E402
+from avcer_amd.engine import MODE_BF16X3, MODE_FP32, Engine  # noqa: E402
+from oracle import video as ov  # noqa: E402
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    eng = Engine(0)
+    frames = synth.face_frames(2468, 8)
+    res = {(m, s): [] for m in ("fp32", "x3") for s in (1.0, 4.0, 8.0)}
+    for seed in range(first, first + n):
+        base = synth.static_state_dict(seed)
+        for scale in (1.0, 4.0, 8.0):
+            sd = dict(base)
+            for k in ("fc2.weight", "fc2.bias"):
+                sd[k] = sd[k] * scale
+            eng.load_static(sd)
+            with torch.no_grad():
+                ref_logits, _ = ov.resnet50_forward(synth.to_torch(sd), ov.pth_processing(frames))
+                ref = torch.softmax(ref_logits, 1).numpy()
+            for name, mode in (("fp32", MODE_FP32), ("x3", MODE_BF16X3)):
+                _, probs, _ = eng.static_forward(torch.from_numpy(frames), mode)
+                d = float(np.abs(probs.cpu().numpy() - ref).max())
+                res[(name, scale)].append(d)
+                print(f"seed {seed} scale {scale:.0f} {name:4s} static max|dprob| {d:.3e}", flush=True)
+    for (name, scale), v in sorted(res.items()):
+        print(f"{name:4s} scale {scale:.0f}: worst {max(v):.3e}  median {statistics.median(v):.3e}  over {len(v)} seeds, "
+              f"{sum(x >= 1e-4 for x in v)} at or above 1e-4")
+
+
+if __name__ == "__main__":
+    main()
