@@ -90,8 +90,24 @@ def test_pack_static_layouts(sd_static):
     # .wf of the chain blocks: stage 1 from block 0 (its conv3 is c3d.w), stage 2 from block 1; stage 3 tails: c3 of blocks
     # 1..4 with c1 of blocks 2..5
     n_chain = (1 + 3 + 3) + (2 + 3 + 3) + 2 * 4
-    assert len(t) == 1 * 3 + 16 * 9 - 4 * 3 + 4 * 2 + 4 + 1 + n_chain
+    assert len(t) == 1 * 3 + 16 * 9 - 4 * 3 + 4 * 2 + 4 + 1 + n_chain + 1   # + stem.b9
     np.testing.assert_array_equal(t["stem7.w"].reshape(64, 7, 8, 4), stem[:, :7])
+    # stem.b9: the shifts of the stem fed with raw pixels (fused.hip stem_pool_u8_kernel), checked where they matter -- a
+    # constant image p makes every valid tap contribute w * (p - mean): conv(p - mean, zero padding) at the four corner / edge /
+    # interior positions of each class must equal conv(p, zero padding) * scale + b9[class]
+    p_img = torch.full((1, 3, 224, 224), 37.0)
+    mu = torch.tensor(packing.PIXEL_MEANS).view(1, 3, 1, 1)
+    wt = torch.from_numpy(w)
+    pad = (2, 3, 2, 3)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad((p_img - mu).double(), pad), wt.double(), stride=2)
+    raw = torch.nn.functional.conv2d(torch.nn.functional.pad(p_img.double(), pad), wt.double(), stride=2)
+    sc, sh = torch.from_numpy(t["stem.s"]).double(), torch.from_numpy(t["stem.b"]).double()
+    b9 = torch.from_numpy(t["stem.b9"]).double()
+    for cy, ry in ((0, 0), (57, 1), (110, 2)):
+        for cx, rx in ((0, 0), (33, 1), (110, 2)):
+            want = ref[0, :, cy, cx] * sc + sh
+            got9 = raw[0, :, cy, cx] * sc + b9[3 * ry + rx]
+            assert (want - got9).abs().max() < 1e-4 * max(1.0, want.abs().max().item()), (cy, cx)
     # chain weights (csrc/fused.hip): the BN scale folded into the rows (the device applies the row permutation)
     np.testing.assert_array_equal(t["l2.2.c3.wf"], t["l2.2.c3.w"] * t["l2.2.c3.s"][:, None])
     assert "l1.0.c1.wf" not in t and "l1.1.c1.wf" in t and "l2.1.c1.wf" not in t and "l2.2.c1.wf" in t and "l3.1.c2.wf" not in t and "l3.1.c3.wf" in t and "l3.5.c1.wf" in t and "l3.5.c3.wf" not in t
