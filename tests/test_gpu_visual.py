@@ -122,8 +122,10 @@ def test_static_resize_path(engine_static, sd_static):
         x = ov.pth_processing(np.stack([ov.nearest_resize_u8(f) for f in odd]))
         lg, _ = ov.resnet50_forward(sd_static, x)
         ref = torch.softmax(lg, 1).numpy()
-    _, probs, _ = engine_static.static_forward(torch.from_numpy(odd), MODE_FP32)
-    assert np.abs(probs.cpu().numpy() - ref).max() < PROB_TOL
+    # the f32 mode resizes in the preprocessing launch, the split-bf16 mode inside the fused stem (fused.hip stem_pool_u8_kernel)
+    for mode in (MODE_FP32, MODE_BF16X3):
+        _, probs, _ = engine_static.static_forward(torch.from_numpy(odd), mode)
+        assert np.abs(probs.cpu().numpy() - ref).max() < PROB_TOL, mode
 
 
 def test_stage3_tail_ragged_rows_match_whole_batch(engine_static):
