@@ -32,6 +32,9 @@ class ConvDesc(C.Structure):
     ]
 
 
+ABI_VERSION = 2          # include/avcer_hip.h AVCER_ABI_VERSION: struct layouts, argument lists and buffer sizes below
+SPLIT_TRAILER = 256      # include/avcer_hip.h AVCER_SPLIT_TRAILER: bytes behind a split weight matrix (its scale)
+
 # name -> (restype, argtypes); exactly the symbols include/avcer_hip.h declares
 SIGNATURES = {
     "avcer_abi_version": (C.c_int, []),
@@ -105,6 +108,9 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if lib.avcer_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB}: ABI version {lib.avcer_abi_version()}, this binding is written for {ABI_VERSION} "
+                               "(include/avcer_hip.h AVCER_ABI_VERSION): rebuild with `python -m avcer_amd.build`")
         _lib = lib
     return _lib
 

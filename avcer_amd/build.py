@@ -8,7 +8,7 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libavcer_hip.so")
 SOURCES = ("gemm.hip", "fused.hip", "kernels.hip", "api.hip")
-HEADERS = ("common.h", "gemm_dev.h", os.path.join("..", "..", "include", "avcer_hip.h"))
+HEADERS = ("common.h", "gemm_dev.h", "split_dev.h", os.path.join("..", "..", "include", "avcer_hip.h"))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

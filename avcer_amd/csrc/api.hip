@@ -1,6 +1,7 @@
 // C ABI of libavcer_hip.so: context, packed-weight loading, and the forward passes of the three AVCER models
 // expressed as sequences of the kernels in gemm.hip / kernels.hip.  See include/avcer_hip.h for the contract.
 #include "common.h"
+#include "split_dev.h"
 
 #include <algorithm>
 #include <cmath>
@@ -142,6 +143,9 @@ int ensure_all_bf16(avcer_ctx* ctx, Model& m, hipStream_t st) {
 
 // split-bf16 copies (k_split_weight_rows: hi/lo per 32-element K group, rows permuted inside every group of 32 output
 // channels) of every GEMM weight whose K is a multiple of 32, made on the first x3 call
+// device bytes of one split copy: the data, its scale trailer (split_dev.h), rounded to 256
+inline size_t split_bytes(size_t numel) { return ((numel * 4 + 255) & ~(size_t)255) + AVCER_SPLIT_TRAILER_BYTES; }
+
 int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
     auto wanted = [](const std::string& k, const Tensor& t) {
         const bool is_w = k.size() > 3 && (k.compare(k.size() - 2, 2, ".w") == 0 || k.compare(k.size() - 3, 3, ".wf") == 0);
@@ -151,7 +155,7 @@ int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
     auto frag_ok = [](const Tensor& t) { return t.dims[0] % 256 == 0 && (t.dims[1] / 32) % 2 == 0; };
     size_t total = 0;
     for (auto& kv : m.t)
-        if (wanted(kv.first, kv.second)) total += ((kv.second.numel * 4 + 255) & ~(size_t)255) * (frag_ok(kv.second) ? 2 : 1);
+        if (wanted(kv.first, kv.second)) total += split_bytes(kv.second.numel) * (frag_ok(kv.second) ? 2 : 1);
     if (!total) return AVCER_OK;
     void* dev = nullptr;
     if (hipMalloc(&dev, total) != hipSuccess) {
@@ -166,11 +170,11 @@ int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
             t.x3 = (bf16_t*)((char*)dev + off);
             // grouped weights ([groups*n][k], pos-conv) are stacked row blocks of multiples of 32 rows: same permutation
             TRY(k_split_weight_rows(ctx, t.f32, t.x3, (int)t.dims[0], (int)t.dims[1], st));
-            off += (t.numel * 4 + 255) & ~(size_t)255;
+            off += split_bytes(t.numel);
             if (frag_ok(t)) {
                 t.x3f = (bf16_t*)((char*)dev + off);
                 TRY(k_weight_frags(ctx, t.x3, t.x3f, (int)t.dims[0], (int)t.dims[1], st));
-                off += (t.numel * 4 + 255) & ~(size_t)255;
+                off += split_bytes(t.numel);
             }
         }
     return AVCER_OK;
@@ -193,7 +197,7 @@ struct Net {
     Model& m;
     int bf16;  // activation / weight type of the MFMA contractions
     hipStream_t st;
-    int x3 = 0;  // f32 activations, split-bf16 MFMA (AVCER_MODE_BF16X3)
+    int x3 = 0;  // f32 activations, split-bf16 MFMA (AVCER_MODE_F16X3)
     int err = AVCER_OK;
 
     const Tensor* T(const std::string& name) {
@@ -303,7 +307,7 @@ constexpr int kStages[4][3] = {{64, 3, 1}, {128, 4, 2}, {256, 6, 2}, {512, 3, 2}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ C ABI: context
-extern "C" int avcer_abi_version(void) { return 1; }
+extern "C" int avcer_abi_version(void) { return AVCER_ABI_VERSION; }
 
 extern "C" int avcer_ctx_create(int device, avcer_ctx** out) {
     if (!out) return AVCER_EINVAL;
@@ -363,13 +367,13 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     if (!ctx) return AVCER_EINVAL;
     if (!ctx->stat.loaded) return set_err(ctx, AVCER_ESTATE, "static weights not loaded");
     if ((!frames && !nchw) || n <= 0 || in_h <= 0 || in_w <= 0) return set_err(ctx, AVCER_EINVAL, "static_forward: bad arguments");
-    if (mode < AVCER_MODE_FP32 || mode > AVCER_MODE_BF16X3) return set_err(ctx, AVCER_EINVAL, "static_forward: mode %d", mode);
+    if (mode < AVCER_MODE_FP32 || mode > AVCER_MODE_F16X3) return set_err(ctx, AVCER_EINVAL, "static_forward: mode %d", mode);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int bf = mode == AVCER_MODE_BF16;
-    const int act = bf ? 1 : (mode == AVCER_MODE_BF16X3 ? 2 : 0);  // activation storage: f32 / bf16 / sp32 pairs
+    const int act = bf ? 1 : (mode == AVCER_MODE_F16X3 ? 2 : 0);  // activation storage: f32 / bf16 / sp32 pairs
     if (bf) TRY(ensure_all_bf16(ctx, ctx->stat, st));
-    if (mode == AVCER_MODE_BF16X3) TRY(ensure_all_x3(ctx, ctx->stat, st));
+    if (mode == AVCER_MODE_F16X3) TRY(ensure_all_x3(ctx, ctx->stat, st));
     const size_t es = bf ? 2 : 4;
     // Two granularities.  The FRONT (stem, stage 1, first block of stage 2: the 55x55 tensors) runs in passes of NB <= 1024
     // frames, the 4 GiB range of a buffer descriptor at 4 bytes per element.  The BACK (rest of stage 2, stages 3-4, tail)
@@ -395,7 +399,7 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     float* feat_ws = (float*)ar.get((size_t)NS * 512 * 4);
     if (!feat_ws) return set_err(ctx, AVCER_ENOMEM, "static workspace arithmetic");
 
-    Net net{ctx, ctx->stat, bf, st, mode == AVCER_MODE_BF16X3};
+    Net net{ctx, ctx->stat, bf, st, mode == AVCER_MODE_F16X3};
     // stem + max-pool of `nb` frames starting at frame f0 of the call: -> B[1] (55x55x64), B[0] is scratch
     auto run_stem = [&](int f0, int nb, void** B) {
         if (net.x3) {
@@ -595,13 +599,13 @@ static int face_forward_impl(avcer_ctx* ctx, const uint8_t* frames, int n, int H
     if (!ctx->face.loaded) return set_err(ctx, AVCER_ESTATE, "face detector weights not loaded");
     if (!frames || !loc || !conf || !landms || n <= 0 || H < 32 || W < 32)
         return set_err(ctx, AVCER_EINVAL, "face_forward: bad arguments (frames of at least 32x32)");
-    if (mode < AVCER_MODE_FP32 || mode > AVCER_MODE_BF16X3) return set_err(ctx, AVCER_EINVAL, "face_forward: mode %d", mode);
+    if (mode < AVCER_MODE_FP32 || mode > AVCER_MODE_F16X3) return set_err(ctx, AVCER_EINVAL, "face_forward: mode %d", mode);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int bf = mode == AVCER_MODE_BF16;
-    const int act = bf ? 1 : (mode == AVCER_MODE_BF16X3 ? 2 : 0);
+    const int act = bf ? 1 : (mode == AVCER_MODE_F16X3 ? 2 : 0);
     if (bf) TRY(ensure_all_bf16(ctx, ctx->face, st));
-    if (mode == AVCER_MODE_BF16X3) TRY(ensure_all_x3(ctx, ctx->face, st));
+    if (mode == AVCER_MODE_F16X3) TRY(ensure_all_x3(ctx, ctx->face, st));
     const size_t es = bf ? 2 : 4;
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;       // conv1 7x7/2, padding 3
     const int PH = 2 * (OH - 1) + 8, PW = 2 * (OW - 1) + 8;      // zero-bordered image the 8x(8x4)-tap stem reads
@@ -638,7 +642,7 @@ static int face_forward_impl(avcer_ctx* ctx, const uint8_t* frames, int n, int H
     float* hd = (float*)ar.get(lvl * 64 * 4);
     if (!hd) return set_err(ctx, AVCER_ENOMEM, "face workspace arithmetic");
 
-    Net net{ctx, ctx->face, bf, st, mode == AVCER_MODE_BF16X3};
+    Net net{ctx, ctx->face, bf, st, mode == AVCER_MODE_F16X3};
     for (int s0 = 0; s0 < n; s0 += NB) {
         const int nb = std::min(NB, n - s0);
         net.chk(k_face_pre(ctx, frames + (size_t)s0 * H * W * 3, nb, H, W, PH, PW, rgb, Pimg, bf, st));
@@ -783,12 +787,12 @@ static int dynamic_forward_impl(avcer_ctx* ctx, const float* windows, int n, int
     if (!ctx) return AVCER_EINVAL;
     if (!ctx->dyn.loaded) return set_err(ctx, AVCER_ESTATE, "dynamic weights not loaded");
     if (!windows || !logits || n <= 0) return set_err(ctx, AVCER_EINVAL, "dynamic_forward: bad arguments");
-    if (mode < AVCER_MODE_FP32 || mode > AVCER_MODE_BF16X3) return set_err(ctx, AVCER_EINVAL, "dynamic_forward: mode %d", mode);
+    if (mode < AVCER_MODE_FP32 || mode > AVCER_MODE_F16X3) return set_err(ctx, AVCER_EINVAL, "dynamic_forward: mode %d", mode);
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    // the recurrence keeps f32 state in every mode; AVCER_MODE_BF16X3 runs its ten dependent GEMMs per layer on the
+    // the recurrence keeps f32 state in every mode; AVCER_MODE_F16X3 runs its ten dependent GEMMs per layer on the
     // split-bf16 MFMA (a 128-row tile of the f32 MFMA costs 5x the cycles, and these launches are pure latency)
-    const int x3 = mode == AVCER_MODE_BF16X3;
+    const int x3 = mode == AVCER_MODE_F16X3;
     if (x3) TRY(ensure_all_x3(ctx, ctx->dyn, st));
     constexpr int T = 10, I = 512, H1 = 512, H2 = 256;
     const size_t total = ((size_t)n * T * 4 * H1 + (size_t)n * 4 * H1 + (size_t)n * T * H1 + (size_t)n * H1 +
@@ -843,7 +847,7 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
     if (!ctx) return AVCER_EINVAL;
     if (!ctx->aud.loaded) return set_err(ctx, AVCER_ESTATE, "audio weights not loaded");
     if (!wav || !logits || n <= 0) return set_err(ctx, AVCER_EINVAL, "audio_forward: bad arguments");
-    if (mode < AVCER_MODE_FP32 || mode > AVCER_MODE_BF16X3) return set_err(ctx, AVCER_EINVAL, "audio_forward: mode %d", mode);
+    if (mode < AVCER_MODE_FP32 || mode > AVCER_MODE_F16X3) return set_err(ctx, AVCER_EINVAL, "audio_forward: mode %d", mode);
     static const int ck[7] = {10, 3, 3, 3, 3, 2, 2}, cs[7] = {5, 2, 2, 2, 2, 2, 2};
     int len[8];
     len[0] = t;
@@ -860,10 +864,10 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int bf = mode == AVCER_MODE_BF16;
-    const int act = bf ? 1 : (mode == AVCER_MODE_BF16X3 ? 2 : 0);  // storage of MFMA operand tensors: f32 / bf16 / sp32
+    const int act = bf ? 1 : (mode == AVCER_MODE_F16X3 ? 2 : 0);  // storage of MFMA operand tensors: f32 / bf16 / sp32
     const int plain = bf ? 1 : 0;                                   // storage of GEMM outputs read by LN / attention
     if (bf) TRY(ensure_all_bf16(ctx, ctx->aud, st));
-    if (mode == AVCER_MODE_BF16X3) TRY(ensure_all_x3(ctx, ctx->aud, st));
+    if (mode == AVCER_MODE_F16X3) TRY(ensure_all_x3(ctx, ctx->aud, st));
     const size_t es = bf ? 2 : 4;
     const int C = 512, E = 1024, FF = 4096;
     const int NB = std::min(n, 128);
@@ -894,7 +898,7 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
     if (!pooled) return set_err(ctx, AVCER_ENOMEM, "audio workspace arithmetic");
     const int ncls = ctx->aud_classes;
 
-    Net net{ctx, ctx->aud, bf, st, mode == AVCER_MODE_BF16X3};
+    Net net{ctx, ctx->aud, bf, st, mode == AVCER_MODE_F16X3};
     // LN whose output is an MFMA operand: f32 in the f32 mode, else a bf16 / sp32 tensor
     // GELU: the library erff in the f32 mode; the short Abramowitz-Stegun erf (gemm_dev.h gelu_fast, same 5e-7 bound as
     // the exact form's own f32 rounding) where the contractions around it are bf16 or split-bf16

@@ -24,7 +24,7 @@ struct DevBuf {
 struct Tensor {
     float* f32 = nullptr;
     bf16_t* bf16 = nullptr;
-    bf16_t* x3 = nullptr;  // split-bf16 (hi/lo per 32-element K group) copy for AVCER_MODE_BF16X3
+    bf16_t* x3 = nullptr;  // split-bf16 (hi/lo per 32-element K group) copy for AVCER_MODE_F16X3
     bf16_t* x3f = nullptr; // the same in MFMA fragment order (conv_gemm dtype 7 / 8), where the shape allows it
     size_t numel = 0;
     int64_t dims[4] = {0, 0, 0, 0};

@@ -21,10 +21,10 @@
 namespace {
 
 // a.w ~= ah.wh + ah.wl + al.wh on the bf16 MFMA with f32 accumulation (same product order as conv_gemm MODE 3)
-__device__ __forceinline__ void mfma3(f32x4_t& acc, const bf16x8_t wh, const bf16x8_t wl, const bf16x8_t ah, const bf16x8_t al) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, acc, 0, 0, 0);
+__device__ __forceinline__ void mfma3(f32x4_t& acc, const spx8_t wh, const spx8_t wl, const spx8_t ah, const spx8_t al) {
+    acc = mfma_sp(wl, ah, acc);
+    acc = mfma_sp(wh, al, acc);
+    acc = mfma_sp(wh, ah, acc);
 }
 
 // Keeps every MFMA that produced these accumulators in front of what follows (a barrier): left alone, hipcc hoists the
@@ -43,17 +43,17 @@ __device__ __forceinline__ void pin(f32x4_t (&acc)[A]) {
     for (int a = 0; a < A; ++a) asm volatile("" : "+v"(acc[a]));
 }
 
-__device__ __forceinline__ bf16x8_t ldfrag(const char* tile, int row, int chunk) {
-    return *reinterpret_cast<const bf16x8_t*>(tile + swz(row, chunk));
+__device__ __forceinline__ spx8_t ldfrag(const char* tile, int row, int chunk) {
+    return *reinterpret_cast<const spx8_t*>(tile + swz(row, chunk));
 }
 
 // 8 f32 values -> bf16 hi / lo fragments (value = hi + lo + O(2^-17))
-__device__ __forceinline__ void split8v(const float (&v)[8], bf16x8_t& hi, bf16x8_t& lo) {
+__device__ __forceinline__ void split8v(const float (&v)[8], spx8_t& hi, spx8_t& lo) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)v[j];
+        const spe_t h = (spe_t)v[j];
         hi[j] = h;
-        lo[j] = (__bf16)(v[j] - (float)h);
+        lo[j] = (spe_t)(v[j] - (float)h);
     }
 }
 
@@ -61,8 +61,8 @@ __device__ __forceinline__ void unpack8(const uint4 h, const uint4 l, float (&r)
     const uint32_t wh[4] = {h.x, h.y, h.z, h.w}, wl[4] = {l.x, l.y, l.z, l.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        r[2 * j] = bf2f((bf16_t)(wh[j] & 0xffff)) + bf2f((bf16_t)(wl[j] & 0xffff));
-        r[2 * j + 1] = bf2f((bf16_t)(wh[j] >> 16)) + bf2f((bf16_t)(wl[j] >> 16));
+        r[2 * j] = sp2f((uint16_t)(wh[j] & 0xffff)) + sp2f((uint16_t)(wl[j] & 0xffff));
+        r[2 * j + 1] = sp2f((uint16_t)(wh[j] >> 16)) + sp2f((uint16_t)(wl[j] >> 16));
     }
 }
 
@@ -127,6 +127,7 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
     const int b = blk / (ST_TY * ST_TX), t = blk % (ST_TY * ST_TX);
     const int ty = t / ST_TX, tx = t % ST_TX;
 
+    const float wmul = split_wmul(p.W, 64 * NK * ROWB);
     const auto prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.P), (short)0, (int)p.p_bytes, 0x00020000);
     const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W), (short)0, 64 * NK * ROWB, 0x00020000);
     // patch: chunk c of the LDS image = chunk (c % 702) of plane c / 702; one DMA instruction copies 64 consecutive chunks
@@ -168,15 +169,15 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
 #pragma unroll
     for (int ky = 0; ky < NK; ++ky) {
         const char* sb = smem + WOFF + ky * WT;
-        bf16x8_t ah[4], al[4];
+        spx8_t ah[4], al[4];
 #pragma unroll
         for (int fm = 0; fm < 4; ++fm) {
-            ah[fm] = *reinterpret_cast<const bf16x8_t*>(smem + abase[fm] + ky * (PCH * 16));
-            al[fm] = *reinterpret_cast<const bf16x8_t*>(smem + PLANE + abase[fm] + ky * (PCH * 16));
+            ah[fm] = *reinterpret_cast<const spx8_t*>(smem + abase[fm] + ky * (PCH * 16));
+            al[fm] = *reinterpret_cast<const spx8_t*>(smem + PLANE + abase[fm] + ky * (PCH * 16));
         }
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) {
-            const bf16x8_t wh = ldfrag(sb, fn * 16 + l15, g), wl = ldfrag(sb, fn * 16 + l15, 4 + g);
+            const spx8_t wh = ldfrag(sb, fn * 16 + l15, g), wl = ldfrag(sb, fn * 16 + l15, 4 + g);
 #pragma unroll
             for (int fm = 0; fm < 4; ++fm) mfma3(acc[fn][fm], wh, wl, ah[fm], al[fm]);
         }
@@ -187,7 +188,9 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
 #pragma unroll
     for (int fn = 0; fn < 4; ++fn) {
         const int ch = 32 * (fn >> 1) + 8 * g + 4 * (fn & 1);  // weight rows are stored permuted (split_weight_rows_kernel)
-        const float4 sc = *reinterpret_cast<const float4*>(p.scale + ch), bi = *reinterpret_cast<const float4*>(p.bias + ch);
+        float4 sc = *reinterpret_cast<const float4*>(p.scale + ch);
+        const float4 bi = *reinterpret_cast<const float4*>(p.bias + ch);
+        sc = make_float4(sc.x * wmul, sc.y * wmul, sc.z * wmul, sc.w * wmul);  // undoes the power of two of the weight split
 #pragma unroll
         for (int fm = 0; fm < 4; ++fm) {
             const int row = wave * 64 + fm * 16 + l15;
@@ -224,12 +227,12 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
         (void)nan;
 #pragma unroll
         for (int j = 0; j < 8; ++j) if (anynan[j]) m[j] = NAN;  // like torch's max-pool
-        bf16x8_t hi, lo;
+        spx8_t hi, lo;
         split8v(m, hi, lo);
         const long e = (((long)b * 55 + py) * 55 + px) * 64 + c8 * 8;
         char* yp = p.Y + sp32_byte(e);
-        *reinterpret_cast<bf16x8_t*>(yp) = hi;
-        *reinterpret_cast<bf16x8_t*>(yp + 64) = lo;
+        *reinterpret_cast<spx8_t*>(yp) = hi;
+        *reinterpret_cast<spx8_t*>(yp + 64) = lo;
     }
 }
 
@@ -260,6 +263,7 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
     const int b = blk / (ST_TY * ST_TX), t = blk % (ST_TY * ST_TX);
     const int ty = t / ST_TX, tx = t % ST_TX;
     const int lrow8 = lane >> 3, slot = lane & 7;
+    const float wmul = split_wmul(p.W, 64 * NK * ROWB);
     const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W), (short)0, 64 * NK * ROWB, 0x00020000);
     // tap row ky = rows [64][32 K] of p.W at column block ky: 8 DMA pieces of 8 rows, two per wave, swizzled like every tile
     unsigned w_off[2];
@@ -310,8 +314,8 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
 #pragma unroll
             for (int px = 0; px < 2; ++px) {
                 // [B G R 0]; integers up to 255 need 8 significant bits: the bf16 is exact
-                const uint32_t lo2 = (uint32_t)f2bf((float)raw[j][px][2]) | ((uint32_t)f2bf((float)raw[j][px][1]) << 16);
-                const uint32_t hi2 = (uint32_t)f2bf((float)raw[j][px][0]);
+                const uint32_t lo2 = (uint32_t)f2sp((float)raw[j][px][2]) | ((uint32_t)f2sp((float)raw[j][px][1]) << 16);
+                const uint32_t hi2 = (uint32_t)f2sp((float)raw[j][px][0]);
                 wds[2 * px] = ok[j][px] ? lo2 : 0u;
                 wds[2 * px + 1] = ok[j][px] ? hi2 : 0u;
             }
@@ -338,16 +342,16 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
         if (ky + 2 < NK) AVCER_STEM_W(ky + 2);
         asm volatile("" ::: "memory");
         const char* sb = smem + WOFF + (ky % WRING) * WT;
-        bf16x8_t ah[4];
+        spx8_t ah[4];
 #pragma unroll
-        for (int fm = 0; fm < 4; ++fm) ah[fm] = *reinterpret_cast<const bf16x8_t*>(smem + abase[fm] + ky * (PCH * 16));
+        for (int fm = 0; fm < 4; ++fm) ah[fm] = *reinterpret_cast<const spx8_t*>(smem + abase[fm] + ky * (PCH * 16));
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) {
-            const bf16x8_t wh = ldfrag(sb, fn * 16 + l15, g), wl = ldfrag(sb, fn * 16 + l15, 4 + g);
+            const spx8_t wh = ldfrag(sb, fn * 16 + l15, g), wl = ldfrag(sb, fn * 16 + l15, 4 + g);
 #pragma unroll
             for (int fm = 0; fm < 4; ++fm) {  // a = ah exactly: a.w = ah.wl + ah.wh (mfma3's order without its al term)
-                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah[fm], acc[fn][fm], 0, 0, 0);
-                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah[fm], acc[fn][fm], 0, 0, 0);
+                acc[fn][fm] = mfma_sp(wl, ah[fm], acc[fn][fm]);
+                acc[fn][fm] = mfma_sp(wh, ah[fm], acc[fn][fm]);
             }
         }
         pin(acc);
@@ -367,7 +371,8 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
         for (int fh = 0; fh < 2; ++fh) {
             const int fn = 2 * half + fh;
             const int ch = 32 * half + 8 * g + 4 * fh;  // weight rows are stored permuted (split_weight_rows_kernel)
-            const float4 sc = *reinterpret_cast<const float4*>(p.scale + ch);
+            float4 sc = *reinterpret_cast<const float4*>(p.scale + ch);
+            sc = make_float4(sc.x * wmul, sc.y * wmul, sc.z * wmul, sc.w * wmul);  // undoes the power of two of the weight split
 #pragma unroll
             for (int fm = 0; fm < 4; ++fm) {
                 const int row = wave * 64 + fm * 16 + l15;
@@ -406,12 +411,12 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
                     }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) if (anynan[j]) m[j] = NAN;  // like torch's max-pool
-                bf16x8_t hi, lo;
+                spx8_t hi, lo;
                 split8v(m, hi, lo);
                 const long e = (((long)b * 55 + py) * 55 + px) * 64 + 32 * half + c8 * 8;
                 char* yp = p.Y + sp32_byte(e);
-                *reinterpret_cast<bf16x8_t*>(yp) = hi;
-                *reinterpret_cast<bf16x8_t*>(yp + 64) = lo;
+                *reinterpret_cast<spx8_t*>(yp) = hi;
+                *reinterpret_cast<spx8_t*>(yp + 64) = lo;
             }
         }
         if (half == 0) __syncthreads();  // the pool of the first half has read the image the second half overwrites
@@ -477,6 +482,10 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
     const int lrow8 = lane >> 3, slot = lane & 7;
     const int m_base = xcd_remap(blockIdx.x, gridDim.x) * BM;
 
+    // accumulator multipliers of the three scaled weight splits (trailers behind the matrices: split_dev.h)
+    const float s2 = split_wmul(p.W2, P * 9 * P * 4), s3 = split_wmul(p.W3, 4 * P * (P + 32 * NQX) * 4);
+    const float s1n = NEXT ? split_wmul(p.W1N, 4 * P * P * 4) : 1.f;
+    (void)s1n;
     const auto t1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.T1), (short)0, (int)p.t1_bytes, 0x00020000);
     const auto w2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W2), (short)0, P * 9 * P * 4, 0x00020000);
     const auto w3rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W3), (short)0, 4 * P * (P + 32 * NQX) * 4, 0x00020000);
@@ -545,7 +554,7 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
                 }
                 const int toff = (tap / 3 - 1) * PW + (tap % 3 - 1);
                 const char* sbw = wt0 + cur * (P * ROWB);
-                bf16x8_t ah[NT], al[NT];
+                spx8_t ah[NT], al[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     ah[t] = ldfrag(patch, sb[t] + toff, g);
@@ -553,7 +562,7 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
                 }
 #pragma unroll
                 for (int i = 0; i < P / 16; ++i) {
-                    const bf16x8_t wh = ldfrag(sbw, i * 16 + l15, g), wl = ldfrag(sbw, i * 16 + l15, 4 + g);
+                    const spx8_t wh = ldfrag(sbw, i * 16 + l15, g), wl = ldfrag(sbw, i * 16 + l15, 4 + g);
 #pragma unroll
                     for (int t = 0; t < NT; ++t) mfma3(acc2[i][t], wh, wl, ah[t], al[t]);
                 }
@@ -613,7 +622,7 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
             if (step + 1 < NK) issue(cur ^ 1);
             const char* sa = smem + cur * TILE_A;
             const char* sb = sa + BM * ROWB;
-            bf16x8_t ah[NT], al[NT];
+            spx8_t ah[NT], al[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int row = wave * (BM / 4) + t * 16 + l15;
@@ -622,7 +631,7 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
             }
 #pragma unroll
             for (int i = 0; i < P / 16; ++i) {
-                const bf16x8_t wh = ldfrag(sb, i * 16 + l15, g), wl = ldfrag(sb, i * 16 + l15, 4 + g);
+                const spx8_t wh = ldfrag(sb, i * 16 + l15, g), wl = ldfrag(sb, i * 16 + l15, 4 + g);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) mfma3(acc2[i][t], wh, wl, ah[t], al[t]);
             }
@@ -679,15 +688,15 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
         }
     }
     // downsample operand: the NQX K-steps of this lane's positions as B fragments, straight from global memory
-    bf16x8_t xh[NQX > 0 ? NQX : 1][NT], xl[NQX > 0 ? NQX : 1][NT];
+    spx8_t xh[NQX > 0 ? NQX : 1][NT], xl[NQX > 0 ? NQX : 1][NT];
     if constexpr (NQX > 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const char* xp = p.X + m_row[t] * (NQX * 128L) + 16 * g;
 #pragma unroll
             for (int q = 0; q < NQX; ++q) {
-                xh[q][t] = *reinterpret_cast<const bf16x8_t*>(xp + q * 128);
-                xl[q][t] = *reinterpret_cast<const bf16x8_t*>(xp + q * 128 + 64);
+                xh[q][t] = *reinterpret_cast<const spx8_t*>(xp + q * 128);
+                xl[q][t] = *reinterpret_cast<const spx8_t*>(xp + q * 128 + 64);
             }
         }
     }
@@ -710,15 +719,17 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
     load_res(1, rh[1], rl[1]);
 
     // T2 as B-operand fragments: K-step q = channels 32q..32q+31, lane group g holds 8g..8g+7 (weight rows were permuted)
-    bf16x8_t t2h[NQ][NT], t2l[NQ][NT];
+    spx8_t t2h[NQ][NT], t2l[NQ][NT];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const float4 b0 = *reinterpret_cast<const float4*>(sbias + 32 * q + 8 * g), b1 = *reinterpret_cast<const float4*>(sbias + 32 * q + 8 * g + 4);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const f32x4_t lo4 = acc2[2 * q][t], hi4 = acc2[2 * q + 1][t];
-            const float v[8] = {relu_nan(lo4[0] + b0.x), relu_nan(lo4[1] + b0.y), relu_nan(lo4[2] + b0.z), relu_nan(lo4[3] + b0.w),
-                                relu_nan(hi4[0] + b1.x), relu_nan(hi4[1] + b1.y), relu_nan(hi4[2] + b1.z), relu_nan(hi4[3] + b1.w)};
+            const float v[8] = {relu_nan(__builtin_fmaf(lo4[0], s2, b0.x)), relu_nan(__builtin_fmaf(lo4[1], s2, b0.y)),
+                                relu_nan(__builtin_fmaf(lo4[2], s2, b0.z)), relu_nan(__builtin_fmaf(lo4[3], s2, b0.w)),
+                                relu_nan(__builtin_fmaf(hi4[0], s2, b1.x)), relu_nan(__builtin_fmaf(hi4[1], s2, b1.y)),
+                                relu_nan(__builtin_fmaf(hi4[2], s2, b1.z)), relu_nan(__builtin_fmaf(hi4[3], s2, b1.w))};
             split8v(v, t2h[q][t], t2l[q][t]);
         }
     }
@@ -743,7 +754,7 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int tp = 0; tp < 2; ++tp) {
-                const bf16x8_t wh = ldfrag(w3t + q * (32 * ROWB), tp * 16 + l15, g), wl = ldfrag(w3t + q * (32 * ROWB), tp * 16 + l15, 4 + g);
+                const spx8_t wh = ldfrag(w3t + q * (32 * ROWB), tp * 16 + l15, g), wl = ldfrag(w3t + q * (32 * ROWB), tp * 16 + l15, 4 + g);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) mfma3(acc3[tp][t], wh, wl, t2h[q][t], t2l[q][t]);
             }
@@ -753,34 +764,35 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
 #pragma unroll
                 for (int tp = 0; tp < 2; ++tp) {
                     const char* wt = w3t + (NQ + q) * (32 * ROWB);
-                    const bf16x8_t wh = ldfrag(wt, tp * 16 + l15, g), wl = ldfrag(wt, tp * 16 + l15, 4 + g);
+                    const spx8_t wh = ldfrag(wt, tp * 16 + l15, g), wl = ldfrag(wt, tp * 16 + l15, 4 + g);
 #pragma unroll
                     for (int t = 0; t < NT; ++t) mfma3(acc3[tp][t], wh, wl, xh[q][t], xl[q][t]);
                 }
         }
         const float* bp = sbias + 2 * P + 32 * G + 8 * g;
         const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
-        bf16x8_t oh[NT], ol[NT];
+        spx8_t oh[NT], ol[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float r[8];
             unpack8(h[t], l[t], r);
             const f32x4_t lo4 = acc3[0][t], hi4 = acc3[1][t];
-            const float v[8] = {relu_nan(lo4[0] + b0.x + r[0]), relu_nan(lo4[1] + b0.y + r[1]), relu_nan(lo4[2] + b0.z + r[2]),
-                                relu_nan(lo4[3] + b0.w + r[3]), relu_nan(hi4[0] + b1.x + r[4]), relu_nan(hi4[1] + b1.y + r[5]),
-                                relu_nan(hi4[2] + b1.z + r[6]), relu_nan(hi4[3] + b1.w + r[7])};
+            const float v[8] = {relu_nan(__builtin_fmaf(lo4[0], s3, b0.x) + r[0]), relu_nan(__builtin_fmaf(lo4[1], s3, b0.y) + r[1]),
+                                relu_nan(__builtin_fmaf(lo4[2], s3, b0.z) + r[2]), relu_nan(__builtin_fmaf(lo4[3], s3, b0.w) + r[3]),
+                                relu_nan(__builtin_fmaf(hi4[0], s3, b1.x) + r[4]), relu_nan(__builtin_fmaf(hi4[1], s3, b1.y) + r[5]),
+                                relu_nan(__builtin_fmaf(hi4[2], s3, b1.z) + r[6]), relu_nan(__builtin_fmaf(hi4[3], s3, b1.w) + r[7])};
             split8v(v, oh[t], ol[t]);
             if (m_ok[t]) {
                 char* yp = p.OUT + (SUB == 1 ? x_row[t] : o_row[SUB > 1 ? t : 0]) + G * 128;
-                *reinterpret_cast<bf16x8_t*>(yp) = oh[t];
-                *reinterpret_cast<bf16x8_t*>(yp + 64) = ol[t];
+                *reinterpret_cast<spx8_t*>(yp) = oh[t];
+                *reinterpret_cast<spx8_t*>(yp + 64) = ol[t];
             }
         }
         if (G + 2 < NG) load_res(G + 2, h, l);  // the slot just consumed
         if constexpr (NEXT) {
 #pragma unroll
             for (int i = 0; i < P / 16; ++i) {
-                const bf16x8_t wh = ldfrag(w1t, i * 16 + l15, g), wl = ldfrag(w1t, i * 16 + l15, 4 + g);
+                const spx8_t wh = ldfrag(w1t, i * 16 + l15, g), wl = ldfrag(w1t, i * 16 + l15, 4 + g);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) mfma3(acc1[i][t], wh, wl, oh[t], ol[t]);
             }
@@ -801,15 +813,17 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const f32x4_t lo4 = acc1[2 * q][t], hi4 = acc1[2 * q + 1][t];
-                const float v[8] = {relu_nan(lo4[0] + b0.x), relu_nan(lo4[1] + b0.y), relu_nan(lo4[2] + b0.z), relu_nan(lo4[3] + b0.w),
-                                    relu_nan(hi4[0] + b1.x), relu_nan(hi4[1] + b1.y), relu_nan(hi4[2] + b1.z), relu_nan(hi4[3] + b1.w)};
-                bf16x8_t hi, lo;
+                const float v[8] = {relu_nan(__builtin_fmaf(lo4[0], s1n, b0.x)), relu_nan(__builtin_fmaf(lo4[1], s1n, b0.y)),
+                                    relu_nan(__builtin_fmaf(lo4[2], s1n, b0.z)), relu_nan(__builtin_fmaf(lo4[3], s1n, b0.w)),
+                                    relu_nan(__builtin_fmaf(hi4[0], s1n, b1.x)), relu_nan(__builtin_fmaf(hi4[1], s1n, b1.y)),
+                                    relu_nan(__builtin_fmaf(hi4[2], s1n, b1.z)), relu_nan(__builtin_fmaf(hi4[3], s1n, b1.w))};
+                spx8_t hi, lo;
                 split8v(v, hi, lo);
                 if (m_ok[t]) {
                     const long m = (long)m_base + wave * (BM / 4) + t * 16 + l15;
                     char* yp = p.T1N + m * (P * 4) + q * 128 + 16 * g;
-                    *reinterpret_cast<bf16x8_t*>(yp) = hi;
-                    *reinterpret_cast<bf16x8_t*>(yp + 64) = lo;
+                    *reinterpret_cast<spx8_t*>(yp) = hi;
+                    *reinterpret_cast<spx8_t*>(yp + 64) = lo;
                 }
             }
         }
@@ -847,6 +861,7 @@ __global__ void __launch_bounds__(512, 2) bneck_tail2_kernel(const BneckParams p
     const int g = lane >> 4, l15 = lane & 15;
     const int lrow8 = lane >> 3, slot = lane & 7;
     const int m_base = xcd_remap(blockIdx.x, gridDim.x) * BM;
+    const float s3 = split_wmul(p.W3, 4 * P * P * 4), s1n = split_wmul(p.W1N, 4 * P * P * 4);  // split_dev.h: weight trailers
     const auto w3rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W3), (short)0, 4 * P * P * 4, 0x00020000);
     const auto w1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W1N), (short)0, 4 * P * P * 4, 0x00020000);
     const auto outrs = __builtin_amdgcn_make_buffer_rsrc(p.OUT, (short)0, (int)p.t1_bytes, 0x00020000);  // t1_bytes: bytes of OUT here
@@ -880,13 +895,13 @@ __global__ void __launch_bounds__(512, 2) bneck_tail2_kernel(const BneckParams p
     const long mc = m_ok ? m : 0;
     const long x_row = mc * (4L * P * 4) + 16 * g;
     const unsigned o_row = m_ok ? (unsigned)x_row : OOB;  // rows past M: the buffer store is dropped
-    bf16x8_t t2h[NQ], t2l[NQ];
+    spx8_t t2h[NQ], t2l[NQ];
     {
         const char* tp = p.T1 + mc * (P * 4L) + 16 * g;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            t2h[q] = *reinterpret_cast<const bf16x8_t*>(tp + q * 128);
-            t2l[q] = *reinterpret_cast<const bf16x8_t*>(tp + q * 128 + 64);
+            t2h[q] = *reinterpret_cast<const spx8_t*>(tp + q * 128);
+            t2l[q] = *reinterpret_cast<const spx8_t*>(tp + q * 128 + 64);
         }
     }
     // Residual ring, two groups deep.  The loads are inline asm so that hipcc does not wait for them itself (inside the loop
@@ -926,11 +941,11 @@ __global__ void __launch_bounds__(512, 2) bneck_tail2_kernel(const BneckParams p
         lds_read8(sbias + P + 32 * (G) + 8 * g, b0, b1);                                                                       \
         float r[8];                                                                                                            \
         unpack8(__builtin_bit_cast(uint4, H), __builtin_bit_cast(uint4, L), r);                                                \
-        const float v[8] = {relu_nan(acc3[0][0] + b0[0] + r[0]), relu_nan(acc3[0][1] + b0[1] + r[1]),                          \
-                            relu_nan(acc3[0][2] + b0[2] + r[2]), relu_nan(acc3[0][3] + b0[3] + r[3]),                          \
-                            relu_nan(acc3[1][0] + b1[0] + r[4]), relu_nan(acc3[1][1] + b1[1] + r[5]),                          \
-                            relu_nan(acc3[1][2] + b1[2] + r[6]), relu_nan(acc3[1][3] + b1[3] + r[7])};                         \
-        bf16x8_t oh, ol;                                                                                                       \
+        const float v[8] = {relu_nan(__builtin_fmaf(acc3[0][0], s3, b0[0]) + r[0]), relu_nan(__builtin_fmaf(acc3[0][1], s3, b0[1]) + r[1]), \
+                            relu_nan(__builtin_fmaf(acc3[0][2], s3, b0[2]) + r[2]), relu_nan(__builtin_fmaf(acc3[0][3], s3, b0[3]) + r[3]), \
+                            relu_nan(__builtin_fmaf(acc3[1][0], s3, b1[0]) + r[4]), relu_nan(__builtin_fmaf(acc3[1][1], s3, b1[1]) + r[5]), \
+                            relu_nan(__builtin_fmaf(acc3[1][2], s3, b1[2]) + r[6]), relu_nan(__builtin_fmaf(acc3[1][3], s3, b1[3]) + r[7])}; \
+        spx8_t oh, ol;                                                                                                       \
         split8v(v, oh, ol);                                                                                                    \
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, oh), outrs, o_row, (G) * 128, 0);                   \
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ol), outrs, o_row, (G) * 128 + 64, 0);              \
@@ -962,14 +977,16 @@ __global__ void __launch_bounds__(512, 2) bneck_tail2_kernel(const BneckParams p
     for (int q = 0; q < NQ; ++q) {
         const float4 b0 = *reinterpret_cast<const float4*>(sbias + 32 * q + 8 * g), b1 = *reinterpret_cast<const float4*>(sbias + 32 * q + 8 * g + 4);
         const f32x4_t lo4 = acc1[2 * q], hi4 = acc1[2 * q + 1];
-        const float v[8] = {relu_nan(lo4[0] + b0.x), relu_nan(lo4[1] + b0.y), relu_nan(lo4[2] + b0.z), relu_nan(lo4[3] + b0.w),
-                            relu_nan(hi4[0] + b1.x), relu_nan(hi4[1] + b1.y), relu_nan(hi4[2] + b1.z), relu_nan(hi4[3] + b1.w)};
-        bf16x8_t hi, lo;
+        const float v[8] = {relu_nan(__builtin_fmaf(lo4[0], s1n, b0.x)), relu_nan(__builtin_fmaf(lo4[1], s1n, b0.y)),
+                            relu_nan(__builtin_fmaf(lo4[2], s1n, b0.z)), relu_nan(__builtin_fmaf(lo4[3], s1n, b0.w)),
+                            relu_nan(__builtin_fmaf(hi4[0], s1n, b1.x)), relu_nan(__builtin_fmaf(hi4[1], s1n, b1.y)),
+                            relu_nan(__builtin_fmaf(hi4[2], s1n, b1.z)), relu_nan(__builtin_fmaf(hi4[3], s1n, b1.w))};
+        spx8_t hi, lo;
         split8v(v, hi, lo);
         if (m_ok) {
             char* yp = p.T1N + m * (P * 4L) + q * 128 + 16 * g;
-            *reinterpret_cast<bf16x8_t*>(yp) = hi;
-            *reinterpret_cast<bf16x8_t*>(yp + 64) = lo;
+            *reinterpret_cast<spx8_t*>(yp) = hi;
+            *reinterpret_cast<spx8_t*>(yp + 64) = lo;
         }
     }
 }
@@ -980,18 +997,18 @@ __global__ void __launch_bounds__(512, 2) bneck_tail2_kernel(const BneckParams p
 // non-trivial operand bits), and a 16-byte-per-lane streaming copy.
 __global__ void __launch_bounds__(256, 2) mfma_rate_kernel(float* sink, int iters) {
     const int lane = threadIdx.x & 63;
-    bf16x8_t a, b;
+    spx8_t a, b;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        a[j] = (__bf16)(0.25f + 0.001f * (float)((lane * 8 + j) % 97));
-        b[j] = (__bf16)(-0.5f + 0.002f * (float)((lane * 5 + j * 3 + blockIdx.x) % 89));
+        a[j] = (spe_t)(0.25f + 0.001f * (float)((lane * 8 + j) % 97));
+        b[j] = (spe_t)(-0.5f + 0.002f * (float)((lane * 5 + j * 3 + blockIdx.x) % 89));
     }
     f32x4_t acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = f32x4_t{0};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < 16; ++i) acc[i] = mfma_sp(a, b, acc[i]);
     }
     float s = 0.f;
 #pragma unroll

@@ -121,8 +121,8 @@ __device__ __forceinline__ void finish8(const GemmParams& p, long m, int n0, con
         const uint32_t wh[4] = {r0.x, r0.y, r0.z, r0.w}, wl[4] = {r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            r[2 * j] = bf2f((bf16_t)(wh[j] & 0xffff)) + bf2f((bf16_t)(wl[j] & 0xffff));
-            r[2 * j + 1] = bf2f((bf16_t)(wh[j] >> 16)) + bf2f((bf16_t)(wl[j] >> 16));
+            r[2 * j] = sp2f((uint16_t)(wh[j] & 0xffff)) + sp2f((uint16_t)(wl[j] & 0xffff));
+            r[2 * j + 1] = sp2f((uint16_t)(wh[j] >> 16)) + sp2f((uint16_t)(wl[j] >> 16));
         }
     }
 #pragma unroll
@@ -149,9 +149,9 @@ __device__ __forceinline__ void finish8(const GemmParams& p, long m, int n0, con
         uint32_t h[4], l[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bf16_t h0 = f2bf(v[2 * j]), h1 = f2bf(v[2 * j + 1]);
+            const uint16_t h0 = f2sp(v[2 * j]), h1 = f2sp(v[2 * j + 1]);
             h[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-            l[j] = (uint32_t)f2bf(v[2 * j] - bf2f(h0)) | ((uint32_t)f2bf(v[2 * j + 1] - bf2f(h1)) << 16);
+            l[j] = (uint32_t)f2sp(v[2 * j] - sp2f(h0)) | ((uint32_t)f2sp(v[2 * j + 1] - sp2f(h1)) << 16);
         }
         char* yp = p.Y + sp32_byte(e);
         *reinterpret_cast<uint4*>(yp) = make_uint4(h[0], h[1], h[2], h[3]);
@@ -265,13 +265,16 @@ __device__ __forceinline__ float4 scale_bias4(const f32x4_t a, const float4 s, c
 
 template <int OUT, int ACT, int NFN, int NFM>
 __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4_t (&acc)[NFN][NFM], int m0, int c0, int lane,
-                                                const uint4 (&rr)[NFN / 2][NFM][2]) {
+                                                const uint4 (&rr)[NFN / 2][NFM][2], const float wmul) {
 #pragma unroll
     for (int j = 0; j < NFN / 2; ++j) {
         const int ch = c0 + 32 * j + 8 * (lane >> 4);  // first of this lane's 8 channels (index into scale / bias too)
         float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
         if (p.scale) { s0 = *reinterpret_cast<const float4*>(p.scale + ch); s1 = *reinterpret_cast<const float4*>(p.scale + ch + 4); }
         if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + ch); b1 = *reinterpret_cast<const float4*>(p.bias + ch + 4); }
+        // the weights were split as w * 2^e (split_dev.h): wmul = 2^-e folds back into the channel scale, exactly
+        s0 = make_float4(s0.x * wmul, s0.y * wmul, s0.z * wmul, s0.w * wmul);
+        s1 = make_float4(s1.x * wmul, s1.y * wmul, s1.z * wmul, s1.w * wmul);
 #pragma unroll
         for (int fm = 0; fm < NFM; ++fm) {
             const long m = (long)m0 + fm * 16 + (lane & 15);
@@ -283,14 +286,14 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4_t (&a
     }
 }
 
-// bf16 <-> f32 split used by MODE 2: x = hi + lo + O(2^-17 |x|) with hi, lo bf16 (round to nearest even)
-__device__ __forceinline__ void split8(const float4 x, const float4 y, bf16x8_t& hi, bf16x8_t& lo) {
+// f32 -> split pair used by MODE 2: x = hi + lo + O(2^-22 |x|) with hi, lo fp16 (round to nearest even; split_dev.h)
+__device__ __forceinline__ void split8(const float4 x, const float4 y, spx8_t& hi, spx8_t& lo) {
     const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)v[j];
+        const spe_t h = (spe_t)v[j];
         hi[j] = h;
-        lo[j] = (__bf16)(v[j] - (float)h);
+        lo[j] = (spe_t)(v[j] - (float)h);
     }
 }
 
@@ -331,13 +334,13 @@ __device__ __forceinline__ void mfma_step(const GemmParams& p, const char* smem,
         }
     } else if constexpr (MODE == 2 || MODE == 3) {
         const int g = lane >> 4;
-        bf16x8_t ahi[NFM], alo[NFM];
+        spx8_t ahi[NFM], alo[NFM];
 #pragma unroll
         for (int fm = 0; fm < NFM; ++fm) {
             const int row = wm * WM + fm * 16 + (lane & 15);
             if constexpr (MODE == 3) {
-                ahi[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, g));
-                alo[fm] = *reinterpret_cast<const bf16x8_t*>(sa + swz(row, 4 + g));
+                ahi[fm] = *reinterpret_cast<const spx8_t*>(sa + swz(row, g));
+                alo[fm] = *reinterpret_cast<const spx8_t*>(sa + swz(row, 4 + g));
                 continue;
             }
             const float4 x = *reinterpret_cast<const float4*>(sa + swz(row, 2 * g));
@@ -347,13 +350,13 @@ __device__ __forceinline__ void mfma_step(const GemmParams& p, const char* smem,
 #pragma unroll
         for (int fn = 0; fn < NFN; ++fn) {
             const int row = wn * WN + fn * 16 + (lane & 15);
-            const bf16x8_t whi = *reinterpret_cast<const bf16x8_t*>(sb + swz(row, g));
-            const bf16x8_t wlo = *reinterpret_cast<const bf16x8_t*>(sb + swz(row, 4 + g));
+            const spx8_t whi = *reinterpret_cast<const spx8_t*>(sb + swz(row, g));
+            const spx8_t wlo = *reinterpret_cast<const spx8_t*>(sb + swz(row, 4 + g));
 #pragma unroll
             for (int fm = 0; fm < NFM; ++fm) {
-                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, ahi[fm], acc[fn][fm], 0, 0, 0);
-                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, alo[fm], acc[fn][fm], 0, 0, 0);
-                acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, ahi[fm], acc[fn][fm], 0, 0, 0);
+                acc[fn][fm] = mfma_sp(wlo, ahi[fm], acc[fn][fm]);
+                acc[fn][fm] = mfma_sp(whi, alo[fm], acc[fn][fm]);
+                acc[fn][fm] = mfma_sp(whi, ahi[fm], acc[fn][fm]);
             }
         }
     } else {
@@ -540,6 +543,8 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
     uint4 rdir[DIRECT ? NFN / 2 : 1][DIRECT ? NFM : 1][2];
     // channel index of this wave's first output column: n_base counts rows of W / entries of scale and bias, the
     // epilogue helpers add p.yoff / p.roff themselves
+    float wmul = 1.f;  // accumulator multiplier of the scaled split weights (trailer behind them: split_dev.h)
+    if constexpr (DIRECT) wmul = split_wmul(p.W, p.w_bytes);
     if constexpr (DIRECT) res_prefetch_direct<OUT, NFN, NFM>(p, m_base + wm * WM, n_base + wn * WN, lane, rdir);
     else res_prefetch<OUT, BMT, BN>(p, m_base, n_base, tid, rres);
 
@@ -570,10 +575,10 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
 #undef AVCER_DMA_SETUP
 
     if constexpr (DIRECT) {
-        if (p.act == 3) epilogue_direct<OUT, 3, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir);
-        else if (p.act == 2) epilogue_direct<OUT, 2, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir);
-        else if (p.act == 1) epilogue_direct<OUT, 1, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir);
-        else epilogue_direct<OUT, 0, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir);
+        if (p.act == 3) epilogue_direct<OUT, 3, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir, wmul);
+        else if (p.act == 2) epilogue_direct<OUT, 2, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir, wmul);
+        else if (p.act == 1) epilogue_direct<OUT, 1, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir, wmul);
+        else epilogue_direct<OUT, 0, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir, wmul);
     } else {
         // epilogue through LDS (the tile buffers are free: the loop ended on a barrier)
         stage_acc<MODE, BN>(p, smem, acc, n_base, wm * WM, wn, lane);
@@ -608,7 +613,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
 #define AVCER_WREGS4(H, L) "+v"(H[0]), "+v"(L[0]), "+v"(H[1]), "+v"(L[1]), "+v"(H[2]), "+v"(L[2]), "+v"(H[3]), "+v"(L[3])
 
 template <int OUT, int ACT, int NFN, int NFM>
-__device__ __forceinline__ void wd_epilogue(const GemmParams& p, f32x4_t (&acc)[NFN][NFM], int m_base, int c0, int lane) {
+__device__ __forceinline__ void wd_epilogue(const GemmParams& p, f32x4_t (&acc)[NFN][NFM], int m_base, int c0, int lane, const float wmul) {
     // straight from the accumulators (weight rows are permuted: lane group g holds channels 8g..8g+7 of every group of 32);
     // the residual is read here, four positions at a time, into the registers the weight fragments left free
 #pragma unroll
@@ -617,6 +622,9 @@ __device__ __forceinline__ void wd_epilogue(const GemmParams& p, f32x4_t (&acc)[
         float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
         if (p.scale) { s0 = *reinterpret_cast<const float4*>(p.scale + ch); s1 = *reinterpret_cast<const float4*>(p.scale + ch + 4); }
         if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + ch); b1 = *reinterpret_cast<const float4*>(p.bias + ch + 4); }
+        // the weights were split as w * 2^e (split_dev.h): wmul = 2^-e folds back into the channel scale, exactly
+        s0 = make_float4(s0.x * wmul, s0.y * wmul, s0.z * wmul, s0.w * wmul);
+        s1 = make_float4(s1.x * wmul, s1.y * wmul, s1.z * wmul, s1.w * wmul);
 #pragma unroll
         for (int h = 0; h < NFM; h += 4) {
             uint4 rr[4][2];
@@ -677,6 +685,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
         wfrs[2] = (int)p.w_bytes;
         wfrs[3] = 0x00020000;
     }
+    const float wmul = split_wmul(p.WF, p.w_bytes);  // accumulator multiplier of the scaled split weights (split_dev.h)
     const int lrow8 = lane >> 3, slot = lane & 7, g = lane >> 4;
     const int nk = p.K >> 5;
     const int n1 = p.K1 >> 5;  // K-steps served by the first source
@@ -788,16 +797,16 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
 #define AVCER_WD_READ(BASE, R, AH, AL)                                                                                  \
     do {                                                                                                                \
         const int row = (R) * 16 + (lane & 15);                                                                         \
-        AH = *reinterpret_cast<const bf16x8_t*>((BASE) + swz(row, g));                                                  \
-        AL = *reinterpret_cast<const bf16x8_t*>((BASE) + swz(row, 4 + g));                                              \
+        AH = *reinterpret_cast<const spx8_t*>((BASE) + swz(row, g));                                                  \
+        AL = *reinterpret_cast<const spx8_t*>((BASE) + swz(row, 4 + g));                                              \
     } while (0)
 #define AVCER_WD_MFMA(R, AH, AL, WH, WL)                                                                                \
     _Pragma("unroll") for (int fn = 0; fn < NFN; ++fn) {                                                                 \
-        const bf16x8_t whi = __builtin_bit_cast(bf16x8_t, WH[fn]), wlo = __builtin_bit_cast(bf16x8_t, WL[fn]);          \
+        const spx8_t whi = __builtin_bit_cast(spx8_t, WH[fn]), wlo = __builtin_bit_cast(spx8_t, WL[fn]);          \
         f32x4_t& c_ = acc[fn][R];                                                                                       \
-        c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, AH, c_, 0, 0, 0);                                             \
-        c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, AL, c_, 0, 0, 0);                                             \
-        c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, AH, c_, 0, 0, 0);                                             \
+        c_ = mfma_sp(wlo, AH, c_);                                             \
+        c_ = mfma_sp(whi, AL, c_);                                             \
+        c_ = mfma_sp(whi, AH, c_);                                             \
     }
 #define AVCER_WD_STEP(S, PH, WH, WL, WHN, WLN)                                                                          \
     do {                                                                                                                \
@@ -836,7 +845,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
     } while (0)
 
     int rslot = 0;  // ring slot the current step reads
-    bf16x8_t ah[2], al[2];
+    spx8_t ah[2], al[2];
     AVCER_WD_ISSUE_A(0);
     asm volatile("" ::: "memory");
     AVCER_WD_LOAD_W(wh0, wl0);
@@ -862,10 +871,10 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
 #undef AVCER_WD_ISSUE_A
 #undef AVCER_WD_LOAD_W
     const int c0 = n_base + wave * (BN / 4);
-    if (p.act == 3) wd_epilogue<OUT, 3, NFN, NFM>(p, acc, m_base, c0, lane);
-    else if (p.act == 2) wd_epilogue<OUT, 2, NFN, NFM>(p, acc, m_base, c0, lane);
-    else if (p.act == 1) wd_epilogue<OUT, 1, NFN, NFM>(p, acc, m_base, c0, lane);
-    else wd_epilogue<OUT, 0, NFN, NFM>(p, acc, m_base, c0, lane);
+    if (p.act == 3) wd_epilogue<OUT, 3, NFN, NFM>(p, acc, m_base, c0, lane, wmul);
+    else if (p.act == 2) wd_epilogue<OUT, 2, NFN, NFM>(p, acc, m_base, c0, lane, wmul);
+    else if (p.act == 1) wd_epilogue<OUT, 1, NFN, NFM>(p, acc, m_base, c0, lane, wmul);
+    else wd_epilogue<OUT, 0, NFN, NFM>(p, acc, m_base, c0, lane, wmul);
 #endif
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 
 #include "common.h"
+#include "split_dev.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;

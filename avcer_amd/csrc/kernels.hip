@@ -2,6 +2,7 @@
 // All of these are HBM/LDS-bound: 16-byte vector accesses, one 64-lane wave per row for reductions,
 // f32 statistics regardless of the activation storage type.
 #include "common.h"
+#include "split_dev.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -66,39 +67,39 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, long i, const
     *reinterpret_cast<uint2*>(p + i) = t;
 }
 
-// sp32 storage (AVCER_MODE_BF16X3 activations): per aligned group of 32 channels, 32 bf16 hi then 32 bf16 lo,
+// sp32 storage (AVCER_MODE_F16X3 activations): per aligned group of 32 channels, 32 fp16 hi then 32 fp16 lo (split_dev.h),
 // x = hi + lo.  4 bytes per element; element index e lives at byte ((e & ~31) << 2) + ((e & 31) << 1) (+64 for lo).
 struct sp32_t { uint32_t raw; };
 __device__ __forceinline__ long sp32_byte(long e) { return ((e & ~31L) << 2) + ((e & 31L) << 1); }
 template <> __device__ __forceinline__ float ldf<sp32_t>(const sp32_t* p, long i) {
     const char* b = reinterpret_cast<const char*>(p) + sp32_byte(i);
-    return bf2f(*reinterpret_cast<const bf16_t*>(b)) + bf2f(*reinterpret_cast<const bf16_t*>(b + 64));
+    return sp2f(*reinterpret_cast<const uint16_t*>(b)) + sp2f(*reinterpret_cast<const uint16_t*>(b + 64));
 }
 template <> __device__ __forceinline__ void stf<sp32_t>(sp32_t* p, long i, float v) {
     char* b = reinterpret_cast<char*>(p) + sp32_byte(i);
-    const bf16_t h = f2bf(v);
-    *reinterpret_cast<bf16_t*>(b) = h;
-    *reinterpret_cast<bf16_t*>(b + 64) = f2bf(v - bf2f(h));
+    const uint16_t h = f2sp(v);
+    *reinterpret_cast<uint16_t*>(b) = h;
+    *reinterpret_cast<uint16_t*>(b + 64) = f2sp(v - sp2f(h));
 }
 template <> __device__ __forceinline__ void ld4<sp32_t>(const sp32_t* p, long i, float* v) {
     const char* b = reinterpret_cast<const char*>(p) + sp32_byte(i);
     const uint2 h = *reinterpret_cast<const uint2*>(b);
     const uint2 l = *reinterpret_cast<const uint2*>(b + 64);
-    v[0] = bf2f((bf16_t)(h.x & 0xffff)) + bf2f((bf16_t)(l.x & 0xffff));
-    v[1] = bf2f((bf16_t)(h.x >> 16)) + bf2f((bf16_t)(l.x >> 16));
-    v[2] = bf2f((bf16_t)(h.y & 0xffff)) + bf2f((bf16_t)(l.y & 0xffff));
-    v[3] = bf2f((bf16_t)(h.y >> 16)) + bf2f((bf16_t)(l.y >> 16));
+    v[0] = sp2f((uint16_t)(h.x & 0xffff)) + sp2f((uint16_t)(l.x & 0xffff));
+    v[1] = sp2f((uint16_t)(h.x >> 16)) + sp2f((uint16_t)(l.x >> 16));
+    v[2] = sp2f((uint16_t)(h.y & 0xffff)) + sp2f((uint16_t)(l.y & 0xffff));
+    v[3] = sp2f((uint16_t)(h.y >> 16)) + sp2f((uint16_t)(l.y >> 16));
 }
 template <> __device__ __forceinline__ void st4<sp32_t>(sp32_t* p, long i, const float* v) {
     char* b = reinterpret_cast<char*>(p) + sp32_byte(i);
-    bf16_t h[4];
+    uint16_t h[4];
     uint2 hh, ll;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) h[j] = f2bf(v[j]);
+    for (int j = 0; j < 4; ++j) h[j] = f2sp(v[j]);
     hh.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
     hh.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
-    ll.x = (uint32_t)f2bf(v[0] - bf2f(h[0])) | ((uint32_t)f2bf(v[1] - bf2f(h[1])) << 16);
-    ll.y = (uint32_t)f2bf(v[2] - bf2f(h[2])) | ((uint32_t)f2bf(v[3] - bf2f(h[3])) << 16);
+    ll.x = (uint32_t)f2sp(v[0] - sp2f(h[0])) | ((uint32_t)f2sp(v[1] - sp2f(h[1])) << 16);
+    ll.y = (uint32_t)f2sp(v[2] - sp2f(h[2])) | ((uint32_t)f2sp(v[3] - sp2f(h[3])) << 16);
     *reinterpret_cast<uint2*>(b) = hh;
     *reinterpret_cast<uint2*>(b + 64) = ll;
 }
@@ -134,14 +135,14 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ in, T* __restrict_
 // Planar split-bf16 variant (input of stem_pool_kernel): the same zero-bordered image as two bf16 planes
 // [n,230,230,4], hi = bf16(v) and lo = bf16(v - hi), so that one 8-pixel tap row is 64 contiguous bytes per plane.
 __device__ __forceinline__ void st4_planar(bf16_t* hi, bf16_t* lo, long idx, const float* v) {
-    bf16_t h[4];
+    uint16_t h[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) h[j] = f2bf(v[j]);
+    for (int j = 0; j < 4; ++j) h[j] = f2sp(v[j]);
     uint2 hh, ll;
     hh.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
     hh.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
-    ll.x = (uint32_t)f2bf(v[0] - bf2f(h[0])) | ((uint32_t)f2bf(v[1] - bf2f(h[1])) << 16);
-    ll.y = (uint32_t)f2bf(v[2] - bf2f(h[2])) | ((uint32_t)f2bf(v[3] - bf2f(h[3])) << 16);
+    ll.x = (uint32_t)f2sp(v[0] - sp2f(h[0])) | ((uint32_t)f2sp(v[1] - sp2f(h[1])) << 16);
+    ll.y = (uint32_t)f2sp(v[2] - sp2f(h[2])) | ((uint32_t)f2sp(v[3] - sp2f(h[3])) << 16);
     *reinterpret_cast<uint2*>(hi + idx * 4) = hh;
     *reinterpret_cast<uint2*>(lo + idx * 4) = ll;
 }
@@ -849,9 +850,27 @@ __global__ void __launch_bounds__(ATT_THREADS) attention_kernel(const T* __restr
 //   softmax over keys     in-lane over its registers + 2 shuffles across the four lane groups
 //   O^T tile = V^T . P^T  the exponentiated accumulators of key tiles (2b, 2b+1) ARE the B operand of the PV MFMA for
 //                         key block b once V^T is stored with k-index 8g+e <-> key 32b + 16(e>>2) + 4g + (e&3)
-// X3 = 1: every product as hi.hi + hi.lo + lo.hi of bf16 pairs (f32-grade, as conv_gemm MODE 2/3); X3 = 0: bf16 operands.
+// X3 = 1: every product as hi.hi + hi.lo + lo.hi of fp16 pairs (f32-grade, as conv_gemm MODE 2/3; split_dev.h: scores and
+// exponentials are O(1), nothing here needs a scale); X3 = 0: bf16 operands.
 typedef __attribute__((ext_vector_type(8))) __bf16 att_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float att_f32x4_t;
+// operand element by arithmetic: the split type (fp16) in the x3 form, bf16 in the plain form
+template <int X3> struct AttOp {
+    typedef spe_t elem_t;
+    typedef spx8_t frag_t;
+    static __device__ __forceinline__ uint16_t bits(float f) { return f2sp(f); }
+    static __device__ __forceinline__ float val(uint16_t b) { return sp2f(b); }
+    static __device__ __forceinline__ att_f32x4_t mfma(const frag_t a, const frag_t b, const att_f32x4_t c) { return mfma_sp(a, b, c); }
+};
+template <> struct AttOp<0> {
+    typedef __bf16 elem_t;
+    typedef att_bf16x8_t frag_t;
+    static __device__ __forceinline__ uint16_t bits(float f) { return f2bf(f); }
+    static __device__ __forceinline__ float val(uint16_t b) { return bf2f(b); }
+    static __device__ __forceinline__ att_f32x4_t mfma(const frag_t a, const frag_t b, const att_f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
 
 __device__ __forceinline__ int att_swz(int row, int chunk) {
     return row * 128 + ((chunk ^ (int)((0x32765410u >> (((row >> 1) & 7) * 4)) & 7u)) << 4);
@@ -862,6 +881,9 @@ template <typename T, typename TO, int NKT, int X3, int D>
 __global__ void __launch_bounds__(64 * ATTM_WAVES) attention_mfma_kernel(const T* __restrict__ qkv, TO* __restrict__ out, int s, int heads,
                                                            float scale) {
     static_assert(D == 64 || D == 32, "head dimension 64 (wav2vec2 layers, tl2) or 32 (tl1)");
+    using Op = AttOp<X3>;
+    using frag_t = typename Op::frag_t;
+    using elem_t = typename Op::elem_t;
     constexpr int KS = D / 32;               // 32-wide K-steps of Q.K^T
     constexpr int TV = D / 16;               // 16-row tiles of V^T / O^T
     constexpr int SP = NKT * 16;             // padded key count
@@ -928,9 +950,9 @@ __global__ void __launch_bounds__(64 * ATTM_WAVES) attention_mfma_kernel(const T
         uint32_t hw[4], lw[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bf16_t h0 = f2bf(kv[2 * j]), h1 = f2bf(kv[2 * j + 1]);
+            const uint16_t h0 = Op::bits(kv[2 * j]), h1 = Op::bits(kv[2 * j + 1]);
             hw[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-            lw[j] = (uint32_t)f2bf(kv[2 * j] - bf2f(h0)) | ((uint32_t)f2bf(kv[2 * j + 1] - bf2f(h1)) << 16);
+            lw[j] = (uint32_t)Op::bits(kv[2 * j] - Op::val(h0)) | ((uint32_t)Op::bits(kv[2 * j + 1] - Op::val(h1)) << 16);
         }
         *reinterpret_cast<uint4*>(khi + att_swz(r, c)) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
         if (X3) *reinterpret_cast<uint4*>(klo + att_swz(r, c)) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
@@ -938,9 +960,9 @@ __global__ void __launch_bounds__(64 * ATTM_WAVES) attention_mfma_kernel(const T
         const int kpos = (r >> 5) * 32 + ((r & 15) >> 2) * 8 + ((r >> 4) & 1) * 4 + (r & 3);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const bf16_t hv = f2bf(vv[j]);
-            *reinterpret_cast<bf16_t*>(vhi + (8 * c + j) * VROW + kpos * 2) = hv;
-            if (X3) *reinterpret_cast<bf16_t*>(vlo + (8 * c + j) * VROW + kpos * 2) = f2bf(vv[j] - bf2f(hv));
+            const uint16_t hv = Op::bits(vv[j]);
+            *reinterpret_cast<uint16_t*>(vhi + (8 * c + j) * VROW + kpos * 2) = hv;
+            if (X3) *reinterpret_cast<uint16_t*>(vlo + (8 * c + j) * VROW + kpos * 2) = Op::bits(vv[j] - Op::val(hv));
         }
     }
     }
@@ -952,16 +974,16 @@ __global__ void __launch_bounds__(64 * ATTM_WAVES) attention_mfma_kernel(const T
         if (tq >= nqt) break;
         const int qrow = tq * 16 + q16;
         // ---- Q fragments (B operand): this lane's query row, head-dim 32ks + 8g .. +7, pre-scaled
-        att_bf16x8_t qh[KS], ql[KS];
+        frag_t qh[KS], ql[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const float (&qv)[8] = qraw[qi][ks];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float x = qv[j] * scale;
-                const __bf16 hh = (__bf16)x;
+                const elem_t hh = (elem_t)x;
                 qh[ks][j] = hh;
-                ql[ks][j] = (__bf16)(x - (float)hh);
+                ql[ks][j] = (elem_t)(x - (float)hh);
             }
         }
         // ---- scores^T: key tiles x this query tile
@@ -972,13 +994,13 @@ __global__ void __launch_bounds__(64 * ATTM_WAVES) attention_mfma_kernel(const T
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int off = att_swz(t * 16 + q16, ks * 4 + g);
-                const att_bf16x8_t kh = *reinterpret_cast<const att_bf16x8_t*>(khi + off);
+                const frag_t kh = *reinterpret_cast<const frag_t*>(khi + off);
                 if (X3) {
-                    const att_bf16x8_t kl = *reinterpret_cast<const att_bf16x8_t*>(klo + off);
-                    sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[ks], sc[t], 0, 0, 0);
-                    sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[ks], sc[t], 0, 0, 0);
+                    const frag_t kl = *reinterpret_cast<const frag_t*>(klo + off);
+                    sc[t] = Op::mfma(kl, qh[ks], sc[t]);
+                    sc[t] = Op::mfma(kh, ql[ks], sc[t]);
                 }
-                sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[ks], sc[t], 0, 0, 0);
+                sc[t] = Op::mfma(kh, qh[ks], sc[t]);
             }
         }
         // ---- softmax over keys (register r of tile t is key 16t + 4g + r); padded keys contribute nothing
@@ -1009,24 +1031,24 @@ __global__ void __launch_bounds__(64 * ATTM_WAVES) attention_mfma_kernel(const T
         for (int tv = 0; tv < TV; ++tv) oc[tv] = att_f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < NKT / 2; ++kb) {
-            att_bf16x8_t ph, pl;
+            frag_t ph, pl;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float x = sc[2 * kb + (j >> 2)][j & 3];
-                const __bf16 hh = (__bf16)x;
+                const elem_t hh = (elem_t)x;
                 ph[j] = hh;
-                pl[j] = (__bf16)(x - (float)hh);
+                pl[j] = (elem_t)(x - (float)hh);
             }
 #pragma unroll
             for (int tv = 0; tv < TV; ++tv) {
                 const int off = (tv * 16 + q16) * VROW + (kb * 4 + g) * 16;
-                const att_bf16x8_t vh = *reinterpret_cast<const att_bf16x8_t*>(vhi + off);
+                const frag_t vh = *reinterpret_cast<const frag_t*>(vhi + off);
                 if (X3) {
-                    const att_bf16x8_t vl = *reinterpret_cast<const att_bf16x8_t*>(vlo + off);
-                    oc[tv] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl, ph, oc[tv], 0, 0, 0);
-                    oc[tv] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, oc[tv], 0, 0, 0);
+                    const frag_t vl = *reinterpret_cast<const frag_t*>(vlo + off);
+                    oc[tv] = Op::mfma(vl, ph, oc[tv]);
+                    oc[tv] = Op::mfma(vh, pl, oc[tv]);
                 }
-                oc[tv] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, oc[tv], 0, 0, 0);
+                oc[tv] = Op::mfma(vh, ph, oc[tv]);
             }
         }
         // ---- normalise and store: registers of tile tv are head-dim 16tv + 4g + r of query lane&15
@@ -1071,44 +1093,78 @@ __global__ void mean_time_relu_kernel(const float* __restrict__ x, float* __rest
     y[idx] = relu_nan(s / (float)t);
 }
 
-// Offline weight split for the split-bf16 contraction: per group of 32 K-elements, 32 hi bf16 then 32 lo bf16
-// (w = hi + lo + O(2^-17 |w|)); same 4 bytes per element as f32, so the DMA addressing is unchanged.
+// The sp32 split of an activation-shaped tensor (avcer_split_weights; also the LSTM's hidden state): per group of 32
+// elements, 32 hi then 32 lo values of the split type (x = hi + lo + O(2^-22 |x|), split_dev.h); same 4 bytes per element
+// as f32, so the DMA addressing is unchanged.  No scaling: activations are stored as they are.
 __global__ void split_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = w[i];
-    const bf16_t h = f2bf(v);
+    const uint16_t h = f2sp(v);
     const size_t g = i >> 5, j = i & 31;
     out[g * 64 + j] = h;
-    out[g * 64 + 32 + j] = f2bf(v - bf2f(h));
+    out[g * 64 + 32 + j] = f2sp(v - sp2f(h));
 }
 
-// The same split for WEIGHT matrices [n][k] of the split-bf16 contractions, with the rows of every group of 32 output
-// channels re-ordered: stored row 16t + 4g + r holds channel 8g + 4t + r (t = 0,1; g = 0..3; r = 0..3).  With weights as
-// the MFMA A operand a lane's accumulators are 4 consecutive ROWS of a 16-row tile, so this order leaves lane group g of
-// two adjacent tiles with the 8 consecutive channels 8g..8g+7: a 16-byte piece of the output row (direct whole-line
-// stores, no LDS staging) and, in fused.hip, the B fragment of the next contraction in natural K order.
+// max |w| of a tensor as float bits (non-negative floats order like their bit patterns; NaN / inf end up largest)
+__global__ void absmax_kernel(const float* __restrict__ w, size_t n, unsigned* __restrict__ slot) {
+    unsigned m = 0u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(w[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(slot, m);
+}
+
+// The power of two a weight matrix is multiplied by before its fp16 split, from its largest magnitude (float bits): the one
+// that puts that magnitude into [2^14, 2^15) -- hi halves stay under fp16's 65504, and a weight's lo half stays a NORMAL
+// fp16 number down to 2^-18 of the largest weight (split_dev.h).  Returns (scale, 1 / scale) as float bits; (1, 1) for an
+// all-zero, non-finite or absurdly scaled tensor, and always in the bf16 lab build (bf16 has f32's range).
+__device__ __forceinline__ uint2 split_scale_bits(unsigned maxbits) {
+    const unsigned e = (maxbits >> 23) & 0xffu;  // biased exponent of max |w|
+#if defined(AVCER_SPLIT_BF16)
+    return make_uint2(0x3f800000u, 0x3f800000u);
+#else
+    if (e < 15u || e > 254u) return make_uint2(0x3f800000u, 0x3f800000u);
+    return make_uint2((268u - e) << 23, (e - 14u) << 23);  // 2^(141 - e), 2^(e - 141): max |w| * scale in [2^14, 2^15)
+#endif
+}
+
+// The split of a WEIGHT matrix [n][k] for the x3 contractions: the layout above along K, every value multiplied by the
+// tensor's power-of-two scale first, and the rows of every group of 32 output channels re-ordered: stored row 16t + 4g + r
+// holds channel 8g + 4t + r (t = 0,1; g = 0..3; r = 0..3).  With weights as the MFMA A operand a lane's accumulators are 4
+// consecutive ROWS of a 16-row tile, so this order leaves lane group g of two adjacent tiles with the 8 consecutive
+// channels 8g..8g+7: a 16-byte piece of the output row (direct whole-line stores, no LDS staging) and, in fused.hip, the
+// B fragment of the next contraction in natural K order.  Trailer behind the n * k * 4 bytes (AVCER_SPLIT_TRAILER_BYTES):
+// word 1 = max |w| as float bits (written by absmax_kernel before this launch), word 0 = 1 / scale as a float, written
+// here: the multiplier every consumer applies to its accumulators.
 __global__ void split_weight_rows_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int n, int k) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned* trailer = reinterpret_cast<unsigned*>(out + (size_t)n * k * 2);
+    const uint2 sc = split_scale_bits(trailer[1]);
+    if (i == 0) trailer[0] = sc.y;
     if (i >= (size_t)n * k) return;
     const int row = i / k, col = i - (size_t)row * k;      // destination row / K index
     const int j = row & 31, t = j >> 4, g = (j >> 2) & 3, r = j & 3;
     const int src = (row & ~31) + 8 * g + 4 * t + r;
-    const float v = w[(size_t)src * k + col];
-    const bf16_t h = f2bf(v);
+    const float v = w[(size_t)src * k + col] * __uint_as_float(sc.x);
+    const uint16_t h = f2sp(v);
     const size_t o = (size_t)row * k * 2 + (size_t)(col >> 5) * 64 + (col & 31);
     out[o] = h;
-    out[o + 32] = f2bf(v - bf2f(h));
+    out[o + 32] = f2sp(v - sp2f(h));
 }
 
 // The row-split weights once more, in MFMA fragment order for conv_gemm_wd_kernel (gemm.hip): [N/16][K/32][hi, lo][64 lanes]
-// [8 bf16], lane l of a fragment = stored row 16 nt + (l & 15), K elements 8 (l >> 4) .. + 8 of the K-step -- the 16 bytes
+// [8 x 16 bit], lane l of a fragment = stored row 16 nt + (l & 15), K elements 8 (l >> 4) .. + 8 of the K-step -- the 16 bytes
 // that lane feeds the MFMA as its A operand, so a wave fetches a whole fragment with one coalesced 1 KiB load.  `rows` is
 // the output of split_weight_rows_kernel (rows already permuted, hi / lo per 32-element K group); one thread per 16 bytes.
+// The trailer (scale words) is copied behind the fragments.
 __global__ void weight_frags_kernel(const uint4* __restrict__ rows, uint4* __restrict__ out, int n, int k) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // destination 16-byte piece
     const int nk = k >> 5;
-    if (i >= (size_t)n * nk * 8) return;
+    const size_t pieces = (size_t)n * nk * 8;
+    if (i < AVCER_SPLIT_TRAILER_BYTES / 16) out[pieces + i] = rows[pieces + i];
+    if (i >= pieces) return;
     const int lane = i & 63, hl = (i >> 6) & 1;
     const size_t f = i >> 7;  // (n tile, K-step)
     const int ks = (int)(f % nk), nt = (int)(f / nk);
@@ -1538,6 +1594,10 @@ int k_audio_chunks(avcer_ctx* ctx, const float* wav, const int32_t* starts, cons
 
 int k_split_weight_rows(avcer_ctx* ctx, const float* w, bf16_t* out, int n, int k, hipStream_t st) {
     if (n % 32 || k % 32) return set_err(ctx, AVCER_EINVAL, "split_weight_rows: n=%d and k=%d must be multiples of 32", n, k);
+    // trailer behind the split data: max |w| (word 1) -> the tensor's power-of-two scale; its inverse is left in word 0
+    unsigned* trailer = reinterpret_cast<unsigned*>(out + (size_t)n * k * 2);
+    HIP_TRY(ctx, hipMemsetAsync(trailer, 0, AVCER_SPLIT_TRAILER_BYTES, st));
+    absmax_kernel<<<(int)std::min<long>(cdiv((long)n * k, 256 * 16), 2048), 256, 0, st>>>(w, (size_t)n * k, trailer + 1);
     split_weight_rows_kernel<<<cdiv((long)n * k, 256), 256, 0, st>>>(w, out, n, k);
     CHECK_LAUNCH(ctx, "split_weight_rows");
     return AVCER_OK;

@@ -1,0 +1,47 @@
+// The split operand type of the parity-grade fast mode ("x3": AVCER_MODE_F16X3), shared by every translation unit.
+//
+// A value x is carried as a pair (hi, lo) of 16-bit floats, x = hi + lo, and a product as ah.wh + ah.wl + al.wh on the
+// 16-bit MFMA with f32 accumulation.  Rounds 1-3 split into bf16 (8 + 8 significand bits: 2^-17 per operand, 4.5e-6 per
+// contraction, which put sharp softmax heads at the 1e-4 probability gate).  Round 4 splits into IEEE fp16 (11 + 11 bits):
+// v_mfma_f32_16x16x32_f16 issues at the bf16 form's rate on gfx950, the storage is the same 4 bytes per element, and the
+// representation error falls to 2^-22 per operand -- 7e-8 per contraction (tools/x3_error_probe.py), f32-grade.
+//
+// What fp16 costs is RANGE, not rate:
+//   * activations are stored unscaled: |x| must stay below 65504 (larger values become +-inf, and inf - inf = NaN in the lo
+//     half: the overflow reaches the output as NaN, never as a wrong finite number).  Below 2^-3 the lo half is subnormal
+//     in fp16 -- kept by the conversion and by the MFMA (tools/f16_probe.hip on the GPU: subnormal A / B operands are not
+//     flushed) -- so a small element carries an ABSOLUTE error of at most 2^-25, f32-grade against an O(1) tensor;
+//   * weights are O(1/sqrt(K)) and would sit in that subnormal band: every weight matrix is multiplied by ONE power of
+//     two that puts its largest magnitude into [2^14, 2^15) before the split (split_weight_rows_kernel), and the inverse
+//     -- also a power of two, so nothing rounds differently -- travels with the weights in a trailer behind the split
+//     data (AVCER_SPLIT_TRAILER bytes: float [0] = the multiplier the consumer applies to its accumulators).
+//
+// AVCER_SPLIT_BF16 (lab builds only, tools/build_lab.sh) restores the round-3 bf16 split for A/B measurements.
+#pragma once
+
+#include <cstdint>
+
+constexpr int AVCER_SPLIT_TRAILER_BYTES = 256;  // == AVCER_SPLIT_TRAILER of include/avcer_hip.h
+
+#if defined(AVCER_SPLIT_BF16)
+typedef __bf16 spe_t;
+#else
+typedef _Float16 spe_t;
+#endif
+typedef __attribute__((ext_vector_type(8))) spe_t spx8_t;
+typedef __attribute__((ext_vector_type(4))) float sp_f32x4_t;
+
+// f32 -> the 16 bits of the split element type (round to nearest even) and back
+__device__ __forceinline__ uint16_t f2sp(float f) { return __builtin_bit_cast(uint16_t, (spe_t)f); }
+__device__ __forceinline__ float sp2f(uint16_t b) { return (float)__builtin_bit_cast(spe_t, b); }
+
+__device__ __forceinline__ sp_f32x4_t mfma_sp(const spx8_t a, const spx8_t b, const sp_f32x4_t c) {
+#if defined(AVCER_SPLIT_BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// the accumulator multiplier stored behind a split weight matrix of `bytes` bytes (see above)
+__device__ __forceinline__ float split_wmul(const char* w, size_t bytes) { return *reinterpret_cast<const float*>(w + bytes); }

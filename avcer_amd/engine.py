@@ -11,11 +11,11 @@ import numpy as np
 import torch
 
 from . import _lib, packing
-from ._lib import AvcerError, ConvDesc
+from ._lib import SPLIT_TRAILER, AvcerError, ConvDesc
 
 MODE_FP32 = 0
 MODE_BF16 = 1
-MODE_BF16X3 = 2
+MODE_F16X3 = 2
 PAD_MODES = {"mean": 0, "constant": 1, "repeat": 2}
 
 
@@ -275,12 +275,12 @@ class Engine:
         return out
 
     def split_weight_rows(self, w):
-        """f32 [N,K] weight matrix -> the split-bf16, row-permuted layout of conv_gemm dtypes 3-6 and the fused kernels
+        """f32 [N,K] weight matrix -> the split-fp16, row-permuted layout of conv_gemm dtypes 3-6 and the fused kernels
         (int16 tensor of 2*N*K entries)."""
         w = self._dev(w, torch.float32)
         if w.dim() != 2:
             raise ValueError("split_weight_rows: w [N,K]")
-        out = torch.empty(w.numel() * 2, dtype=torch.int16, device=self.device)
+        out = torch.empty(w.numel() * 2 + SPLIT_TRAILER // 2, dtype=torch.int16, device=self.device)
         self._check(self.lib.avcer_split_weight_rows(self.ctx, _ptr(w), _ptr(out), int(w.shape[0]), int(w.shape[1]), self._stream()))
         return out
 

@@ -132,7 +132,7 @@ def pack_static(sd) -> "OrderedDict[str, np.ndarray]":
 
 
 def permute_rows_for_mfma(w: np.ndarray) -> np.ndarray:
-    """Row order of every split-bf16 weight matrix on the device (the library applies it when it builds the split copies,
+    """Row order of every split-fp16 weight matrix on the device (the library applies it when it builds the split copies,
     csrc/kernels.hip split_weight_rows_kernel; this numpy twin exists for tests): inside every group of 32 output
     channels, stored row 16t + 4g + r holds channel 8g + 4t + r (t = 0,1; g = 0..3; r = 0..3), so that the two
     16-row MFMA tiles of a group leave every lane group g with the 8 consecutive channels 8g..8g+7."""

@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 
 from avcer_amd import dist as adist  # noqa: E402
 from avcer_amd import synth  # noqa: E402
-from avcer_amd.engine import MODE_BF16, MODE_BF16X3, MODE_FP32  # noqa: E402
+from avcer_amd.engine import MODE_BF16, MODE_F16X3, MODE_FP32  # noqa: E402
 
 T_FRAMES, T_AUDIO, FPS = 16, 32000, 25
 # Algorithmic work (forward hooks on the imported reference; 1 MAC = 2 FLOP)
@@ -55,7 +55,7 @@ GFLOP_CLIP_GEMM = GFLOP_CLIP - GFLOP_AUDIO_NOT_GEMM - 2 * 512 * 7 * T_FRAMES * 1
 GUIDE = "/opt/skills/guides/MI355X_MICROARCH.md"
 PEAK_FALLBACK = {"fp32": 157.3, "bf16": 2500.0, "x3": 2500.0}  # used only where the guide file is absent
 MFMA_PASSES = {"fp32": 1, "bf16": 1, "x3": 3}  # MFMA products issued per algorithmic product
-DTYPE = {"fp32": "f32", "bf16": "bf16", "x3": "bf16x3 (bf16 MFMA on hi/lo-split f32 operands, f32 accumulate)"}
+DTYPE = {"fp32": "f32", "bf16": "bf16", "x3": "f16x3 (f16 MFMA on hi/lo-split f32 operands, f32 accumulate)"}
 KERNEL = {"fp32": "conv_gemm_kernel<0,0,*>", "bf16": "conv_gemm_kernel<1,*,*>",
           "x3": "conv_gemm_kernel<3,*,*> (sp32 activations; <2,*,*> where the input is still f32)"}
 
@@ -427,7 +427,7 @@ def main():
 
     from avcer_amd.pipeline import AVPipeline
 
-    modes = {"fp32": MODE_FP32, "bf16": MODE_BF16, "x3": MODE_BF16X3}
+    modes = {"fp32": MODE_FP32, "bf16": MODE_BF16, "x3": MODE_F16X3}
     pk, pk_src = peaks()
     torch.set_num_threads(min(usable_cores(), 16))
     log(f"rank {rank}/{world}: building pipeline (synthetic weights, seed 42)")

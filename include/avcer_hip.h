@@ -41,23 +41,27 @@ enum {
 
 /* arithmetic mode of the MFMA contractions */
 enum {
-    AVCER_MODE_FP32 = 0, /* f32 operands, v_mfma_f32_32x32x2_f32: parity mode (<=1e-4 on probabilities) */
-    AVCER_MODE_BF16 = 1, /* bf16 operands / f32 accumulate, v_mfma_f32_16x16x32_bf16: throughput mode */
-    AVCER_MODE_BF16X3 = 2 /* f32 activations and results; each product as ah*wh + ah*wl + al*wh on the bf16 MFMA
-                             (operands split into bf16 hi+lo, ~2^-17 relative error): parity-grade, 3 MFMAs per product */
+    AVCER_MODE_FP32 = 0, /* f32 operands, v_mfma_f32_32x32x2_f32: exact f32 FMA chains */
+    AVCER_MODE_BF16 = 1, /* bf16 operands / f32 accumulate, v_mfma_f32_16x16x32_bf16: throughput mode, NOT parity-grade */
+    AVCER_MODE_F16X3 = 2 /* the fast parity mode: f32-grade activations and results; every operand is carried as an fp16
+                            pair hi + lo (11 + 11 significand bits) and every product as ah*wh + ah*wl + al*wh on
+                            v_mfma_f32_16x16x32_f16 with f32 accumulation: 3 MFMAs per product, ~7e-8 relative error per
+                            contraction (rounds 1-3 split into bf16 pairs: 4.5e-6; that mode was AVCER_MODE_BF16X3) */
 };
-/* Error bounds of the two parity-grade modes against the reference's CPU path, measured over five synthetic weight draws
- * (tests/test_gpu_parity_breadth.py, profiles/r03_x3_stage_error.txt):
- *   AVCER_MODE_FP32    |dlogit| <= 1.6e-5, |dprob| <= 1.6e-5 up to 8 x sharper heads than the synthetic generator's;
- *   AVCER_MODE_BF16X3  static CNN |dlogit| <= 7.5e-5 absolute, whatever the head (each contraction carries 4.5e-6 relative
- *                      error; the 7x7 average pool and the f32 fc1 / fc2 keep 4.6e-6 of the trunk's 1.3e-5), so
- *                      |dprob| <= 2.9e-5 at the generator's logit scale (rms 1.7-7.9) over 21 weight draws: inside the
- *                      1e-4 gate with a margin of 3.  The error grows with the sharpness of the head and only shows on
- *                      frames whose two leading classes are nearly tied: at 4 x the scale 20 draws of 21 stay under
- *                      6.6e-5 and one reads 1.1e-4; at 8 x the worst reads 1.9e-4 (tools/x3_margin_sweep.py).  A
- *                      checkpoint whose logits are that large belongs in AVCER_MODE_FP32 (<= 1.8e-5 at every scale
- *                      tried), the default of the host mirrors. */
+/* Range contract of AVCER_MODE_F16X3 (csrc/split_dev.h).  Activations are stored unscaled as fp16 pairs: every
+ * intermediate activation must satisfy |x| < 65504.  A larger value becomes +-inf in its hi half and NaN in hi + lo, and the
+ * NaN reaches the outputs: an overflow is never a wrong finite number (tests/test_gpu_edges.py).  Weights are multiplied
+ * by one power of two per matrix before the split (largest |w| -> [2^14, 2^15)); the inverse, also a power of two, rides
+ * behind the split data (AVCER_SPLIT_TRAILER) and every consumer folds it into its epilogue, so no result depends on it.
+ * Error bounds of the two parity-grade modes against the reference's CPU path are in DESIGN.md section 6 and asserted by
+ * tests/test_gpu_parity_breadth.py: ONE gate of 1e-4 on probabilities for both modes at 1 x, 4 x and 8 x the synthetic
+ * generator's logit scale. */
 
+/* Bumped whenever a struct layout, an argument list or a buffer size of this header changes incompatibly; the Python binding
+ * refuses a library whose avcer_abi_version() differs (avcer_amd/_lib.py).
+ *   2: avcer_conv_desc grew r_sub / r_h / r_w / tile_m, avcer_bneck_chain gained out_step, avcer_set_option left (round 3);
+ *      split weight buffers carry a trailer and AVCER_MODE_BF16X3 became AVCER_MODE_F16X3 (round 4). */
+#define AVCER_ABI_VERSION 2
 int avcer_abi_version(void);
 
 int avcer_ctx_create(int device, avcer_ctx** out);
@@ -99,7 +103,7 @@ int avcer_gather_windows(avcer_ctx* ctx, const float* feats, const int32_t* idx,
  *   ref: architectures/video.py:169-185 (LSTMPyTorch.forward), get_prob_video.py:122-129
  * windows f32 [n,10,512] -> logits f32 [n,7] (raw logits, no softmax). Always f32 arithmetic. */
 int avcer_dynamic_forward(avcer_ctx* ctx, const float* windows, int n, float* logits, avcer_stream_t stream);
-/* Same with an arithmetic mode: AVCER_MODE_BF16X3 runs the projections on the split-bf16 MFMA (f32 state, f32-grade
+/* Same with an arithmetic mode: AVCER_MODE_F16X3 runs the projections on the split-fp16 MFMA (f32 state, f32-grade
  * results); AVCER_MODE_BF16 keeps them in f32 (the recurrence is latency-bound, not worth a third weight copy). */
 int avcer_dynamic_forward_mode(avcer_ctx* ctx, const float* windows, int n, int mode, float* logits,
                                avcer_stream_t stream);
@@ -184,11 +188,11 @@ int avcer_fuse(avcer_ctx* ctx, const float* stat, const float* dyn_logits, const
 /* The contraction kernel itself (implicit-GEMM convolution with fused epilogue), exported for kernel-level
  * parity tests and micro-benchmarks:  Y[m, n] = act(scale[n] * sum_k A[m,k] * W[n,k] + bias[n] (+ R[m,n]))
  * where A is gathered from an NHWC tensor.  See avcer_conv_desc. dtype: 0 = f32 in/out, 1 = bf16 in/out,
- * 2 = bf16 in / f32 out; split-bf16 arithmetic with w pre-split by avcer_split_weight_rows: 3 = f32 in / f32 out,
+ * 2 = bf16 in / f32 out; split-fp16 ("x3") arithmetic with w pre-split by avcer_split_weight_rows: 3 = f32 in / f32 out,
  * 4 = f32 in / sp32 out, 5 = sp32 in / sp32 out (+ sp32 residual), 6 = sp32 in / f32 out (+ f32 residual);
  * 7 / 8 = 5 / 6 with w in fragment order (avcer_weight_frags): the weights-direct form of the kernel, bit-identical results,
  * for n % 256 == 0, an even number of 32-element K-steps and groups <= 1 (anything else is AVCER_EINVAL: use 5 / 6).
- * "sp32" storage = per aligned group of 32 channels, 32 bf16 hi values then 32 bf16 lo values (x = hi + lo), i.e. the
+ * "sp32" storage = per aligned group of 32 channels, 32 fp16 hi values then 32 fp16 lo values (x = hi + lo), i.e. the
  * layout avcer_split_weights produces; 4 bytes per element. */
 typedef struct avcer_conv_desc {
     int32_t batch, in_h, in_w;       /* input extents used for bounds (zero padding outside) */
@@ -203,7 +207,7 @@ typedef struct avcer_conv_desc {
     int64_t r_ld; int32_t r_coff;    /* residual row stride / offset (if residual != NULL) */
     int32_t act;                     /* 0 none, 1 relu, 2 gelu(erf), 3 gelu with the Abramowitz-Stegun 7.1.26 erf: within 4.7e-7 of
                                         the exact function (the f32 rounding of the exact form itself), a third of the
-                                        instructions; what the library uses around bf16 / split-bf16 contractions */
+                                        instructions; what the library uses around bf16 / split-fp16 contractions */
     int32_t res_after_act;           /* 0: act(v + r), 1: act(v) + r */
     int32_t groups;                  /* 0/1 = plain; G > 1 = grouped convolution in ONE launch: group g reads input
                                         channels x_coff + g*cin, uses weight rows [g*n, (g+1)*n) of w (and scale/bias
@@ -231,7 +235,7 @@ int avcer_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, const v
 int avcer_conv_gemm_dual(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, const void* x, const void* x2, const void* w,
                          const float* scale, const float* bias, const void* residual, void* y, avcer_stream_t stream);
 
-/* Fused kernels of the static CNN in the split-bf16 arithmetic (csrc/fused.hip), exported for kernel-level parity tests.
+/* Fused kernels of the static CNN in the split-fp16 arithmetic (csrc/fused.hip), exported for kernel-level parity tests.
  *
  * avcer_bneck_chain: the tail of one ResNet bottleneck and the head of the next in ONE launch,
  *     T2 = relu(conv3x3(T1) + b2);  OUT = relu(conv1x1(T2) + b3 + X);  T1N = relu(conv1x1(OUT) + b1n)
@@ -247,7 +251,7 @@ int avcer_conv_gemm_dual(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, co
  *   sp32 [nb, (h+1)/2, (w+1)/2, 4*planes]; t1 and x keep their [nb,h,w] grids.  out_step = 1: every position.
  *
  * avcer_stem_pool: conv 7x7/2 (TF-"same" padding) + BN + ReLU + max-pool 3x3/2 in one launch,
- *   ref: architectures/video.py:63-90,98-103,116-117.  planes_hi_lo: two bf16 planes [n,230,230,4] (hi, then lo plane_bytes
+ *   ref: architectures/video.py:63-90,98-103,116-117.  planes_hi_lo: two fp16 planes [n,230,230,4] (hi, then lo plane_bytes
  *   later) of the zero-bordered preprocessed image as avcer_static_forward builds it; w split [64][7*32] (tap rows of
  *   8 pixels x 4 channels); scale / bias f32 [64]; y sp32 [n,55,55,64]. */
 int avcer_bneck_chain(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, int out_step,
@@ -256,37 +260,45 @@ int avcer_bneck_chain(avcer_ctx* ctx, int planes, int nb, int h, int w, const vo
 int avcer_stem_pool(avcer_ctx* ctx, const void* planes_hi_lo, size_t plane_bytes, const void* w, const float* scale,
                     const float* bias, void* y, int n, avcer_stream_t stream);
 /* The same launch fed with the u8 frames themselves ([n,in_h,in_w,3] RGB; data/utils.py:19-39 -- NEAREST resize to 224, BGR flip,
- * mean subtraction -- happens inside): raw pixel values are exact in bf16, so the stem runs two MFMAs per product, and the
+ * mean subtraction -- happens inside): raw pixel values are exact in fp16, so the stem runs two MFMAs per product, and the
  * channel means move into shifts9 f32 [9][64] = BN shift - BN scale * (sum over the taps inside the image of w * mean), one
  * row per border class 3 * row_class + col_class (0: first stem row / column, 1: interior, 2: row / column 110; see
- * avcer_amd/packing.py stem_border_shifts).  What avcer_static_forward runs in AVCER_MODE_BF16X3. */
+ * avcer_amd/packing.py stem_border_shifts).  What avcer_static_forward runs in AVCER_MODE_F16X3. */
 int avcer_stem_pool_u8(avcer_ctx* ctx, const uint8_t* frames, int n, int in_h, int in_w, const void* w, const float* scale,
                        const float* shifts9, void* y, avcer_stream_t stream);
 
 /* The sp32 split of an ACTIVATION tensor (what a producer's epilogue writes with dtype 4 / 5): for every group of 32
- * elements, 32 bf16 "hi" values then 32 bf16 "lo" values with x = hi + lo (+ O(2^-17 |x|)).  x f32 [numel] (a multiple
- * of 32) -> out, same size in bytes.  Both device pointers.  NOT a weight layout: the weights of dtypes 3-6 additionally
- * need their rows permuted (avcer_split_weight_rows below); a weight matrix split with this call would come out with
- * its output channels silently permuted inside every group of 32. */
+ * elements, 32 fp16 "hi" values then 32 fp16 "lo" values with x = hi + lo (+ O(2^-22 |x|); |x| < 65504).  x f32 [numel] (a
+ * multiple of 32) -> out, same size in bytes, no scaling.  Both device pointers.  NOT a weight layout: the weights of dtypes
+ * 3-8 are scaled, carry a trailer and have their rows permuted (avcer_split_weight_rows below). */
 int avcer_split_weights(avcer_ctx* ctx, const float* w, void* out, size_t numel, avcer_stream_t stream);
 
-/* The split of a WEIGHT matrix w f32 [n][k] (n, k multiples of 32) as the split-bf16 contractions (dtype 3-6 of
- * avcer_conv_gemm, avcer_bneck_chain, avcer_stem_pool) expect it: the layout above along K, and the rows of every group of
- * 32 output channels re-ordered so that stored row 16t + 4g + r holds channel 8g + 4t + r (t = 0,1; g = 0..3; r = 0..3).
- * With weights as the MFMA A operand this leaves each lane with 8 consecutive output channels, i.e. 16-byte pieces of
- * the output row (direct whole-line stores).  scale / bias / residual / output stay in natural channel order. */
+/* Bytes behind the n * k * 4 bytes of a split WEIGHT matrix that hold its scale: float [0] = the power of two a consumer
+ * multiplies its accumulators by (the inverse of the scale the weights were split at), word [1] = max |w| as float bits.
+ * Every buffer written by avcer_split_weight_rows / avcer_weight_frags is n * k * 4 + AVCER_SPLIT_TRAILER bytes. */
+#define AVCER_SPLIT_TRAILER 256
+
+/* The split of a WEIGHT matrix w f32 [n][k] (n, k multiples of 32) as the x3 contractions (dtype 3-6 of avcer_conv_gemm,
+ * avcer_bneck_chain, avcer_stem_pool) expect it: every value times the matrix's power-of-two scale (largest magnitude ->
+ * [2^14, 2^15): keeps the lo halves of all significant weights normal fp16 numbers), the layout above along K, and the rows
+ * of every group of 32 output channels re-ordered so that stored row 16t + 4g + r holds channel 8g + 4t + r (t = 0,1;
+ * g = 0..3; r = 0..3).  With weights as the MFMA A operand this leaves each lane with 8 consecutive output channels, i.e.
+ * 16-byte pieces of the output row (direct whole-line stores).  scale / bias / residual / output stay in natural channel
+ * order and in real units: the kernels undo the weight scale themselves from the trailer.
+ * out: n * k * 4 + AVCER_SPLIT_TRAILER bytes. */
 int avcer_split_weight_rows(avcer_ctx* ctx, const float* w, void* out, int n, int k, avcer_stream_t stream);
 
 /* The output of avcer_split_weight_rows once more in MFMA fragment order, the weight layout of avcer_conv_gemm dtypes 7 / 8
  * (conv_gemm_wd_kernel: weight fragments go straight from global memory to the registers, only the activation tile passes
- * through LDS): [n/16][k/32][hi, lo][64 lanes][16 bytes], lane l = stored row 16 t + (l & 15), K elements 8 (l >> 4) .. + 8.
- * rows, out: device pointers, n * k * 4 bytes each; n a multiple of 16, k of 32. */
+ * through LDS): [n/16][k/32][hi, lo][64 lanes][16 bytes], lane l = stored row 16 t + (l & 15), K elements 8 (l >> 4) .. + 8,
+ * then the trailer.  rows, out: device pointers, n * k * 4 + AVCER_SPLIT_TRAILER bytes each; n a multiple of 16, k of 32. */
 int avcer_weight_frags(avcer_ctx* ctx, const void* rows, void* out, int n, int k, avcer_stream_t stream);
 
-/* Measured ceilings of the GPU this context lives on (about 0.2 s): dense bf16 MFMA issue rate of a register-only
- * v_mfma_f32_16x16x32_bf16 loop in TFLOP/s, and the bandwidth of a 1 GiB -> 1 GiB 16-byte-per-lane copy in TB/s (bytes read
- * + bytes written).  bench.py prints them next to the datasheet peaks it divides by.  Uses 2 GiB of workspace. */
-int avcer_measure_ceilings(avcer_ctx* ctx, double* mfma_bf16_tflops, double* hbm_copy_tbs, avcer_stream_t stream);
+/* Measured ceilings of the GPU this context lives on (about 0.2 s): dense 16-bit MFMA issue rate of a register-only
+ * v_mfma_f32_16x16x32_f16 loop in TFLOP/s (the instruction of AVCER_MODE_F16X3; the bf16 form issues at the same rate,
+ * tools/f16_probe.hip), and the bandwidth of a 1 GiB -> 1 GiB 16-byte-per-lane copy in TB/s (bytes read + bytes written).
+ * bench.py prints them next to the datasheet peaks it divides by.  Uses 2 GiB of workspace. */
+int avcer_measure_ceilings(avcer_ctx* ctx, double* mfma16_tflops, double* hbm_copy_tbs, avcer_stream_t stream);
 
 /* Last launch statistics of the dominant kernel (for bench.py's roofline object): number of conv_gemm
  * launches and their summed algorithmic FLOPs since the previous call to this function. */

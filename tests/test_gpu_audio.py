@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from avcer_amd import audio_pipeline, synth
-from avcer_amd.engine import MODE_BF16, MODE_BF16X3, MODE_FP32
+from avcer_amd.engine import MODE_BF16, MODE_F16X3, MODE_FP32
 from oracle import audio as oa
 
 pytestmark = pytest.mark.gpu
@@ -77,11 +77,11 @@ def test_audio_model_mirror_squeezes_like_reference(engine_audio, sd_audio, gold
 
 def test_expr_model_split_bf16_meets_parity_gate(engine_audio, golden):
     g = golden("audio_model")
-    out = engine_audio.audio_forward(torch.from_numpy(synth.waveforms(5678, 2, 32000)), normalize=True, mode=MODE_BF16X3)
+    out = engine_audio.audio_forward(torch.from_numpy(synth.waveforms(5678, 2, 32000)), normalize=True, mode=MODE_F16X3)
     got, ref = out.cpu().numpy(), g["t32000_logits"]
     p_got = torch.softmax(torch.from_numpy(got[:, :7]), 1).numpy()
     p_ref = torch.softmax(torch.from_numpy(ref[:, :7]), 1).numpy()
-    print("audio split-bf16 max|dlogit|", np.abs(got - ref).max(), "max|dprob|", np.abs(p_got - p_ref).max())
+    print("audio split-fp16 max|dlogit|", np.abs(got - ref).max(), "max|dprob|", np.abs(p_got - p_ref).max())
     assert np.abs(p_got - p_ref).max() < 1e-4
     assert (got.argmax(1) == ref.argmax(1)).all()
 
@@ -132,7 +132,7 @@ def test_seven_class_variant(engine, golden):
     assert eng.audio_classes == 7
     wav = torch.from_numpy(synth.waveforms(777, 2, 32000))
     ref = golden("audio_model7")["logits"]
-    for mode, tol in ((MODE_FP32, 1e-4), (MODE_BF16X3, 8e-4)):  # measured 9e-6 / 7.7e-5
+    for mode, tol in ((MODE_FP32, 1e-4), (MODE_F16X3, 8e-4)):  # measured 9e-6 / 7.7e-5
         out = eng.audio_forward(wav, normalize=True, mode=mode).cpu().numpy()
         assert out.shape == (2, 7)
         p_got = torch.softmax(torch.from_numpy(out), 1).numpy()
@@ -142,7 +142,7 @@ def test_seven_class_variant(engine, golden):
     eng.close()
 
 
-@pytest.mark.parametrize("mode,tol", [(MODE_BF16X3, 1e-4), (MODE_BF16, 0.1)])
+@pytest.mark.parametrize("mode,tol", [(MODE_F16X3, 1e-4), (MODE_BF16, 0.1)])
 def test_four_second_windows_mfma_attention(engine_audio, golden, mode, tol):
     """T = 64000 -> 199 tokens: the 16-key-tile instantiation of the MFMA attention kernel (the reference's run-time
     window), batch of 3 to exercise several (window, head) blocks; row 0 is the golden's input."""

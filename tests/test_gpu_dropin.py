@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from avcer_amd import synth
-from avcer_amd.engine import MODE_BF16X3, MODE_FP32
+from avcer_amd.engine import MODE_F16X3, MODE_FP32
 from avcer_amd.models import AudioModel, DynamicModel, StaticModel
 from oracle import audio as oa
 from oracle import video as ov
@@ -59,7 +59,7 @@ def frame_loop(pth_model_static, pth_model_dynamic, activations, frames_u8, pres
     return np.array(probs_static), np.array(probs_dynamic)
 
 
-@pytest.mark.parametrize("mode,tol_s,tol_d", [(MODE_FP32, 1e-4, 2e-5), (MODE_BF16X3, 1e-4, 1e-4)])
+@pytest.mark.parametrize("mode,tol_s,tol_d", [(MODE_FP32, 1e-4, 2e-5), (MODE_F16X3, 1e-4, 1e-4)])
 @pytest.mark.parametrize("case", ["gap25", "gap30", "lead25", "full25"])
 def test_reference_frame_loop_runs_unchanged_on_the_mirrors(engine, sd_static, sd_dynamic, golden, case, mode, tol_s, tol_d):
     g = golden("visual_harness")
@@ -83,7 +83,7 @@ def test_reference_frame_loop_runs_unchanged_on_the_mirrors(engine, sd_static, s
 def test_static_mirror_batch_of_one_equals_row_of_a_batch(engine, sd_static):
     """One frame per call (the reference's pattern) and the same frame inside a batch: same bits, in both parity modes."""
     x = ov.pth_processing(synth.face_frames(4321, 5))
-    for mode in (MODE_FP32, MODE_BF16X3):
+    for mode in (MODE_FP32, MODE_F16X3):
         m = StaticModel(engine, sd_static, mode=mode)
         whole = m(x.to(engine.device)).cpu()
         feats = m.activations["features"].cpu()
@@ -122,7 +122,7 @@ class _EmotionRecognitionLike:
         return np.array(probs), np.array(framess)
 
 
-@pytest.mark.parametrize("mode,tol", [(MODE_FP32, 2e-5), (MODE_BF16X3, 1e-4)])
+@pytest.mark.parametrize("mode,tol", [(MODE_FP32, 2e-5), (MODE_F16X3, 1e-4)])
 def test_reference_audio_loop_runs_unchanged_on_the_mirror(engine, sd_audio, golden, mode, tol):
     from transformers import Wav2Vec2FeatureExtractor
 
@@ -164,7 +164,7 @@ def test_static_call_larger_than_one_back_pass(engine, sd_static):
     base = torch.from_numpy(synth.face_frames(77, 64)).to(engine.device)
     frames = base.repeat((n + 63) // 64, 1, 1, 1)[:n].contiguous()
     frames[2048:] = torch.from_numpy(synth.face_frames(78, n - 2048)).to(engine.device)   # the second back pass gets its own content
-    for mode, tol in ((MODE_BF16X3, 1e-4), (MODE_FP32, 1e-4)):
+    for mode, tol in ((MODE_F16X3, 1e-4), (MODE_FP32, 1e-4)):
         lg, pr, ft = [t.cpu() for t in engine.static_forward(frames, mode)]
         assert torch.isfinite(lg).all()
         l2, p2, f2 = [t.cpu() for t in engine.static_forward(frames[2040:], mode)]      # rows 2040.. straddle the pass boundary
@@ -180,7 +180,7 @@ def test_static_call_larger_than_one_back_pass(engine, sd_static):
         assert d < tol
 
 
-@pytest.mark.parametrize("mode", [MODE_FP32, MODE_BF16X3])
+@pytest.mark.parametrize("mode", [MODE_FP32, MODE_F16X3])
 def test_two_granularity_schedule_small_passes(engine, sd_static, mode):
     """avcer_set_static_batch(4) with 11 frames: front passes of 4 + 4 + 3 frames writing into the back buffer at offsets
     c0 > 0, back passes of 8 + 3 frames (s0 > 0).  Bit-identical to the single-pass result, and equal to the oracle."""

@@ -5,7 +5,7 @@ import torch
 
 from avcer_amd import audio_pipeline, fusion, synth, video_pipeline
 from avcer_amd._lib import AvcerError
-from avcer_amd.engine import MODE_BF16X3, MODE_FP32
+from avcer_amd.engine import MODE_F16X3, MODE_FP32
 
 pytestmark = pytest.mark.gpu
 
@@ -17,7 +17,7 @@ def test_clip_without_any_face_yields_zero_tables(engine_static, engine_dynamic)
 
 
 def test_single_frame_and_single_window(engine_static, engine_dynamic, engine_audio):
-    for mode in (MODE_FP32, MODE_BF16X3):
+    for mode in (MODE_FP32, MODE_F16X3):
         lg, pr, ft = engine_static.static_forward(torch.from_numpy(synth.face_frames(2, 1)), mode)
         assert lg.shape == (1, 7) and ft.shape == (1, 512) and abs(float(pr.sum()) - 1) < 1e-5
         out = engine_audio.audio_forward(torch.from_numpy(synth.waveforms(2, 1, 32000)), True, mode)
@@ -80,3 +80,18 @@ def test_c_abi_audio_chunks_empty_chunk_in_repeat_mode_is_nan_not_a_fault(engine
     o = out.cpu()
     assert o[0].tolist() == [float(1 + i % 10) for i in range(16)]
     assert torch.isnan(o[1]).all() and torch.isnan(o[2]).all()
+
+
+def test_x3_activation_overflow_reaches_the_output_as_nan(engine_static):
+    """Range contract of AVCER_MODE_F16X3 (include/avcer_hip.h): activations are fp16 pairs, |x| < 65504.  A preprocessed
+    tensor scaled far beyond that must come back as NaN probabilities -- never as finite, wrong ones -- while the f32 mode
+    still computes it."""
+    x = torch.from_numpy(synth.face_frames(7, 2)).float().permute(0, 3, 1, 2).contiguous() - 100.0
+    lg, pr, _ = engine_static.static_forward_nchw(x * 1.0e4, MODE_F16X3)
+    assert torch.isnan(pr).all() and torch.isnan(lg).all()
+    lg32, pr32, _ = engine_static.static_forward_nchw(x * 1.0e4, MODE_FP32)
+    assert torch.isfinite(lg32).all()
+    # the same tensor inside the range: the two parity-grade modes agree
+    lg, pr, _ = engine_static.static_forward_nchw(x, MODE_F16X3)
+    lg32, pr32, _ = engine_static.static_forward_nchw(x, MODE_FP32)
+    assert torch.isfinite(pr).all() and (pr - pr32).abs().max() < 1e-4

@@ -93,11 +93,11 @@ def test_full_size_batch_properties_x3(engine, sd_static, sd_dynamic, sd_audio):
     """BASELINE config 4/5 per-GPU size (128 clips = 2048 frames + 128 windows) in the headline arithmetic mode:
     determinism, independence of batch composition (a clip's record does not depend on its neighbours or position),
     probabilities normalised, and agreement of a sample of clips with the oracle within the 1e-4 gate."""
-    from avcer_amd.engine import MODE_BF16X3
+    from avcer_amd.engine import MODE_F16X3
     from avcer_amd.pipeline import AVPipeline
 
     pipe = AVPipeline.__new__(AVPipeline)
-    pipe.engine, pipe.mode = engine, MODE_BF16X3
+    pipe.engine, pipe.mode = engine, MODE_F16X3
     engine.load_static(sd_static); engine.load_dynamic(sd_dynamic); engine.load_audio(sd_audio)
     n, t = 128, 16
     frames = torch.from_numpy(synth.face_frames(31337, n * t).reshape(n, t, 224, 224, 3)).to(engine.device)

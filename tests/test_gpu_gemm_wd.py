@@ -1,4 +1,4 @@
-"""The weights-direct form of the split-bf16 contraction (avcer_conv_gemm dtype 7 / 8, gemm.hip conv_gemm_wd_kernel)
+"""The weights-direct form of the split-fp16 contraction (avcer_conv_gemm dtype 7 / 8, gemm.hip conv_gemm_wd_kernel)
 against the LDS-staged form (dtype 5 / 6) it stands in for: the same product order per output element, so the results are
 required to be BIT-IDENTICAL, on every gather path (plain matrix, padded 3x3 with border positions, strided 1x1,
 un-padded multi-tap Conv1d with dilation, the channel-chunk-major K order, a second activation source), every epilogue
@@ -7,7 +7,8 @@ The staged form itself is checked against float64 in tests/test_gpu_kernels.py."
 import pytest
 import torch
 
-from test_gpu_kernels import _desc, from_sp32, to_sp32
+from avcer_amd.sp32 import from_sp32, to_sp32
+from test_gpu_kernels import _desc
 
 pytestmark = pytest.mark.gpu
 

@@ -5,6 +5,7 @@ import torch
 import torch.nn.functional as F
 
 from avcer_amd._lib import ConvDesc
+from avcer_amd.sp32 import from_sp32, split_weight_mul, to_sp32
 
 pytestmark = pytest.mark.gpu
 
@@ -23,23 +24,6 @@ def _desc(**kw):
 
 def _act(v, act):
     return F.relu(v) if act == 1 else (F.gelu(v) if act in (2, 3) else v)
-
-
-def to_sp32(x):
-    """f32 [..., C] -> sp32 storage as int16 [..., 2C]: per group of 32 channels, 32 bf16 hi then 32 bf16 lo."""
-    hi = x.to(torch.bfloat16)
-    lo = (x - hi.float()).to(torch.bfloat16)
-    c = x.shape[-1]
-    h = hi.contiguous().view(torch.int16).reshape(*x.shape[:-1], c // 32, 32)
-    l = lo.contiguous().view(torch.int16).reshape(*x.shape[:-1], c // 32, 32)
-    return torch.cat([h, l], dim=-1).reshape(*x.shape[:-1], 2 * c).contiguous()
-
-
-def from_sp32(s):
-    g = s.contiguous().reshape(*s.shape[:-1], s.shape[-1] // 64, 64)
-    hi = g[..., :32].contiguous().view(torch.bfloat16).float()
-    lo = g[..., 32:].contiguous().view(torch.bfloat16).float()
-    return (hi + lo).reshape(*s.shape[:-1], s.shape[-1] // 2)
 
 
 A_KIND = {0: "f32", 1: "bf16", 2: "bf16", 3: "f32", 4: "f32", 5: "sp32", 6: "sp32"}
@@ -63,7 +47,7 @@ def _run(engine, d, dtype, x, w, scale, bias, res, y):
     ak, ok = A_KIND[dtype], O_KIND[dtype]
     xd = _enc(x, ak, dev)
     wd = w.to(dev, torch.bfloat16 if ak == "bf16" else torch.float32).contiguous()
-    # split-bf16 arithmetic: bf16 hi/lo split of the f32 weights, rows permuted inside groups of 32 output channels
+    # x3 arithmetic: scaled fp16 hi/lo split of the f32 weights, rows permuted inside groups of 32 output channels
     w_arg = engine.split_weight_rows(wd.reshape(wd.shape[0], -1)) if dtype >= 3 else wd
     sd_ = None if scale is None else scale.to(dev, torch.float32)
     bd = None if bias is None else bias.to(dev, torch.float32)
@@ -193,8 +177,9 @@ def test_bad_shapes_are_rejected(engine):
         engine.conv_gemm(d, 0, x, x, None, None, None, x)
 
 
-def test_split_bf16_is_far_more_accurate_than_bf16(engine):
-    """The split-bf16 contraction must sit at f32-grade error, two orders below plain bf16."""
+def test_split_fp16_is_f32_grade_and_far_more_accurate_than_bf16(engine):
+    """The x3 contraction (fp16 hi/lo pairs, three MFMAs per product) must sit at the f32 MFMA's own error, three orders
+    below plain bf16 (the bf16 split of rounds 1-3 read 30 x the f32 error here)."""
     g = torch.Generator().manual_seed(3)
     m, k, n = 512, 1024, 256
     x, w = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5
@@ -204,8 +189,8 @@ def test_split_bf16_is_far_more_accurate_than_bf16(engine):
     for dtype in (0, 2, 3):
         y, *_ = _run(engine, d, dtype, x, w, None, None, None, torch.zeros(m, n))
         errs[dtype] = float((y.double() - ref).abs().max())
-    print("max|err| f32 / bf16 / split-bf16:", errs)
-    assert errs[3] < 30 * errs[0] + 1e-6 and errs[3] < errs[2] / 50
+    print("max|err| f32 / bf16 / split-fp16:", errs)
+    assert errs[3] < 3 * errs[0] + 1e-7 and errs[3] < errs[2] / 1000
 
 
 @pytest.mark.parametrize("dtype", [0, 2, 3, 6])
@@ -406,11 +391,17 @@ def test_split_weight_rows_layout(engine):
     """avcer_split_weight_rows: hi/lo per 32-element K group + the row order of packing.permute_rows_for_mfma."""
     from avcer_amd.packing import permute_rows_for_mfma
 
-    w = torch.randn(96, 64, generator=torch.Generator().manual_seed(1))
-    got = from_sp32(engine.split_weight_rows(w).cpu().reshape(96, 128))
-    ref = torch.from_numpy(permute_rows_for_mfma(w.numpy()))
-    assert (got - ref).abs().max() < 2e-5 and (got - ref).abs().max() > 0      # hi + lo is not exactly f32
+    w = torch.randn(96, 64, generator=torch.Generator().manual_seed(1)) * 0.03
+    buf = engine.split_weight_rows(w).cpu()
+    mul = split_weight_mul(buf, 96, 64)
+    # one power of two per matrix: the largest magnitude lands in [2^14, 2^15)
+    assert mul == 2.0 ** round(np.log2(mul)) and 2 ** 14 <= w.abs().max().item() / mul < 2 ** 15
+    got = from_sp32(buf[:96 * 128].reshape(96, 128))
+    ref = torch.from_numpy(permute_rows_for_mfma(w.numpy())) / mul
+    assert (got - ref).abs().max() <= 2.0 ** -22 * ref.abs().max()             # 11 + 11 significand bits
     assert torch.equal(from_sp32(to_sp32(ref)), got)
+    # the fragment-order copy carries the same trailer
+    assert split_weight_mul(engine.weight_frags(w).cpu(), 96, 64) == mul
 
 
 def test_bneck_chain_first_block_with_downsample(engine):
@@ -446,7 +437,7 @@ def test_bneck_chain_first_block_with_downsample(engine):
 
 def test_stem_pool_vs_float64(engine):
     """conv 7x7/2 with TF-"same" padding (2 before, 3 after) + BN + ReLU + max-pool 3x3/2 (video.py:63-90,98-103,116-117) in
-    one launch, from the planar bf16 hi/lo image, against float64 torch ops."""
+    one launch, from the planar fp16 hi/lo image, against float64 torch ops."""
     g = torch.Generator().manual_seed(11)
     n = 3
     img = torch.randn(n, 3, 224, 224, generator=g) * 60.0                 # preprocessed BGR - mean values
@@ -455,11 +446,11 @@ def test_stem_pool_vs_float64(engine):
     x = F.pad(img.double(), (2, 3, 2, 3))
     ref = F.max_pool2d(F.relu(F.conv2d(x, w.double(), stride=2) * scale.double()[None, :, None, None] + bias.double()[None, :, None, None]),
                        3, 2)                                               # [n, 64, 55, 55]
-    # zero-bordered NHWC4 image (border = the padding, 4th channel 0), split into bf16 hi / lo planes
+    # zero-bordered NHWC4 image (border = the padding, 4th channel 0), split into fp16 hi / lo planes
     pad = torch.zeros(n, 230, 230, 4)
     pad[:, 2:226, 2:226, :3] = img.permute(0, 2, 3, 1)
-    hi = pad.to(torch.bfloat16)
-    lo = (pad - hi.float()).to(torch.bfloat16)
+    hi = pad.to(torch.float16)
+    lo = (pad - hi.float()).to(torch.float16)
     planes = torch.stack([hi.view(torch.int16), lo.view(torch.int16)])
     w7 = torch.zeros(64, 7, 8, 4)
     w7[:, :, :7, :3] = w.permute(0, 2, 3, 1)                               # [O][kh][kw][I] with kw, I zero-padded to 8 x 4
@@ -505,3 +496,48 @@ def test_stem_pool_from_u8_frames_vs_float64(engine, hw):
     err = (got - ref).abs().max().item()
     print(f"stem_pool_u8 {h}x{w_}: max|err| {err:.2e} (max|ref| {ref.abs().max().item():.1f})")
     assert err < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+# ---- range contract of the fp16 split (csrc/split_dev.h): activations unscaled, |x| < 65504; overflow -> NaN, never garbage
+@pytest.mark.parametrize("dtype", [5, 7])
+def test_x3_keeps_f32_grade_accuracy_with_activations_near_1e4(engine, dtype):
+    """sp32 activations of magnitude 1e4 (fp16 tops out at 65504) through a contraction whose outputs are of that order
+    too: the error stays at the f32 MFMA's level relative to the result."""
+    g = torch.Generator().manual_seed(5)
+    m, k, n = 384, 512, 256
+    x = torch.rand(m, k, generator=g) * 3.0e4                      # 0 .. 3e4
+    w = torch.randn(n, k, generator=g) / k                         # outputs: rms ~ 7e2, max ~ 4e3
+    bias = torch.randn(n, generator=g) * 1.0e4
+    d = _desc(batch=m, cin=k, x_stride_b=k, x_stride_h=k, x_stride_w=k, n=n, y_ld=n, r_ld=n, act=1)
+    dev = engine.device
+    xd = to_sp32(x).to(dev)
+    yd = torch.zeros(m, 2 * n, dtype=torch.int16, device=dev)
+    w_arg = engine.weight_frags(w.to(dev)) if dtype == 7 else engine.split_weight_rows(w.to(dev))
+    engine.conv_gemm(d, dtype, xd, w_arg, None, bias.to(dev), None, yd)
+    torch.cuda.synchronize()
+    ref = F.relu(from_sp32(xd.cpu()).double() @ w.double().t() + bias.double())
+    got = from_sp32(yd.cpu()).double()
+    assert ref.max() > 2.0e4 and torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    print(f"dtype {dtype}: activations up to 3e4, outputs up to {ref.max().item():.0f}: max|err| {err:.2e}")
+    assert err < 2e-6 * ref.abs().max().item()
+
+
+def test_x3_overflow_is_nan_not_a_wrong_number(engine):
+    """An sp32 OUTPUT beyond fp16's range: hi = +-inf, lo = x - inf = -+inf, hi + lo = NaN for every consumer."""
+    m, k, n = 128, 64, 64
+    x = torch.full((m, k), 2.0e3)
+    w = torch.ones(n, k)                                            # outputs 1.28e5 > 65504
+    w[1::2] *= 0.25                                                 # odd channels 3.2e4: representable
+    d = _desc(batch=m, cin=k, x_stride_b=k, x_stride_h=k, x_stride_w=k, n=n, y_ld=n, r_ld=n)
+    dev = engine.device
+    yd = torch.zeros(m, 2 * n, dtype=torch.int16, device=dev)
+    engine.conv_gemm(d, 5, to_sp32(x).to(dev), engine.split_weight_rows(w.to(dev)), None, None, None, yd)
+    torch.cuda.synchronize()
+    got = from_sp32(yd.cpu())
+    assert torch.isnan(got[:, 0::2]).all() and (got[:, 1::2] == 3.2e4).all()
+    # ... and as the INPUT of the next contraction the NaN spreads to every output that reads it
+    y2 = torch.zeros(m, n, device=dev)
+    engine.conv_gemm(d, 6, yd, engine.split_weight_rows(torch.ones(n, n, device=dev)), None, None, None, y2)
+    torch.cuda.synchronize()
+    assert torch.isnan(y2).all()

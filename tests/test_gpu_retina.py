@@ -6,7 +6,7 @@ import torch
 
 from avcer_amd import face_tiles as ft
 from avcer_amd import synth
-from avcer_amd.engine import MODE_BF16, MODE_BF16X3, MODE_FP32
+from avcer_amd.engine import MODE_BF16, MODE_F16X3, MODE_FP32
 from oracle import face as of
 from oracle import retina as orf
 
@@ -25,7 +25,7 @@ def engine_face(engine, sd_retina):
 
 
 @pytest.mark.parametrize("name", ["a", "b"])
-@pytest.mark.parametrize("mode,tol", [(MODE_FP32, 1e-4), (MODE_BF16X3, 1e-4)])
+@pytest.mark.parametrize("mode,tol", [(MODE_FP32, 1e-4), (MODE_F16X3, 1e-4)])
 def test_network_matches_reference_class(engine_face, golden, name, mode, tol):
     g = golden("face_net")
     h, w = (int(v) for v in g[f"{name}_size"])
@@ -73,7 +73,7 @@ def test_predictor_chain_matches_oracle_chain(engine_face, sd_retina):
 
 def test_batch_equals_frame_by_frame(engine_face, sd_retina):
     frames = synth.video_frames(11, 4, 96, 128)
-    pred = ft.RetinaFacePredictor(engine_face, sd_retina, threshold=0.3, mode=MODE_BF16X3)
+    pred = ft.RetinaFacePredictor(engine_face, sd_retina, threshold=0.3, mode=MODE_F16X3)
     together = pred.batch(frames, rgb=False)
     for t in range(4):
         np.testing.assert_array_equal(together[t], pred(frames[t], rgb=False))

@@ -6,7 +6,7 @@ import torch
 
 from avcer_amd import run as arun
 from avcer_amd import synth
-from avcer_amd.engine import MODE_BF16X3, MODE_FP32
+from avcer_amd.engine import MODE_F16X3, MODE_FP32
 from avcer_amd.fusion import WEIGHTS_AV_1
 from oracle import audio as oa
 from oracle import face as oface
@@ -25,7 +25,7 @@ def engine_all(engine, sd_static, sd_dynamic, sd_audio):
     return engine
 
 
-@pytest.mark.parametrize("mode,tol", [(MODE_FP32, 1e-4), (MODE_BF16X3, 1e-4)])
+@pytest.mark.parametrize("mode,tol", [(MODE_FP32, 1e-4), (MODE_F16X3, 1e-4)])
 def test_run_inference_matches_oracle_chain(engine_all, sd_static, sd_dynamic, sd_audio, tmp_path, mode, tol):
     frames, script = golden_frames(), golden_script()
     total, fps, sr = len(frames), 25, 16000

@@ -4,7 +4,8 @@ import pytest
 import torch
 
 from avcer_amd import synth, video_pipeline
-from avcer_amd.engine import MODE_BF16, MODE_BF16X3, MODE_FP32
+from avcer_amd.engine import MODE_BF16, MODE_F16X3, MODE_FP32
+from avcer_amd.sp32 import raw_to_f32
 from oracle import video as ov
 
 pytestmark = pytest.mark.gpu
@@ -52,11 +53,8 @@ def test_static_stage_taps_fp32(engine_static, sd_static):
 
 
 def _sp32_to_f32(raw_i16: torch.Tensor, shape):
-    """Decode an sp32 tensor (per 32 channels: 32 bf16 hi then 32 bf16 lo; value = hi + lo) tapped as raw int16."""
-    c = shape[-1]
-    v = raw_i16.view(-1, c // 32, 2, 32).to(torch.int32)
-    f = (v << 16).view(torch.float32)
-    return (f[:, :, 0] + f[:, :, 1]).reshape(shape)
+    """Decode an sp32 tensor (per 32 channels: 32 fp16 hi then 32 fp16 lo; value = hi + lo) tapped as raw int16."""
+    return raw_to_f32(raw_i16, shape)
 
 
 def test_static_stage_taps_x3(engine_static, sd_static):
@@ -70,7 +68,7 @@ def test_static_stage_taps_x3(engine_static, sd_static):
     for name in ("stem", "layer1", "layer2", "layer3", "layer4"):
         ref = _nhwc(taps[name]) if name == "stem" else _stage_out(taps, name)
         dst = engine_static.debug_tap(name, ref.numel() * 2, dtype=torch.int16)
-        engine_static.static_forward(torch.from_numpy(frames), MODE_BF16X3)
+        engine_static.static_forward(torch.from_numpy(frames), MODE_F16X3)
         torch.cuda.synchronize()
         assert engine_static.debug_tap_copied() == ref.numel() * 4, name
         got = _sp32_to_f32(dst.cpu(), ref.shape)
@@ -95,11 +93,11 @@ def test_static_matches_golden_and_oracle_fp32(engine_static, sd_static, golden)
 
 
 def test_static_split_bf16_meets_parity_gate(engine_static, golden):
-    """AVCER_MODE_BF16X3 (bf16 MFMA on hi/lo-split operands) must satisfy the same 1e-4 gate as the f32 mode."""
+    """AVCER_MODE_F16X3 (bf16 MFMA on hi/lo-split operands) must satisfy the same 1e-4 gate as the f32 mode."""
     g = golden("static")
     frames = synth.face_frames(1234, 8)
-    logits, probs, feats = [t.cpu().numpy() for t in engine_static.static_forward(torch.from_numpy(frames), MODE_BF16X3)]
-    print("static split-bf16 max|dprob|", np.abs(probs - g["probs"]).max(), "max|dlogit|", np.abs(logits - g["logits"]).max())
+    logits, probs, feats = [t.cpu().numpy() for t in engine_static.static_forward(torch.from_numpy(frames), MODE_F16X3)]
+    print("static split-fp16 max|dprob|", np.abs(probs - g["probs"]).max(), "max|dlogit|", np.abs(logits - g["logits"]).max())
     assert np.abs(probs - g["probs"]).max() < PROB_TOL
     assert (probs.argmax(1) == g["probs"].argmax(1)).all()
 
@@ -122,8 +120,8 @@ def test_static_resize_path(engine_static, sd_static):
         x = ov.pth_processing(np.stack([ov.nearest_resize_u8(f) for f in odd]))
         lg, _ = ov.resnet50_forward(sd_static, x)
         ref = torch.softmax(lg, 1).numpy()
-    # the f32 mode resizes in the preprocessing launch, the split-bf16 mode inside the fused stem (fused.hip stem_pool_u8_kernel)
-    for mode in (MODE_FP32, MODE_BF16X3):
+    # the f32 mode resizes in the preprocessing launch, the split-fp16 mode inside the fused stem (fused.hip stem_pool_u8_kernel)
+    for mode in (MODE_FP32, MODE_F16X3):
         _, probs, _ = engine_static.static_forward(torch.from_numpy(odd), mode)
         assert np.abs(probs.cpu().numpy() - ref).max() < PROB_TOL, mode
 
@@ -133,8 +131,8 @@ def test_stage3_tail_ragged_rows_match_whole_batch(engine_static):
     128-row tile: 21 frames = 4116 positions = 32 tiles + 20 rows.  The rows of the ragged last tile are bit-identical to
     the same frames inside a larger call (rows past M are dropped by the store descriptor, never written elsewhere)."""
     frames = torch.from_numpy(synth.face_frames(5, 40))
-    big = [t.cpu() for t in engine_static.static_forward(frames, MODE_BF16X3)]
-    part = [t.cpu() for t in engine_static.static_forward(frames[:21], MODE_BF16X3)]
+    big = [t.cpu() for t in engine_static.static_forward(frames, MODE_F16X3)]
+    part = [t.cpu() for t in engine_static.static_forward(frames[:21], MODE_F16X3)]
     assert all(torch.equal(a[:21], b) for a, b in zip(big, part))
 
 
@@ -182,11 +180,11 @@ def test_visual_harness_matches_reference_tables(engine_static, engine_dynamic, 
 
 def test_lstm_split_bf16_mode(engine, sd_dynamic, golden):
     """x3 projections (f32 state): still f32-grade against the reference LSTM."""
-    from avcer_amd.engine import MODE_BF16X3
+    from avcer_amd.engine import MODE_F16X3
     engine.load_dynamic(sd_dynamic)
     w = np.maximum(synth.centered(5, "lstm_in", (4, 10, 512), 1.0), 0).astype(np.float32)
     w[0] = w[0, 0]
-    out = engine.dynamic_forward(torch.from_numpy(w), MODE_BF16X3).cpu().numpy()
+    out = engine.dynamic_forward(torch.from_numpy(w), MODE_F16X3).cpu().numpy()
     d = np.abs(out - golden("lstm")["logits"]).max()
     print("lstm x3 max|dlogit|", d)
     assert d < 2e-5  # measured 1.8e-6

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the two forms of the split-bf16 contraction on the hot path's layer shapes, interleaved in ONE process
+"""A/B of the two forms of the split-fp16 contraction on the hot path's layer shapes, interleaved in ONE process
 (rule: never compare timings taken in different processes or on different boxes):
 
     staged   avcer_conv_gemm dtype 5 / 6  (A and W tiles through LDS, conv_gemm_kernel<3, *, *>)

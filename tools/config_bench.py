@@ -10,9 +10,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avcer_amd import synth  # noqa: E402
-from avcer_amd.engine import MODE_BF16, MODE_BF16X3, MODE_FP32, Engine  # noqa: E402
+from avcer_amd.engine import MODE_BF16, MODE_F16X3, MODE_FP32, Engine  # noqa: E402
 
-MODES = (("fp32", MODE_FP32, 157.3, 1), ("bf16", MODE_BF16, 2500.0, 1), ("x3", MODE_BF16X3, 2500.0, 3))
+MODES = (("fp32", MODE_FP32, 157.3, 1), ("bf16", MODE_BF16, 2500.0, 1), ("x3", MODE_F16X3, 2500.0, 3))
 
 
 def timeit(fn, iters=5):

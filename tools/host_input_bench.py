@@ -11,12 +11,12 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from avcer_amd import synth  # noqa: E402
-from avcer_amd.engine import MODE_BF16X3  # noqa: E402
+from avcer_amd.engine import MODE_F16X3  # noqa: E402
 from avcer_amd.pipeline import AVPipeline  # noqa: E402
 
 if __name__ == "__main__":
     clips, steps, warmup = 128, 5, 2
-    pipe = AVPipeline(0, seed=42, mode=MODE_BF16X3)
+    pipe = AVPipeline(0, seed=42, mode=MODE_F16X3)
     dev = pipe.engine.device
     h_frames = torch.from_numpy(synth.face_frames(1234, clips * bench.T_FRAMES).reshape(clips, bench.T_FRAMES, 224, 224, 3)).pin_memory()
     h_wav = torch.from_numpy(synth.waveforms(5678, clips, bench.T_AUDIO)).pin_memory()

@@ -14,7 +14,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avcer_amd import synth  # noqa: E402
-from avcer_amd.engine import MODE_BF16X3  # noqa: E402
+from avcer_amd.engine import MODE_F16X3  # noqa: E402
 from avcer_amd.pipeline import AVPipeline  # noqa: E402
 from avcer_amd.video_pipeline import visual_forward  # noqa: E402
 
@@ -25,8 +25,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
-    p1 = AVPipeline(device=0, seed=42, mode=MODE_BF16X3)
-    p2 = AVPipeline(device=0, seed=42, mode=MODE_BF16X3)
+    p1 = AVPipeline(device=0, seed=42, mode=MODE_F16X3)
+    p2 = AVPipeline(device=0, seed=42, mode=MODE_F16X3)
     frames = torch.from_numpy(synth.face_frames(1234, a.clips * 16)).reshape(a.clips, 16, 224, 224, 3).to(dev)
     wav = torch.from_numpy(synth.waveforms(5678, a.clips, 32000)).to(dev)
     present = np.ones((a.clips, 16), bool)
@@ -46,10 +46,10 @@ def main():
         s_aud.wait_stream(main_s)
         s_v2.wait_stream(main_s)
         with torch.cuda.stream(s_aud):
-            aud = p1.engine.audio_forward(wav, normalize=True, mode=MODE_BF16X3)
+            aud = p1.engine.audio_forward(wav, normalize=True, mode=MODE_F16X3)
         with torch.cuda.stream(s_v2):
-            st2, dy2 = visual_forward(p2.engine, frames[h:], present[h:], 25, MODE_BF16X3)
-        st1, dy1 = visual_forward(p1.engine, frames[:h], present[:h], 25, MODE_BF16X3)
+            st2, dy2 = visual_forward(p2.engine, frames[h:], present[h:], 25, MODE_F16X3)
+        st1, dy1 = visual_forward(p1.engine, frames[:h], present[:h], 25, MODE_F16X3)
         main_s.wait_stream(s_aud)
         main_s.wait_stream(s_v2)
         return torch.cat([st1, st2]), torch.cat([dy1, dy2]), aud
@@ -59,10 +59,10 @@ def main():
         s_aud.wait_stream(main_s)
         s_v2.wait_stream(main_s)
         with torch.cuda.stream(s_aud):
-            a1 = p1.engine.audio_forward(wav[:h], normalize=True, mode=MODE_BF16X3)
+            a1 = p1.engine.audio_forward(wav[:h], normalize=True, mode=MODE_F16X3)
         with torch.cuda.stream(s_v2):
-            a2 = p2.engine.audio_forward(wav[h:], normalize=True, mode=MODE_BF16X3)
-        st, dy = visual_forward(p1.engine, frames, present, 25, MODE_BF16X3)
+            a2 = p2.engine.audio_forward(wav[h:], normalize=True, mode=MODE_F16X3)
+        st, dy = visual_forward(p1.engine, frames, present, 25, MODE_F16X3)
         main_s.wait_stream(s_aud)
         main_s.wait_stream(s_v2)
         return st, dy, torch.cat([a1, a2])

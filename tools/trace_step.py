@@ -16,10 +16,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def run():
     import torch
     from avcer_amd import synth
-    from avcer_amd.engine import MODE_BF16X3
+    from avcer_amd.engine import MODE_F16X3
     from avcer_amd.pipeline import AVPipeline
 
-    pipe = AVPipeline(device=0, seed=42, mode=MODE_BF16X3)
+    pipe = AVPipeline(device=0, seed=42, mode=MODE_F16X3)
     frames = torch.from_numpy(synth.face_frames(1234, 128 * 16)).reshape(128, 16, 224, 224, 3).cuda()
     wav = torch.from_numpy(synth.waveforms(5678, 128, 32000)).cuda()
     for _ in range(3):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Which rounding owns the error of the split-bf16 ("x3") contraction?  
+"""Which rounding owns the error of the split-fp16 ("x3") contraction?  (fp16 pairs since round 4.)
 
 For y = x @ w^T with post-ReLU-like x >= 0 and zero-mean w, against the float64 product of the SAME f32 inputs:
 
@@ -25,16 +25,16 @@ from avcer_amd._lib import ConvDesc  # noqa: E402
 from avcer_amd.engine import Engine  # noqa: E402
 
 
-def bf16_round(a: np.ndarray) -> np.ndarray:
-    """float32 -> nearest-even bfloat16, returned as float32."""
-    u = a.astype(np.float32).view(np.uint32).astype(np.uint64)
-    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
-    return r.astype(np.uint32).view(np.float32)
-
-
 def split(a):
-    h = bf16_round(a)
-    return h, bf16_round(a - h)
+    """f32 -> (hi, lo) fp16 pair as float32 arrays (numpy rounds to nearest even and keeps subnormals, like the GPU)."""
+    a = a.astype(np.float32)
+    h = a.astype(np.float16).astype(np.float32)
+    return h, (a - h).astype(np.float16).astype(np.float32)
+
+
+def weight_scale(w):
+    """The power of two avcer_split_weight_rows multiplies a matrix by: largest magnitude -> [2^14, 2^15)."""
+    return np.float32(2.0 ** (14 - int(np.floor(np.log2(np.abs(w).max())))))
 
 
 def linear_desc(m, k, n):
@@ -51,16 +51,17 @@ def main():
     eng = Engine(0)
     rng = np.random.default_rng(0)
     m, n = 2048, 128
-    print(f"{'K':>6} {'total':>10} {'operands':>10} {'dropped':>10} {'accum rms':>10} {'accum bias':>11} {'f32 MFMA':>10}")
-    for k in (64, 256, 1024, 2304, 4608):
-        x = np.maximum(rng.standard_normal((m, k)), 0).astype(np.float32)
+    print(f"{'K':>6} {'xscale':<7} {'total':>10} {'operands':>10} {'dropped':>10} {'accum rms':>10} {'accum bias':>11} {'f32 MFMA':>10}")
+    for k, xs in ((64, 1.0), (256, 1.0), (1024, 1.0), (2304, 1.0), (4608, 1.0), (1024, 0.02), (1024, 300.0)):
+        x = (np.maximum(rng.standard_normal((m, k)), 0) * xs).astype(np.float32)  # xs: activation scale (fp16 range probe)
         w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
         exact = x.astype(np.float64) @ w.astype(np.float64).T
         xh, xl = split(x)
-        wh, wl = split(w)
+        ws = weight_scale(w)
+        wh, wl = split(w * ws)
         f = np.float64
-        x3 = xh.astype(f) @ wh.astype(f).T + xh.astype(f) @ wl.astype(f).T + xl.astype(f) @ wh.astype(f).T
-        dropped = xl.astype(f) @ wl.astype(f).T
+        x3 = (xh.astype(f) @ wh.astype(f).T + xh.astype(f) @ wl.astype(f).T + xl.astype(f) @ wh.astype(f).T) / f(ws)
+        dropped = xl.astype(f) @ wl.astype(f).T / f(ws)
         xd, wd = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
         y3, y0 = torch.empty(m, n, device="cuda"), torch.empty(m, n, device="cuda")
         eng.conv_gemm(linear_desc(m, k, n), 3, xd, eng.split_weight_rows(wd), None, None, None, y3)
@@ -71,7 +72,7 @@ def main():
         rms = lambda e: np.sqrt((e ** 2).mean()) / s  # noqa: E731
         acc = g3 - x3
         bias = (acc * np.sign(exact)).mean() / s
-        print(f"{k:6d} {rms(g3 - exact):10.2e} {rms(x3 - exact):10.2e} {rms(dropped):10.2e} {rms(acc):10.2e} {bias:11.2e} "
+        print(f"{k:6d} x{xs:<6g} {rms(g3 - exact):10.2e} {rms(x3 - exact):10.2e} {rms(dropped):10.2e} {rms(acc):10.2e} {bias:11.2e} "
               f"{rms(g0 - exact):10.2e}")
 
 

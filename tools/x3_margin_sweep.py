@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The probability-gate sweep of tests/test_gpu_parity_breadth.py over MORE weight draws than the test takes (default 16
-seeds x logit scales 1 / 4 / 8, static CNN, 8 frames): how far the split-bf16 mode sits from the 1e-4 gate is a statistic,
+seeds x logit scales 1 / 4 / 8, static CNN, 8 frames): how far the split-fp16 mode sits from the 1e-4 gate is a statistic,
 and five seeds are a small sample of it.  Prints every case and the worst / median per scale.
 
     python tools/x3_margin_sweep.py [first_seed] [n_seeds]
@@ -15,7 +15,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from avcer_amd import synth  # noqa: E402
-from avcer_amd.engine import MODE_BF16X3, MODE_FP32, Engine  # noqa: E402
+from avcer_amd.engine import MODE_F16X3, MODE_FP32, Engine  # noqa: E402
 from oracle import video as ov  # noqa: E402
 
 
@@ -35,7 +35,7 @@ def main():
             with torch.no_grad():
                 ref_logits, _ = ov.resnet50_forward(synth.to_torch(sd), ov.pth_processing(frames))
                 ref = torch.softmax(ref_logits, 1).numpy()
-            for name, mode in (("fp32", MODE_FP32), ("x3", MODE_BF16X3)):
+            for name, mode in (("fp32", MODE_FP32), ("x3", MODE_F16X3)):
                 _, probs, _ = eng.static_forward(torch.from_numpy(frames), mode)
                 d = float(np.abs(probs.cpu().numpy() - ref).max())
                 res[(name, scale)].append(d)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-stage error of the static CNN in the split-bf16 (x3) and f32 modes against the CPU oracle, over weight seeds.
+"""Per-stage error of the static CNN in the split-fp16 (x3) and f32 modes against the CPU oracle, over weight seeds.
 
 For every seed: 8 frames, the stage taps (stem, layer1-4, avgpool), the fc1 features and the logits; printed as
 rms(err) / rms(ref) per tap and max |dlogit| -- where the x3 logit error is made, and how it compares with the f32
@@ -15,17 +15,15 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avcer_amd import synth  # noqa: E402
-from avcer_amd.engine import MODE_BF16X3, MODE_FP32, Engine  # noqa: E402
+from avcer_amd.engine import MODE_F16X3, MODE_FP32, Engine  # noqa: E402
+from avcer_amd.sp32 import raw_to_f32  # noqa: E402
 from oracle import video as ov  # noqa: E402
 
 TAPS = ("stem", "layer1", "layer2", "layer3", "layer4")
 
 
 def sp32_to_f32(raw_i16, shape):
-    c = shape[-1]
-    v = raw_i16.view(-1, c // 32, 2, 32).to(torch.int32)
-    f = (v << 16).view(torch.float32)
-    return (f[:, :, 0] + f[:, :, 1]).reshape(shape)
+    return raw_to_f32(raw_i16, shape)
 
 
 def main():
@@ -47,19 +45,19 @@ def main():
         with torch.no_grad():
             logits, feats = ov.resnet50_forward(tsd, ov.pth_processing(frames), taps)
             probs = torch.softmax(logits, 1)
-        for name, mode in (("fp32", MODE_FP32), ("x3", MODE_BF16X3)):
+        for name, mode in (("fp32", MODE_FP32), ("x3", MODE_F16X3)):
             rel = []
             for t in TAPS:
                 ref = taps[t].permute(0, 2, 3, 1).contiguous()
                 if t in ("layer1", "layer2", "layer3"):
                     ref = ref[:, ::2, ::2].contiguous()  # the library evaluates a stage's last block where the next stage reads it
-                if mode == MODE_BF16X3:
+                if mode == MODE_F16X3:
                     dst = eng.debug_tap(t, ref.numel() * 2, dtype=torch.int16)
                 else:
                     dst = eng.debug_tap(t, ref.numel())
                 eng.static_forward(ft, mode)
                 torch.cuda.synchronize()
-                got = sp32_to_f32(dst.cpu(), ref.shape) if mode == MODE_BF16X3 else dst.cpu().view(ref.shape)
+                got = sp32_to_f32(dst.cpu(), ref.shape) if mode == MODE_F16X3 else dst.cpu().view(ref.shape)
                 rel.append(((got - ref).double().pow(2).mean().sqrt() / ref.double().pow(2).mean().sqrt()).item())
             dst = eng.debug_tap("avgpool", taps["avgpool"].numel())
             lg, pr, fe = eng.static_forward(ft, mode)
