@@ -8,7 +8,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from .engine import Engine, MODE_FP32
+from .engine import Engine, MODE_DEFAULT
 
 EMO_AUDIO_8 = ("Neutral", "Anger", "Disgust", "Fear", "Happiness", "Sadness", "Surprise", "Other")  # :114-123
 
@@ -27,7 +27,7 @@ def chunk_spans(n_samples: int, sr: int, fps: float, window: float, step: float)
 
 
 def audio_forward(engine: Engine, wav: torch.Tensor, sr: int = 16000, fps: float = 25, window: float = 4,
-                  step: float = 0.5, padding: str = "mean", mode: int = MODE_FP32):
+                  step: float = 0.5, padding: str = "mean", mode: int = MODE_DEFAULT):
     """wav f32 [L] (mono, already at `sr`).  Returns (window_logits [n_win, C], frame_lo [n_win], frame_hi [n_win]).
     An empty tail window (len(wav) % (step*sr) == 0) yields NaN logits, as in the reference ('mean' padding of an
     empty chunk is NaN, data/utils.py:76-82)."""

@@ -596,15 +596,17 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
 //     [64 lanes][16 B], rows permuted like every split weight -- so a wave gets a whole fragment with ONE coalesced 1 KiB
 //     load straight into the registers the MFMA reads (inline asm: hipcc would otherwise drain the LDS-DMA queue for it);
 //   * only the activation tile goes through LDS (16 KiB per K-step instead of 32): a FOUR-slot ring fits twice per CU
-//     (64 KiB per block); the tile of step s+2 is requested at the top of step s and stays in flight across the barrier;
+//     (64 KiB per block); the tile of step s+2 is requested in the second half of step s and stays in flight across the
+//     step boundary;
 //   * 128 x 256 tiles, the four waves side by side along n, each owning all 128 positions x 64 channels: nobody loads a
 //     weight fragment twice and one LDS fragment read feeds 12 MFMAs (the 2 x 2 form: 6); the fragments of 16 positions are
 //     read while the 12 MFMAs of the previous 16 run (two register pairs, ping-pong) -- across K-steps too: the step's one
 //     barrier sits in the MIDDLE of its MFMA work, so the step boundary is seamless (no wait, no exposed LDS latency).
 // Same product order per output element as conv_gemm_kernel<3, *, *>: bit-identical results (tests/test_gpu_gemm_wd.py).
-// Vector-memory operations of a wave, in issue order: prologue A(0) W(0) A(1); step s: W(s+1) [8 loads], A(s+2) [4 DMA
-// pieces].  Two counted waits per step: vmcnt(12) in front of the mid-step barrier (A(s+1), issued a step earlier, has
-// landed; this step's 12 operations may still fly) and vmcnt(4) at the end (W(s+1) is in its registers).  Past the end of
+// Vector-memory operations of a wave, in issue order: prologue A(0) W(0) A(1); step s: W(s+1) [8 loads, two in front of
+// each of the first four tiles' MFMAs], A(s+2) [4 DMA pieces, in front of the last four tiles'].  Two counted waits per step:
+// vmcnt(8) in front of the mid-step barrier (A(s+1), issued in the second half of the step before, has landed; this step's 8
+// weight loads may still fly) and vmcnt(4) at the end (W(s+1) is in its registers; the 4 pieces may fly).  Past the end of
 // K the same operations are issued on dummy targets (out-of-range DMA = zeros into a free slot, a repeated weight load into
 // dead registers), so the count is exact.  The K position is a handful of scalars advanced by additions; GATHER selects the
 // activation addressing at compile time: 0 = plain matrix (every Linear and 1x1 convolution: one tap, no padding), 1 = the
@@ -673,9 +675,6 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
     }
     const int m_base = tile_m * BMT, n_base = tile_n * BN;
     const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.X), (short)0, (int)p.x_bytes, 0x00020000);
-    const auto x2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(GATHER == 1 ? p.X2 : p.X), (short)0,
-                                                        (int)(GATHER == 1 ? p.x2_bytes : p.x_bytes), 0x00020000);
-    (void)x2rs;
     typedef __attribute__((ext_vector_type(4))) int i32x4_t;
     i32x4_t wfrs;
     {
@@ -729,69 +728,77 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
     unsigned a_so = 0, x2_so = 0, wk = 0, w_saved = 0;
     int islot = 0;  // ring slot of the next A issue
 
+// the two loads (hi, lo) of n tile FN of the NEXT K-step's weight fragments
+#define AVCER_WD_LOAD_W1(WH, WL, FN)                                                                                    \
+    do {                                                                                                                \
+        const unsigned so_ = w_saved * 16u + (unsigned)(FN) * wstride; /* K-step index * 2048 + n tile */               \
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(WH[FN]) : "v"(wv0), "s"(wfrs), "s"(so_) : "memory"); \
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(WL[FN]) : "v"(wv0), "s"(wfrs), "s"(so_) : "memory"); \
+    } while (0)
 #define AVCER_WD_LOAD_W(WH, WL)                                                                                         \
     do {                                                                                                                \
-        unsigned so_ = w_saved * 16u; /* K-step index * 2048 */                                                         \
-        _Pragma("unroll") for (int fn = 0; fn < NFN; ++fn) {                                                             \
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(WH[fn]) : "v"(wv0), "s"(wfrs), "s"(so_) : "memory"); \
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(WL[fn]) : "v"(wv0), "s"(wfrs), "s"(so_) : "memory"); \
-            so_ += wstride;                                                                                             \
+        _Pragma("unroll") for (int fn = 0; fn < NFN; ++fn) AVCER_WD_LOAD_W1(WH, WL, fn);                                 \
+    } while (0)
+// One 1 KiB piece (8 rows) J of the activation tile of K-step T, into ring slot islot.  ONE DMA instruction whatever T is
+// (no branch: tools/audit_asm_loads.py counts the vector-memory operations of every path through the loop): past the end of
+// K (T >= nk) and for rows outside the image the per-lane offset is out of range -- the hardware writes zeros without
+// fetching --, and the second source of GATHER 1 is a wave-uniform choice of descriptor and scalar offset.
+#define AVCER_WD_ISSUE_A1(T, J)                                                                                         \
+    do {                                                                                                                \
+        char* sa_ = smem + islot * ABYTES + wave * 4096 + (J) * 1024;                                                   \
+        const bool live_ = (T) < nk;                                                                                    \
+        if constexpr (GATHER == 1) {                                                                                    \
+            const bool second_ = (T) >= n1; /* tail of K: the second source */                                          \
+            const auto rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(second_ ? p.X2 : p.X), (short)0,       \
+                                                               (int)(second_ ? p.x2_bytes : p.x_bytes), 0x00020000);    \
+            const unsigned vo_ = second_ ? a_off2k[GATHER == 1 ? (J) : 0] : a_offk[J];                                  \
+            dma16(rs_, sa_, live_ ? vo_ : OOB, second_ ? x2_so : a_so);                                                 \
+        } else if constexpr (GATHER == 3) {                                                                             \
+            const int iy = a_iy[GATHER == 3 ? (J) : 0] + ky * p.dh, ix = a_ix[GATHER == 3 ? (J) : 0] + kx * p.dw;       \
+            const bool ok = live_ & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.Wd);                   \
+            /* the tap offset goes into the per-lane offset: the hardware bounds test ignores the scalar offset, and */ \
+            /* a border row's base offset is negative (wrapped) until its tap is added                              */ \
+            dma16(xrs, sa_, ok ? a_offk[J] + a_so : OOB);                                                               \
+        } else {                                                                                                        \
+            dma16(xrs, sa_, live_ ? a_offk[J] : OOB, a_so);                                                             \
         }                                                                                                               \
     } while (0)
-// T >= nk: past the end of K -- four out-of-range DMA pieces (zeros into the free slot) keep the count exact
-#define AVCER_WD_ISSUE_A(T)                                                                                             \
+// behind the last piece of K-step T: the ring slot and the K position (a handful of scalars) move on
+#define AVCER_WD_ADVANCE_A(T)                                                                                           \
     do {                                                                                                                \
-        char* sa_ = smem + islot * ABYTES + wave * 4096;                                                                \
         islot = islot == STAGES - 1 ? 0 : islot + 1;                                                                    \
-        if ((T) >= nk) {                                                                                                \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) dma16(xrs, sa_ + j * 1024, OOB);                               \
-        } else {                                                                                                        \
+        if ((T) < nk) {                                                                                                 \
             w_saved = wk;                                                                                               \
-            if constexpr (GATHER == 0) { /* plain matrix: one tap, channels in order */                                 \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) dma16(xrs, sa_ + j * 1024, a_offk[j], a_so);               \
-                a_so += ROWB;                                                                                           \
-                wk += ROWB;                                                                                             \
-            } else if (GATHER == 1 && (T) >= n1) { /* tail of K: the second source */                                   \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) dma16(x2rs, sa_ + j * 1024, a_off2k[GATHER == 1 ? j : 0], x2_so); \
+            if (GATHER == 1 && (T) >= n1) {                                                                             \
                 x2_so += ROWB;                                                                                          \
                 wk += ROWB;                                                                                             \
-            } else if constexpr (GATHER == 1) {                                                                         \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) dma16(xrs, sa_ + j * 1024, a_offk[j], a_so);               \
+            } else if constexpr (GATHER <= 1) { /* plain matrix: one tap, channels in order */                          \
                 a_so += ROWB;                                                                                           \
                 wk += ROWB;                                                                                             \
-            } else {                                                                                                    \
-                if constexpr (GATHER == 3) {                                                                            \
-                    const int dy = ky * p.dh, dx = kx * p.dw;                                                           \
-                    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
-                        const int iy = a_iy[GATHER == 3 ? j : 0] + dy, ix = a_ix[GATHER == 3 ? j : 0] + dx;             \
-                        const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.Wd);               \
-                        /* the tap offset goes into the per-lane offset: the hardware bounds test ignores the scalar */ \
-                        /* offset, and a border row's base offset is negative (wrapped) until its tap is added        */ \
-                        dma16(xrs, sa_ + j * 1024, ok ? a_offk[j] + a_so : OOB);                                        \
-                    }                                                                                                   \
-                } else {                                                                                                \
-                    _Pragma("unroll") for (int j = 0; j < 4; ++j) dma16(xrs, sa_ + j * 1024, a_offk[j], a_so);           \
+            } else if (p.tap_inner) { /* (channel chunk, ky, kx) order: the next tap of the same chunk */               \
+                a_so += p.tapW4;                                                                                        \
+                wk += cin4;                                                                                             \
+                if (++kx == p.KW) {                                                                                     \
+                    kx = 0;                                                                                             \
+                    a_so += p.tapH4 - p.KW * p.tapW4;                                                                   \
+                    if (++ky == p.KH) { ky = 0; a_so += ROWB - p.KH * p.tapH4; kc4 += ROWB; wk = (unsigned)kc4; }       \
                 }                                                                                                       \
-                if (p.tap_inner) { /* (channel chunk, ky, kx) order: the next tap of the same chunk */                  \
-                    a_so += p.tapW4;                                                                                    \
-                    wk += cin4;                                                                                         \
-                    if (++kx == p.KW) {                                                                                 \
-                        kx = 0;                                                                                         \
-                        a_so += p.tapH4 - p.KW * p.tapW4;                                                               \
-                        if (++ky == p.KH) { ky = 0; a_so += ROWB - p.KH * p.tapH4; kc4 += ROWB; wk = (unsigned)kc4; }   \
-                    }                                                                                                   \
-                } else { /* (ky, kx, channel chunk) order */                                                            \
-                    a_so += ROWB;                                                                                       \
-                    wk += ROWB;                                                                                         \
-                    kc4 += ROWB;                                                                                        \
-                    if (kc4 == cin4) {                                                                                  \
-                        kc4 = 0;                                                                                        \
-                        a_so += p.tapW4 - cin4;                                                                         \
-                        if (++kx == p.KW) { kx = 0; a_so += p.tapH4 - p.KW * p.tapW4; ++ky; }                           \
-                    }                                                                                                   \
+            } else { /* (ky, kx, channel chunk) order */                                                                \
+                a_so += ROWB;                                                                                           \
+                wk += ROWB;                                                                                             \
+                kc4 += ROWB;                                                                                            \
+                if (kc4 == cin4) {                                                                                      \
+                    kc4 = 0;                                                                                            \
+                    a_so += p.tapW4 - cin4;                                                                             \
+                    if (++kx == p.KW) { kx = 0; a_so += p.tapH4 - p.KW * p.tapW4; ++ky; }                               \
                 }                                                                                                       \
             }                                                                                                           \
         }                                                                                                               \
+    } while (0)
+#define AVCER_WD_ISSUE_A(T)                                                                                             \
+    do {                                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) AVCER_WD_ISSUE_A1(T, j);                                           \
+        AVCER_WD_ADVANCE_A(T);                                                                                          \
     } while (0)
 #define AVCER_WD_WAIT(N, H, L) asm volatile("s_waitcnt vmcnt(" #N ")" : AVCER_WREGS4(H, L)::"memory")
 #define AVCER_WD_READ(BASE, R, AH, AL)                                                                                  \
@@ -808,12 +815,15 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
         c_ = mfma_sp(whi, AL, c_);                                             \
         c_ = mfma_sp(whi, AH, c_);                                             \
     }
+// One K-step.  Its twelve vector-memory operations are SPREAD over the step instead of leading it (round 4): the two
+// loads of one n tile of W(S+1) in front of the MFMAs of each of the tiles 0-3, one piece of A(S+2) in front of those of
+// each of the last four tiles.  As a burst at the top of the step (96 operations per CU within a few hundred cycles) they
+// backed up the CU's one vector-memory pipe and the waves sat in ISSUE behind it with their MFMAs unissued: -2 ... -10 % time
+// per layer against the burst on the same box (profiles/experiments/r04_wd_ablate_*.txt).  Counted waits: vmcnt(8) in front
+// of the mid-step barrier (A(S+1), issued in the second half of step S-1, has landed; the 8 weight loads of this step may
+// fly), vmcnt(4) at the end (W(S+1) is in its registers, this step's four pieces may fly).
 #define AVCER_WD_STEP(S, PH, WH, WL, WHN, WLN)                                                                          \
     do {                                                                                                                \
-        AVCER_WD_LOAD_W(WHN, WLN);                                                                                      \
-        asm volatile("" ::: "memory");                                                                                  \
-        AVCER_WD_ISSUE_A((S) + 2);                                                                                      \
-        asm volatile("" ::: "memory");                                                                                  \
         const char* sa = smem + rslot * ABYTES;                                                                         \
         rslot = rslot == STAGES - 1 ? 0 : rslot + 1;                                                                    \
         const char* sa_next = smem + rslot * ABYTES;                                                                    \
@@ -827,15 +837,24 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
             __builtin_amdgcn_sched_barrier(0);                                                                          \
             if (t + 1 < NFM) AVCER_WD_READ(sa, t + 1, ah[nxt_], al[nxt_]);                                              \
             else AVCER_WD_READ(sa_next, 0, ah[nxt_], al[nxt_]);                                                         \
+            asm volatile("" ::: "memory");                                                                              \
+            if (t < NFN) {                                                                                              \
+                AVCER_WD_LOAD_W1(WHN, WLN, t);                                                                          \
+            } else { /* pieces 0..3 of A(S+2) at tiles 4 .. 7 (NFM = 7: tiles 4, 5 and, two pieces, 6) */               \
+                if (NFM == 8 || t < 6) { AVCER_WD_ISSUE_A1((S) + 2, t - NFN); }                                         \
+                else { AVCER_WD_ISSUE_A1((S) + 2, 2); AVCER_WD_ISSUE_A1((S) + 2, 3); }                                  \
+                if (t == NFM - 1) AVCER_WD_ADVANCE_A((S) + 2);                                                          \
+            }                                                                                                           \
+            asm volatile("" ::: "memory");                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
             AVCER_WD_MFMA(t, ah[cur_], al[cur_], WH, WL);                                                               \
             if (t == 3) {                                                                                               \
-                /* the step's one barrier, in the MIDDLE of its MFMA work: behind it the tile of step S+1 (issued a   */ \
-                /* step ago; still allowed in flight: the 8 weight loads and 4 DMA pieces issued at the top of this   */ \
-                /* step) is complete for every wave, and every wave has finished reading the slot of step S-1, which  */ \
-                /* the next issue overwrites (four slots: the one being read, the two in flight, the one just freed)  */ \
+                /* the step's one barrier, in the MIDDLE of its MFMA work: behind it the tile of step S+1 (issued in  */ \
+                /* the second half of the previous step) is complete for every wave, and every wave has finished      */ \
+                /* reading the slot of step S-1, which the pieces issued behind this barrier overwrite (four slots:   */ \
+                /* the one being read, the one that just landed, the one about to be filled, the one just freed)      */ \
                 __builtin_amdgcn_sched_barrier(0);                                                                      \
-                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                                       \
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                        \
                 __builtin_amdgcn_s_barrier();                                                                           \
                 asm volatile("" ::: "memory");                                                                          \
             }                                                                                                           \
@@ -869,6 +888,9 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
 #undef AVCER_WD_READ
 #undef AVCER_WD_WAIT
 #undef AVCER_WD_ISSUE_A
+#undef AVCER_WD_ISSUE_A1
+#undef AVCER_WD_ADVANCE_A
+#undef AVCER_WD_LOAD_W1
 #undef AVCER_WD_LOAD_W
     const int c0 = n_base + wave * (BN / 4);
     if (p.act == 3) wd_epilogue<OUT, 3, NFN, NFM>(p, acc, m_base, c0, lane, wmul);

@@ -25,6 +25,8 @@ import numpy as np
 import torch
 from scipy.optimize import linear_sum_assignment
 
+from .engine import MODE_DEFAULT
+
 # retina_face/config.py:22-39 (cfg_re50)
 CFG_RE50 = {"min_sizes": [[16, 32], [64, 128], [256, 512]], "steps": [8, 16, 32], "variance": [0.1, 0.2], "clip": False}
 
@@ -93,7 +95,7 @@ class RetinaFacePredictor:
     box decoding and the device-side filter / NMS / top-k (`FaceDetections`).  `state_dict` = RetinaFace(cfg_re50).state_dict() (the file
     `Resnet50_Final.pth`, with or without the `module.` prefix)."""
 
-    def __init__(self, engine, state_dict, threshold: float = 0.8, mode: int = 0):
+    def __init__(self, engine, state_dict, threshold: float = 0.8, mode: int = MODE_DEFAULT):
         self.engine, self.mode = engine, mode
         engine.load_face(state_dict)
         self.post = FaceDetections(engine, threshold=threshold)

@@ -12,13 +12,13 @@ from __future__ import annotations
 
 import torch
 
-from .engine import Engine, MODE_FP32
+from .engine import Engine, MODE_DEFAULT
 
 
 class StaticModel:
     """Drop-in for `pth_model_static` (architectures/video.py ResNet50(7) in eval mode)."""
 
-    def __init__(self, engine: Engine, state_dict, mode: int = MODE_FP32):
+    def __init__(self, engine: Engine, state_dict, mode: int = MODE_DEFAULT):
         self.engine, self.mode = engine, mode
         engine.load_static(state_dict)
         self.activations = {}
@@ -51,7 +51,7 @@ class StaticModel:
 class DynamicModel:
     """Drop-in for `pth_model_dynamic` (architectures/video.py LSTMPyTorch in eval mode)."""
 
-    def __init__(self, engine: Engine, state_dict, mode: int = 0):
+    def __init__(self, engine: Engine, state_dict, mode: int = MODE_DEFAULT):
         self.engine = engine
         self.mode = mode
         engine.load_dynamic(state_dict)
@@ -75,7 +75,7 @@ class AudioModel:
     """Drop-in for `audio_model` (architectures/audio_8_cl.py ExprModelV3 / audio_7_cl.py ExprModelV2, eval mode).
     Input is the already normalised window, exactly what the reference passes (get_prob_audio_8_cl.py:87-92)."""
 
-    def __init__(self, engine: Engine, state_dict, mode: int = MODE_FP32):
+    def __init__(self, engine: Engine, state_dict, mode: int = MODE_DEFAULT):
         self.engine, self.mode = engine, mode
         engine.load_audio(state_dict)
 

@@ -6,14 +6,14 @@ import numpy as np
 import torch
 
 from . import synth
-from .engine import Engine, MODE_FP32
+from .engine import Engine, MODE_DEFAULT
 from .fusion import WEIGHTS_AV_1, fuse_clips
 from .models import AudioModel, DynamicModel, StaticModel
 from .video_pipeline import visual_forward
 
 
 class AVPipeline:
-    def __init__(self, device: int = 0, seed: int = 42, state_dicts=None, mode: int = MODE_FP32, audio: bool = True):
+    def __init__(self, device: int = 0, seed: int = 42, state_dicts=None, mode: int = MODE_DEFAULT, audio: bool = True):
         """state_dicts = (static, dynamic, audio) in the reference's key names; None -> synthetic weights."""
         self.engine = Engine(device)
         self.mode = mode

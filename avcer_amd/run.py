@@ -15,7 +15,7 @@ import torch
 
 from . import io_formats
 from .audio_pipeline import audio_forward, replicate_per_frame
-from .engine import MODE_F16X3
+from .engine import MODE_DEFAULT
 from .face_tiles import VideoTiler, track_clip
 from .fusion import MODEL_ORDER, fuse
 from .video_pipeline import visual_forward
@@ -24,7 +24,7 @@ from .video_pipeline import visual_forward
 def run_inference(engine, frames_bgr, wav, fps: float, detector=None, detections: Optional[Sequence[np.ndarray]] = None,
                   path_save_results: str = "", name_video: str = "video", flag_save_prob: bool = False,
                   weights_prob_model=None, weights_model=(1, 1, 1), ce_weights_type: bool = True, ce_mask: bool = False,
-                  sr: int = 16000, window: float = 4, step: float = 0.5, padding: str = "mean", mode: int = MODE_F16X3):
+                  sr: int = 16000, window: float = 4, step: float = 0.5, padding: str = "mean", mode: int = MODE_DEFAULT):
     """engine: an `Engine` with the static, dynamic and audio weights loaded.  frames_bgr u8 [T,H,W,3] as cv2 decodes
     them; wav float32 [L] mono at `sr`; fps as `int(cv2.CAP_PROP_FPS)` gives it (get_face_images.py:23).
     `detector`: a `face_tiles.RetinaFacePredictor` (threshold 0.8 in the reference); or pass per-frame `detections`.

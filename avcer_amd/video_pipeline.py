@@ -12,7 +12,7 @@ from dataclasses import dataclass, field
 import numpy as np
 import torch
 
-from .engine import Engine, MODE_FP32
+from .engine import Engine, MODE_DEFAULT
 
 DICT_EMO_VIDEO = ("Neutral", "Happiness", "Sadness", "Surprise", "Fear", "Disgust", "Anger")  # get_prob_video.py:56-64
 
@@ -99,7 +99,7 @@ def _device_plan(engine: Engine, present: np.ndarray, fps: float) -> _DevicePlan
     return plan
 
 
-def visual_forward(engine: Engine, frames_u8: torch.Tensor, present, fps: float, mode: int = MODE_FP32):
+def visual_forward(engine: Engine, frames_u8: torch.Tensor, present, fps: float, mode: int = MODE_DEFAULT):
     """frames_u8 [N,T,H,W,3] (or [T,H,W,3]) RGB tiles, present [N,T] bool.
     Returns (static_probs [N,T,7], dynamic_logits [N,T,7]) float32 in VIDEO column order (DICT_EMO_VIDEO).
     The reference's tables turn float64 when they contain a zero placeholder row; the values are the same."""

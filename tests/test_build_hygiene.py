@@ -47,17 +47,50 @@ def test_library_reads_no_environment_and_exports_the_header():
         assert re.search(rf"\b{name}\b", defined), name
 
 
-def test_tail_kernel_asm_loaded_registers_are_untouched_until_their_wait(tmp_path):
-    """bneck_tail2_kernel loads its residual ring by inline asm, so only the counted `s_waitcnt vmcnt(4)` that names the
-    registers protects them; tools/audit_asm_loads.py checks the generated ISA for any earlier read or write."""
+def _audit_module():
     import importlib.util
 
-    asm = tmp_path / "fused.s"
-    flags = [f for f in build.FLAGS if f not in ("-fPIC", "-shared")]
-    r = subprocess.run([_hipcc()] + flags + ["-S", "--cuda-device-only", "-o", str(asm), os.path.join(CSRC, "fused.hip")],
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
     spec = importlib.util.spec_from_file_location("audit_asm_loads", os.path.join(os.path.dirname(CSRC), "..", "tools", "audit_asm_loads.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert mod.audit(str(asm)) == []
+    return mod
+
+
+@pytest.mark.parametrize("src,kernel,instances", [("fused.hip", "bneck_tail2_kernel", 1), ("gemm.hip", "conv_gemm_wd_kernel", 16)])
+def test_asm_loaded_registers_are_untouched_until_their_wait(src, kernel, instances, tmp_path):
+    """Every kernel that loads into VGPRs by inline asm (the residual ring of bneck_tail2_kernel, the weight fragments of all
+    sixteen conv_gemm_wd_kernel instantiations): only the kernel's counted `s_waitcnt vmcnt(N)` protects those registers, so
+    tools/audit_asm_loads.py walks the generated ISA's control-flow graph with the queue of outstanding vector-memory
+    operations as its state and checks that no instruction reads or writes a register with an asm load in flight."""
+    asm = tmp_path / (src + ".s")
+    flags = [f for f in build.FLAGS if f not in ("-fPIC", "-shared")]
+    r = subprocess.run([_hipcc()] + flags + ["-S", "--cuda-device-only", "-o", str(asm), os.path.join(CSRC, src)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    mod = _audit_module()
+    assert len(mod.kernels(str(asm), kernel)) == instances
+    assert mod.audit(str(asm), kernel) == []
+
+
+def test_the_asm_load_audit_catches_a_hazard(tmp_path):
+    """The audit on hand-written ISA: a use before the counted wait, a use on a path that skips the wait, an overwrite of
+    the destination and a missing drain are reported; the correct sequences are not."""
+    mod = _audit_module()
+
+    def run(body):
+        f = tmp_path / "k.s"
+        f.write_text("_Z9my_kernelv:\n" + body + "\n.Lfunc_end0:\n")
+        return mod.audit(str(f), "my_kernel")
+
+    load = ";;#ASMSTART\nbuffer_load_dwordx4 v[4:7], v1, s[0:3], s4 offen\n;;#ASMEND\n"
+    dma = "buffer_load_dwordx4 v1, s[0:3], 0 offen lds\n"
+    assert run(load + dma + "s_waitcnt vmcnt(1)\nv_mfma_f32_16x16x32_f16 v[8:11], v[4:7], v[12:15], v[8:11]\ns_endpgm") == []
+    assert any("touches" in p for p in run(load + dma + dma + "s_waitcnt vmcnt(3)\nv_add_f32 v9, v4, v4\ns_waitcnt vmcnt(0)\ns_endpgm"))
+    assert any("touches" in p for p in run(load + "v_mov_b32 v5, 0\ns_waitcnt vmcnt(0)\ns_endpgm"))          # overwritten in flight
+    assert any("s_endpgm" in p for p in run(load + "s_endpgm"))                                                   # never drained
+    # a loop whose back edge skips the wait on one path
+    loop = (".LBB0_1:\n" + load + "s_cbranch_scc1 .LBB0_2\ns_waitcnt vmcnt(0)\n.LBB0_2:\nv_add_f32 v9, v6, v6\n"
+            "s_cbranch_vccnz .LBB0_1\ns_waitcnt vmcnt(0)\ns_endpgm")
+    assert any("touches" in p for p in run(loop))
+    good = (".LBB0_1:\n" + load + dma + "s_waitcnt vmcnt(1)\nv_add_f32 v9, v6, v6\ns_cbranch_vccnz .LBB0_1\ns_waitcnt vmcnt(0)\ns_endpgm")
+    assert run(good) == []

@@ -160,7 +160,9 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(build.LIB)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.avcer_abi_version() == 1
+    # the header's version, the library's and the binding's agree (avcer_amd/_lib.py refuses a mismatch at load)
+    assert int(re.search(r"#define AVCER_ABI_VERSION (\d+)", header).group(1)) == lib.avcer_abi_version() == _lib.ABI_VERSION
+    assert int(re.search(r"#define AVCER_SPLIT_TRAILER (\d+)", header).group(1)) == _lib.SPLIT_TRAILER
 
 
 def test_engine_refuses_to_run_without_gpu():
