@@ -180,16 +180,17 @@ int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
     return AVCER_OK;
 }
 
-// Which form of the split-bf16 contraction serves a layer of M positions, N channels, K inputs: the weights-direct kernel
+// Which form of the x3 contraction serves a layer of M positions, N channels, K inputs: the weights-direct kernel
 // (128 x 256 tiles, dtype 7 / 8) or the LDS-staged one (128 x 128, dtype 5 / 6).  Results are bit-identical, so this is
-// speed only.  Model, calibrated on tools/ab_layers.py (profiles/r03_ab_layers*.txt): a 128 x 256 tile costs 1.84 tiles of
-// 128 x 128 (1.90 where K <= 1024: the tile's prologue and epilogue weigh more), a 112 x 256 tile 7/8 of that, and the
-// grid takes common.h grid_rounds() rounds of 512 blocks.
-bool prefer_weights_direct(long M, int N, long K) {
+// speed only.  Model, calibrated on tools/ab_layers.py (profiles/r04_ab_layers*.txt; round 4's spread K loop moved it from
+// 1.84-1.90): a 128 x 256 tile costs 1.72 tiles of 128 x 128 (qkv 1.73, out-proj 1.75, ffn1 1.69, l3.x.c2 1.68, fe6 1.72),
+// a 112 x 256 tile 7/8 of that, and the grid takes common.h grid_rounds() rounds of the block slots.
+bool prefer_weights_direct(long M, int N, long K, long slots) {
+    (void)K;
     const long mt = (M + 127) / 128, mt112 = (M + 111) / 112;
     // the direct form also has a 112-row tile (gemm.hip launch_wd picks it by the same model)
-    const double wd = std::min(grid_rounds(mt * (N / 256)), grid_rounds(mt112 * (N / 256)) * 112.0 / 128.0);
-    return wd * (K <= 1024 ? 1.90 : 1.84) < grid_rounds(mt * (N / 128));
+    const double wd = std::min(grid_rounds(mt * (N / 256), slots), grid_rounds(mt112 * (N / 256), slots) * 112.0 / 128.0);
+    return wd * 1.72 < grid_rounds(mt * (N / 128), slots);
 }
 
 struct Net {
@@ -237,7 +238,7 @@ struct Net {
             wp = w->x3;
             // sp32 activations: the weights-direct kernel wherever a fragment-order copy exists (one group, pad-free second source)
             if (akind == 2 && w->x3f && d.groups <= 1 && (d.tile_n == 256 || (d.tile_n == 0 &&
-                    prefer_weights_direct((long)d.batch * d.out_h * d.out_w, d.n, K)))) {
+                    prefer_weights_direct((long)d.batch * d.out_h * d.out_w, d.n, K, ctx->block_slots)))) {
                 dtype = okind == 2 ? 7 : 8;
                 wp = w->x3f;
             }
@@ -318,6 +319,9 @@ extern "C" int avcer_ctx_create(int device, avcer_ctx** out) {
     avcer_ctx* c = new (std::nothrow) avcer_ctx();
     if (!c) return AVCER_ENOMEM;
     c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        c->block_slots = 2 * prop.multiProcessorCount;  // two 256-thread MFMA blocks per CU (partitioned modes have fewer CUs)
     *out = c;
     return AVCER_OK;
 }

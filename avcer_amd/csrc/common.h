@@ -43,6 +43,7 @@ struct avcer_ctx {
     Model stat, dyn, aud, face;
     int aud_classes = 0;
     int static_batch = 1024;  // frames per internal pass of the static CNN (4 GiB buffer-descriptor limit at f32)
+    int block_slots = 512;    // 2 x hipDeviceProp_t::multiProcessorCount: what grid_rounds() divides a grid by
     // grow-only workspace arenas (activations), one per pipeline
     DevBuf ws[8];
     int64_t gemm_launches = 0;
@@ -92,16 +93,17 @@ int launch_stem_pool_u8(avcer_ctx* ctx, const uint8_t* frames, int in_h, int in_
 // conv2 + conv3 (+ residual) of one bottleneck and conv1 of the next block (t1n / w1n null when there is none);
 // ds_cin = 0: x [M][4 planes] is the residual; ds_cin = 64: x [M][64] is the downsample operand and w3 is [4 planes][planes + 64];
 // all activations sp32, weights split-bf16 (row-permuted) with the BN scale folded in (packing.py: *.wf, c3d.w)
-// Rounds a grid of 256-thread blocks takes on the 512 block slots (two per CU), as the form / tile choices model them.
+// Rounds a grid of 256-thread blocks takes on the chip's block slots (two per CU: `slots` = 2 x the CU count the context
+// read from the device at creation, 512 on a whole MI355X), as the form / tile choices model them.
 // Calibrated on tools/ab_layers.py (profiles/r03_ab_layers*.txt, 128- against 112-row tiles of the same layer): a grid of
 // at most one block per CU runs in 0.62 of a round (a block alone on its CU is that much faster); behind whole rounds, a
 // partial round that still fits one block per CU (fraction f <= 0.5) costs 0.25 + 0.7 f -- the whole rounds end ragged and
 // absorb part of it --, a larger one a whole round (some CU runs two blocks from start to end).
-inline double grid_rounds(long tiles) {
-    const long whole = tiles / 512, rest = tiles % 512;
-    if (whole == 0) return tiles <= 256 ? 0.62 : 1.0;
-    const double f = (double)rest / 512.0;
-    return (double)whole + (rest == 0 ? 0.0 : (rest <= 256 ? 0.25 + 0.7 * f : 1.0));
+inline double grid_rounds(long tiles, long slots) {
+    const long whole = tiles / slots, rest = tiles % slots;
+    if (whole == 0) return 2 * tiles <= slots ? 0.62 : 1.0;
+    const double f = (double)rest / (double)slots;
+    return (double)whole + (rest == 0 ? 0.0 : (2 * rest <= slots ? 0.25 + 0.7 * f : 1.0));
 }
 
 int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, int out_step,

@@ -67,6 +67,7 @@ struct GemmParams {
     int tap_inner;  // K-steps walk (channel chunk, ky, kx) instead of (ky, kx, channel chunk): see launch_conv_gemm
     const char* WF;  // dtype 7 / 8: the weights in MFMA fragment order (kernels.hip weight_frags_kernel), else null
     int tapH4, tapW4;  // byte steps of one filter tap down / right: dil_h * x_stride_h * 4, dil_w * x_stride_w * 4
+    int slots;         // host side only: block slots of the device (2 per CU), for the tile choices of the launchers
     int rsub, rH, rW;  // residual sub-sampling (avcer_conv_desc.r_sub): output (b, oy, ox) adds residual row (b, oy*rsub, ox*rsub)
 };
 
@@ -917,7 +918,7 @@ template <int OUT>
 void launch_wd(const GemmParams& p0, hipStream_t st) {
     GemmParams p = p0;
     const long ntn = p.N / 256;
-    const double c128 = grid_rounds((p.M + 127L) / 128 * ntn) * 128, c112 = grid_rounds((p.M + 111L) / 112 * ntn) * 112;
+    const double c128 = grid_rounds((p.M + 127L) / 128 * ntn, p.slots) * 128, c112 = grid_rounds((p.M + 111L) / 112 * ntn, p.slots) * 112;
     const bool m112 = p.tile_m == 112 || (p.tile_m == 0 && c112 < 0.97 * c128);
     if (m112) launch_wd_t<OUT, 7>(p, st);
     else launch_wd_t<OUT, 8>(p, st);
@@ -931,7 +932,7 @@ void launch_t(const GemmParams& p0, hipStream_t st) {
     GemmParams p = p0;
     bool bn128 = p.N % 128 == 0 && choose_bn128(p);
     // a grid of at most one block per two CUs (the LSTM's recurrent GEMMs, fc1, single-frame calls): twice the blocks at half the width
-    if (bn128 && (long)((p.M + 127) / 128) * (p.N / 128) <= 128) bn128 = false;
+    if (bn128 && (long)((p.M + 127) / 128) * (p.N / 128) <= p.slots / 4) bn128 = false;
     if (p.tile_n == 64) bn128 = false;
     if (p.tile_n == 128 && p.N % 128 == 0) bn128 = true;
     p.ntm = (p.M + 127) / 128;
@@ -1029,7 +1030,7 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
         p.x2_bytes = (unsigned)x2_extent; p.K1 = (int)K1;
         p.sB2 = d.x2_stride_b; p.sH2 = d.x2_stride_h; p.sW2 = d.x2_stride_w; p.coff2 = d.x2_coff; p.st2 = d.x2_stride;
     }
-    p.ntn = 0; p.nwg = 0; p.groups = groups;
+    p.ntn = 0; p.nwg = 0; p.groups = groups; p.slots = ctx->block_slots;
     if (d.tile_n != 0 && d.tile_n != 64 && d.tile_n != 128 && d.tile_n != 256)
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: tile_n %d (0, 64, 128 or 256)", d.tile_n);
     p.tile_n = d.tile_n;

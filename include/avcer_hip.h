@@ -314,8 +314,17 @@ int avcer_profile_read(avcer_ctx* ctx, double* total_ms, int64_t* launches);
  * named intermediate activation (first sub-batch) into dst_dev.  Names: static "pre", "stem_conv", "stem",
  * "l1b0_c1", "l1b0_c2", "l1b0", "layer1".."layer4", "avgpool"; audio "norm", "conv0", "extract", "proj",
  * "posconv", "layer0".."layer11", "w2v", "tl1", "tl2", "td0", "mp", "td4", "pooled".  Activations are NHWC / time-major,
- * f32 in AVCER_MODE_FP32 and bf16 in AVCER_MODE_BF16 (residual streams "proj".."tl2" and the head are always f32).
- * avcer_debug_tap_copied returns the number of bytes copied (-1 if the tap did not fire). */
+ * f32 in AVCER_MODE_FP32, bf16 in AVCER_MODE_BF16 and sp32 (fp16 hi / lo per 32 channels, see avcer_conv_gemm) in
+ * AVCER_MODE_F16X3 (residual streams "proj".."tl2", "avgpool" and the heads are always f32).
+ * What differs from the reference's tensors of the same name:
+ *   - "layer1", "layer2", "layer3" hold the stage output on the grid the NEXT stage reads, i.e. the reference's tensor at
+ *     [:, ::2, ::2] -- [n,28,28,256], [n,14,14,512], [n,7,7,1024]: the last bottleneck of stages 1-3 is evaluated at the
+ *     even positions only (its other outputs feed nothing: the next stage's 1x1 convolutions have stride 2); "layer4" is
+ *     the full [n,7,7,2048];
+ *   - "pre", "stem_conv", "l1b0_c2" exist in AVCER_MODE_FP32 / _BF16 only: AVCER_MODE_F16X3 preprocesses inside the fused
+ *     stem and keeps conv2 outputs in registers, so those taps do not fire there.
+ * avcer_debug_tap_copied returns the number of bytes copied, or -1 if the tap did not fire (compare it with the size you
+ * expect: a short copy means the tensor is smaller than the buffer, e.g. a sub-sampled stage tap). */
 int avcer_debug_tap(avcer_ctx* ctx, const char* name, void* dst_dev, size_t bytes);
 int64_t avcer_debug_tap_copied(const avcer_ctx* ctx);
 

@@ -12,7 +12,8 @@ P4="SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_AC
 P5="SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_ANY SQ_INST_LEVEL_LDS SQ_IFETCH"
 i=1
 for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
-  rocprofv3 --pmc $P --output-format csv -d $O/p$i -o p -- python3 "$@" > $O/p$i.log 2>&1 || { tail -5 $O/p$i.log; echo "pass $i failed (continuing)"; }
+  # a pass that dies (a GPU fault or hang included) ends the script: no further launches on a card that just failed
+  rocprofv3 --pmc $P --output-format csv -d $O/p$i -o p -- python3 "$@" > $O/p$i.log 2>&1 || { tail -5 $O/p$i.log; echo "pass $i failed: see $O/p$i.log; no counters aggregated"; exit 1; }
   i=$((i+1))
 done
 python3 - "$O" "$K" <<'PY'
