@@ -3,7 +3,7 @@
 (sclk, socket power).  Finding of round 4 (profiles/r04_clock_probe.txt): every MFMA-heavy kernel runs AT the socket power
 cap; the chip answers extra memory traffic with a lower clock, not with stalls one could schedule away.
 
-    python tools/clock_probe.py [seconds per case]
+    python tools/clock_probe.py [seconds per case] [--lib one-off-build.so] [--only substring]
 """
 import json
 import os
@@ -32,12 +32,17 @@ def smi():
 def main():
     import torch
 
+    if "--lib" in sys.argv:  # a one-off experiment build of the library
+        from avcer_amd import _lib
+        _lib.LIB = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
     from avcer_amd import synth
     from avcer_amd.engine import MODE_BF16, MODE_F16X3, MODE_FP32, Engine
     from avcer_amd.sp32 import to_sp32
     from tools.layer_bench import conv2d, linear
 
-    secs = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
+    argv = list(sys.argv[1:])
+    only = argv.pop(argv.index("--only") + 1) if "--only" in argv else ""
+    secs = float(argv[0]) if argv and not argv[0].startswith("--") else 4.0
     eng = Engine(0)
     dev = eng.device
     eng.load_static(synth.static_state_dict(42))
@@ -79,6 +84,8 @@ def main():
     cases.append(("register-only MFMA loop + 1 GiB copies (measure_ceilings)", lambda: eng.measure_ceilings(), 0.0))
     print("idle: sclk %d MHz, %.0f W" % smi())
     for label, fn, flop in cases:
+        if only not in label:
+            continue
         samples, stop = [], threading.Event()
 
         def poll():

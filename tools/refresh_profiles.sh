@@ -18,6 +18,11 @@ python3 tools/pmc_traffic.py "$O/pmc_FETCH_SIZE" "$O/pmc_WRITE_SIZE" --out "$O/t
 find "$O/stats" -name "*kernel_stats.csv" -exec cp {} "$O/kernel_stats.csv" \;
 # the raw counter dumps are large: keep the summaries only
 rm -rf "$O/pmc_FETCH_SIZE" "$O/pmc_WRITE_SIZE" "$O/stats"
+timeout -k 10 300 python3 tools/trace_step.py run > /dev/null 2>&1 || true
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/trace" -o t -- python3 tools/trace_step.py run > "$O/trace.log" 2>&1
+python3 tools/trace_step.py show "$O/trace" > "$O/step_trace.txt" 2>&1 || true
+rm -rf "$O/trace"
+timeout -k 10 200 python3 tools/clock_probe.py 3 > "$O/clock_probe.txt" 2>&1
 timeout -k 10 300 python3 tools/ab_layers.py --frames 1024 > "$O/ab_layers.txt" 2>&1
 timeout -k 10 300 python3 tools/ab_layers.py --frames 2048 --only "l3." > "$O/ab_layers_2048_l3.txt" 2>&1
 timeout -k 10 300 python3 tools/ab_layers.py --frames 2048 --only "l4." > "$O/ab_layers_2048_l4.txt" 2>&1
