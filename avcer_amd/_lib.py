@@ -82,6 +82,8 @@ SIGNATURES = {
     "avcer_stem_pool": (C.c_int, [c_ctx, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_stream]),
     "avcer_stem_pool_u8": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      c_stream]),
+    "avcer_attention": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                  c_stream]),
     "avcer_measure_ceilings": (C.c_int, [c_ctx, C.POINTER(C.c_double), C.POINTER(C.c_double), c_stream]),
     "avcer_gemm_stats": (C.c_int, [c_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
     "avcer_profile_enable": (C.c_int, [c_ctx, C.c_int]),

@@ -1166,6 +1166,14 @@ extern "C" int avcer_split_weight_rows(avcer_ctx* ctx, const float* w, void* out
     return k_split_weight_rows(ctx, w, (bf16_t*)out, n, k, (hipStream_t)stream);
 }
 
+extern "C" int avcer_attention(avcer_ctx* ctx, const void* qkv, void* out, int n, int s, int heads, int head_dim, float scale,
+                               int in_kind, int out_kind, avcer_stream_t stream) {
+    if (!ctx) return AVCER_EINVAL;
+    if (!qkv || !out || n <= 0 || heads <= 0) return set_err(ctx, AVCER_EINVAL, "attention: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return k_attention(ctx, qkv, out, n, s, heads, head_dim, scale, in_kind, out_kind, (hipStream_t)stream);
+}
+
 extern "C" int avcer_weight_frags(avcer_ctx* ctx, const void* rows, void* out, int n, int k, avcer_stream_t stream) {
     if (!ctx) return AVCER_EINVAL;
     if (!rows || !out || n <= 0 || k <= 0) return set_err(ctx, AVCER_EINVAL, "weight_frags: bad arguments");

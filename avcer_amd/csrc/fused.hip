@@ -51,9 +51,10 @@ __device__ __forceinline__ spx8_t ldfrag(const char* tile, int row, int chunk) {
 __device__ __forceinline__ void split8v(const float (&v)[8], spx8_t& hi, spx8_t& lo) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const spe_t h = (spe_t)v[j];
+        const float x = sp_value(v[j]);  // one f32 number for both halves (split_dev.h)
+        const spe_t h = (spe_t)x;
         hi[j] = h;
-        lo[j] = (spe_t)(v[j] - (float)h);
+        lo[j] = (spe_t)(x - (float)h);
     }
 }
 

@@ -149,6 +149,8 @@ __device__ __forceinline__ void finish8(const GemmParams& p, long m, int n0, con
     } else {
         uint32_t h[4], l[4];
 #pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = sp_value(v[j]);  // one f32 number for both halves of the pair (split_dev.h)
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint16_t h0 = f2sp(v[2 * j]), h1 = f2sp(v[2 * j + 1]);
             h[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);

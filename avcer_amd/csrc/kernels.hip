@@ -77,6 +77,7 @@ template <> __device__ __forceinline__ float ldf<sp32_t>(const sp32_t* p, long i
 }
 template <> __device__ __forceinline__ void stf<sp32_t>(sp32_t* p, long i, float v) {
     char* b = reinterpret_cast<char*>(p) + sp32_byte(i);
+    v = sp_value(v);  // one f32 number for both halves (split_dev.h)
     const uint16_t h = f2sp(v);
     *reinterpret_cast<uint16_t*>(b) = h;
     *reinterpret_cast<uint16_t*>(b + 64) = f2sp(v - sp2f(h));
@@ -90,10 +91,13 @@ template <> __device__ __forceinline__ void ld4<sp32_t>(const sp32_t* p, long i,
     v[2] = sp2f((uint16_t)(h.y & 0xffff)) + sp2f((uint16_t)(l.y & 0xffff));
     v[3] = sp2f((uint16_t)(h.y >> 16)) + sp2f((uint16_t)(l.y >> 16));
 }
-template <> __device__ __forceinline__ void st4<sp32_t>(sp32_t* p, long i, const float* v) {
+template <> __device__ __forceinline__ void st4<sp32_t>(sp32_t* p, long i, const float* vin) {
     char* b = reinterpret_cast<char*>(p) + sp32_byte(i);
     uint16_t h[4];
     uint2 hh, ll;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = sp_value(vin[j]);  // one f32 number for both halves (split_dev.h)
 #pragma unroll
     for (int j = 0; j < 4; ++j) h[j] = f2sp(v[j]);
     hh.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
@@ -134,8 +138,11 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ in, T* __restrict_
 
 // Planar split-bf16 variant (input of stem_pool_kernel): the same zero-bordered image as two bf16 planes
 // [n,230,230,4], hi = bf16(v) and lo = bf16(v - hi), so that one 8-pixel tap row is 64 contiguous bytes per plane.
-__device__ __forceinline__ void st4_planar(bf16_t* hi, bf16_t* lo, long idx, const float* v) {
+__device__ __forceinline__ void st4_planar(bf16_t* hi, bf16_t* lo, long idx, const float* vin) {
     uint16_t h[4];
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = sp_value(vin[j]);  // one f32 number for both halves (split_dev.h)
 #pragma unroll
     for (int j = 0; j < 4; ++j) h[j] = f2sp(v[j]);
     uint2 hh, ll;
@@ -980,7 +987,7 @@ __global__ void __launch_bounds__(64 * ATTM_WAVES) attention_mfma_kernel(const T
             const float (&qv)[8] = qraw[qi][ks];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float x = qv[j] * scale;
+                const float x = sp_value(qv[j] * scale);
                 const elem_t hh = (elem_t)x;
                 qh[ks][j] = hh;
                 ql[ks][j] = (elem_t)(x - (float)hh);
@@ -1034,7 +1041,7 @@ __global__ void __launch_bounds__(64 * ATTM_WAVES) attention_mfma_kernel(const T
             frag_t ph, pl;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float x = sc[2 * kb + (j >> 2)][j & 3];
+                const float x = sp_value(sc[2 * kb + (j >> 2)][j & 3]);
                 const elem_t hh = (elem_t)x;
                 ph[j] = hh;
                 pl[j] = (elem_t)(x - (float)hh);
@@ -1099,7 +1106,7 @@ __global__ void mean_time_relu_kernel(const float* __restrict__ x, float* __rest
 __global__ void split_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float v = w[i];
+    const float v = sp_value(w[i]);
     const uint16_t h = f2sp(v);
     const size_t g = i >> 5, j = i & 31;
     out[g * 64 + j] = h;
@@ -1147,7 +1154,7 @@ __global__ void split_weight_rows_kernel(const float* __restrict__ w, bf16_t* __
     const int row = i / k, col = i - (size_t)row * k;      // destination row / K index
     const int j = row & 31, t = j >> 4, g = (j >> 2) & 3, r = j & 3;
     const int src = (row & ~31) + 8 * g + 4 * t + r;
-    const float v = w[(size_t)src * k + col] * __uint_as_float(sc.x);
+    const float v = sp_value(w[(size_t)src * k + col] * __uint_as_float(sc.x));
     const uint16_t h = f2sp(v);
     const size_t o = (size_t)row * k * 2 + (size_t)(col >> 5) * 64 + (col & 31);
     out[o] = h;

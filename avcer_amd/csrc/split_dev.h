@@ -31,6 +31,19 @@ typedef _Float16 spe_t;
 typedef __attribute__((ext_vector_type(8))) spe_t spx8_t;
 typedef __attribute__((ext_vector_type(4))) float sp_f32x4_t;
 
+// A value about to be split must be ONE f32 number for both halves.  HIP contracts floating-point expressions by default,
+// and on gfx950 hipcc folds a producing multiply INTO the conversion (v_fma_mixlo_f16: f16(a * b) with a single rounding) --
+// separately for each use.  Round 4 caught it in the attention kernel's output: hi was stored as f16(f32(o * inv)) while lo
+// was computed against f16(o * inv); on the rare values whose f32 rounding lands on an fp16 tie the two disagree by one hi
+// ulp, and hi + lo is then wrong by 2^-11 relative (tools/x3_audio_stage_error.py: 6e-6 rms in the attention output, three
+// times the f32 mode's error at the logits).  Passing the value through an empty asm makes it an opaque register.
+__device__ __forceinline__ float sp_value(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+
 // f32 -> the 16 bits of the split element type (round to nearest even) and back
 __device__ __forceinline__ uint16_t f2sp(float f) { return __builtin_bit_cast(uint16_t, (spe_t)f); }
 __device__ __forceinline__ float sp2f(uint16_t b) { return (float)__builtin_bit_cast(spe_t, b); }

@@ -307,6 +307,12 @@ class Engine:
         self._check(self.lib.avcer_bneck_chain(self.ctx, planes, nb, h, w, _ptr(t1), _ptr(x), int(ds_cin), int(out_step), _ptr(out),
                                                _ptr(t1n), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), _ptr(w1n), _ptr(b1n), self._stream()))
 
+    def attention(self, qkv, out, n: int, s: int, heads: int, head_dim: int, scale: float, in_kind: int, out_kind: int):
+        """Kernel-level entry of the attention kernel: qkv [n, s, 3 * heads * head_dim] -> out [n, s, heads * head_dim];
+        storage kinds 0 = f32, 1 = bf16, 2 = sp32 (int16 tensor of twice the elements)."""
+        self._check(self.lib.avcer_attention(self.ctx, _ptr(qkv), _ptr(out), n, s, heads, head_dim, float(scale), in_kind,
+                                             out_kind, self._stream()))
+
     def measure_ceilings(self):
         """(bf16 MFMA TFLOP/s of a register-only MFMA loop, TB/s of a 1 GiB streaming copy) measured on this GPU."""
         a, b = C.c_double(0.0), C.c_double(0.0)

@@ -294,6 +294,16 @@ int avcer_split_weight_rows(avcer_ctx* ctx, const float* w, void* out, int n, in
  * then the trailer.  rows, out: device pointers, n * k * 4 + AVCER_SPLIT_TRAILER bytes each; n a multiple of 16, k of 32. */
 int avcer_weight_frags(avcer_ctx* ctx, const void* rows, void* out, int n, int k, avcer_stream_t stream);
 
+/* The attention kernel on its own (kernel-level parity tests): softmax(Q K^T * scale) V per (row block, head).
+ *   ref: architectures/attention_layers.py:80-144 (ScaledDotProductAttention inside MultiHeadAttention), transformers
+ *        Wav2Vec2Attention (eager).
+ * qkv [n, s, 3 * heads * head_dim]: per token the queries of all heads, then the keys, then the values (the packed output of
+ * the fused q / k / v projection); out [n, s, heads * head_dim].  head_dim 64 or 32, s <= 256.  Storage kinds: 0 = f32,
+ * 1 = bf16, 2 = sp32.  (in 0, out 0): exact f32 arithmetic on the VALU; (in 1, out 1): bf16 operands on the MFMA;
+ * (in 0, out 2): what AVCER_MODE_F16X3 runs -- f32 in, sp32 out (see the kernel for its arithmetic). */
+int avcer_attention(avcer_ctx* ctx, const void* qkv, void* out, int n, int s, int heads, int head_dim, float scale,
+                    int in_kind, int out_kind, avcer_stream_t stream);
+
 /* Measured ceilings of the GPU this context lives on (about 0.2 s): dense 16-bit MFMA issue rate of a register-only
  * v_mfma_f32_16x16x32_f16 loop in TFLOP/s (the instruction of AVCER_MODE_F16X3; the bf16 form issues at the same rate,
  * tools/f16_probe.hip), and the bandwidth of a 1 GiB -> 1 GiB 16-byte-per-lane copy in TB/s (bytes read + bytes written).

@@ -541,3 +541,42 @@ def test_x3_overflow_is_nan_not_a_wrong_number(engine):
     engine.conv_gemm(d, 6, yd, engine.split_weight_rows(torch.ones(n, n, device=dev)), None, None, None, y2)
     torch.cuda.synchronize()
     assert torch.isnan(y2).all()
+
+
+# ---- attention kernel on its own (avcer_attention)
+@pytest.mark.parametrize("s,heads,d", [(99, 16, 64), (199, 4, 64), (99, 8, 32), (37, 2, 64)])
+def test_attention_f32_and_x3_against_float64(engine, s, heads, d):
+    """softmax(Q K^T * scale) V per head (attention_layers.py:80-144; transformers Wav2Vec2Attention): the f32 VALU kernel
+    and the x3 MFMA kernel (fp16 hi/lo pairs, sp32 output) against float64.  Both must be f32-grade -- the x3 form read
+    6.8e-6 rms here until round 4: hipcc folded the final multiply into the f16 conversion separately for the hi store and
+    for the lo subtraction, and the two roundings disagreed on near-ties (csrc/split_dev.h sp_value)."""
+    g = torch.Generator().manual_seed(s + d)
+    n, e = 3, heads * d
+    qkv = torch.randn(n, s, 3 * e, generator=g)
+    qkv[..., :e] *= 2.0                                              # scores up to ~ +-10
+    scale = 1.0 / d ** 0.5
+    q, k, v = (qkv[..., i * e:(i + 1) * e].double().view(n, s, heads, d).transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(n, s, e)
+    dev = engine.device
+    qd = qkv.to(dev)
+    o32 = torch.full((n, s, e), float("nan"), device=dev)
+    engine.attention(qd, o32, n, s, heads, d, scale, 0, 0)
+    osp = torch.full((n, s, 2 * e), 0x7e00, dtype=torch.int16, device=dev)
+    engine.attention(qd, osp, n, s, heads, d, scale, 0, 2)
+    torch.cuda.synchronize()
+    rms = ref.pow(2).mean().sqrt()
+    for name, got in (("f32", o32.cpu().double()), ("x3", from_sp32(osp.cpu()).double())):
+        err = got - ref
+        rel, worst = (err.pow(2).mean().sqrt() / rms).item(), err.abs().max().item()
+        print(f"attention s={s} heads={heads} d={d} {name}: rel rms {rel:.2e}, max|err| {worst:.2e}")
+        assert rel < 1e-6 and worst < 4e-6, (name, rel, worst)
+
+
+def test_attention_argument_errors(engine):
+    from avcer_amd._lib import AvcerError
+
+    x = torch.zeros(1, 300, 3 * 64, device=engine.device)
+    with pytest.raises(AvcerError):
+        engine.attention(x, x, 1, 300, 1, 64, 0.125, 0, 0)           # more than 256 tokens
+    with pytest.raises(AvcerError):
+        engine.attention(x, x, 1, 99, 1, 48, 0.125, 0, 0)            # head dimension

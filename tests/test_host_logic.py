@@ -181,3 +181,24 @@ def test_synth_is_deterministic():
     # pinned values: the generator must never change (golden vectors depend on it)
     assert synth.raw_u64(42, "pin", 2).tolist() == synth.raw_u64(42, "pin", 2).tolist()
     assert synth.face_frames(1, 1)[0, 0, 0].tolist() == synth.face_frames(1, 1)[0, 0, 0].tolist()
+
+
+def test_sp32_host_view_roundtrip_and_layout():
+    """avcer_amd/sp32.py, the host-side view of the x3 mode's storage (csrc/split_dev.h): per 32 channels 32 fp16 hi then 32
+    fp16 lo; hi + lo carries 22 significand bits; subnormal lo halves survive; an overflow decodes to NaN."""
+    from avcer_amd.sp32 import from_sp32, raw_to_f32, to_sp32
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 7, 64, generator=g) * torch.tensor([1e-3, 1.0, 3e3, 0.1, 30.0]).view(5, 1, 1)
+    s = to_sp32(x)
+    assert s.dtype == torch.int16 and s.shape == (5, 7, 128)
+    back = from_sp32(s)
+    assert ((back - x).abs() <= 2.0 ** -21 * x.abs() + 2.0 ** -24).all()
+    # layout: element c of a row -> hi at int16 index 64 * (c // 32) + c % 32, lo 32 further on
+    row = s[1, 2].view(torch.float16).float()
+    for c in (0, 31, 32, 63):
+        assert abs(float(row[64 * (c // 32) + c % 32] + row[64 * (c // 32) + 32 + c % 32]) - float(x[1, 2, c])) <= 2.0 ** -21 * abs(float(x[1, 2, c]))
+    torch.testing.assert_close(raw_to_f32(s.reshape(-1), (5, 7, 64)), back)
+    assert torch.isnan(from_sp32(to_sp32(torch.full((1, 32), 7.0e4)))).all()          # beyond fp16: inf + (-inf)
+    tiny = torch.full((1, 32), 3.0e-5)                                                  # lo half is an fp16 subnormal
+    assert float((from_sp32(to_sp32(tiny)) - tiny).abs().max()) <= 2.0 ** -25
