@@ -743,6 +743,8 @@ __global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
 
     // ---------------- phases B + C per 32-channel output group (two groups per trip: the residual ring is indexed statically)
     auto group = [&](int G, uint4 (&h)[NT], uint4 (&l)[NT]) {
+        // (a burst: spreading these pieces over the conv3 MFMAs, as conv_gemm_wd_kernel and bneck_tail2_kernel do, measured
+        // +2.4 % at planes 64 and +0.6 % at planes 128 -- the group's barrier drains them, and they land later)
         if (G + 1 < NG) issue_group(G + 1);
         const char* w3t = smem + (G & 1) * TILE_B;
         const char* w1t = w3t + NQT * (32 * ROWB);
@@ -892,6 +894,15 @@ __global__ void __launch_bounds__(512, 2) bneck_tail2_kernel(const BneckParams p
 #pragma unroll
         for (int j = 0; j < G1_ISS; ++j) dma16(w1rs, b1 + (wave * G1_ISS + j) * 1024, live ? g1_off[j] : OOB, (unsigned)(G * ROWB));
     };
+    // one of the G3_ISS + G1_ISS pieces of group G (round 4: inside a group the pieces are issued one by one between the
+    // conv3 MFMAs instead of as a burst in front of them -- what paid in conv_gemm_wd_kernel, gemm.hip AVCER_WD_STEP)
+    static_assert(G3_ISS + G1_ISS == NQ, "one piece per conv3 K-step");
+    auto issue_piece = [&](int G, int j) {
+        const bool live = G < NG;
+        if (j < G3_ISS) dma16(w3rs, smem + (G & 1) * W3B + g3_dst[j], live ? g3_off[j] : OOB, (unsigned)(G * 32 * P * 4));
+        else dma16(w1rs, smem + 2 * W3B + (G & 1) * W1B + (wave * G1_ISS + (j - G3_ISS)) * 1024, live ? g1_off[j - G3_ISS] : OOB,
+                   (unsigned)(G * ROWB));
+    };
     issue_weights(0);
 
     const long m = (long)m_base + wave * 16 + l15;
@@ -932,15 +943,21 @@ __global__ void __launch_bounds__(512, 2) bneck_tail2_kernel(const BneckParams p
     // [G3_ISS + G1_ISS DMA of group G+1] [2 stores] [2 residual loads of group G+2].
 #define AVCER_TAIL_GROUP(G, H, L, HN, LN)                                                                                      \
     do {                                                                                                                       \
-        issue_weights((G) + 1); /* buffers of the other parity: every wave left group G-1 at the barrier */                    \
-        asm volatile("" ::: "memory");            /* nothing below may be hoisted above the DMA: the count relies on it */       \
         const char* w3t = smem + ((G) & 1) * W3B;                                                                              \
         const char* w1t = smem + 2 * W3B + ((G) & 1) * W1B;                                                                    \
         f32x4_t acc3[2] = {f32x4_t{0}, f32x4_t{0}};                                                                            \
         _Pragma("unroll") for (int q = 0; q < NQ; ++q) _Pragma("unroll") for (int tp = 0; tp < 2; ++tp) {                      \
+            if (tp == 0) { /* piece q of group G+1 -> the buffers of the other parity (every wave left group G-1 at the */     \
+                           /* barrier); all eight are issued before this group's stores and residual loads: the count holds */ \
+                __builtin_amdgcn_sched_barrier(0);                                                                             \
+                issue_piece((G) + 1, q);                                                                                       \
+                asm volatile("" ::: "memory");                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                                             \
+            }                                                                                                                  \
             const char* wt = w3t + q * (32 * ROWB);                                                                            \
             mfma3(acc3[tp], ldfrag(wt, tp * 16 + l15, g), ldfrag(wt, tp * 16 + l15, 4 + g), t2h[q], t2l[q]);                   \
         }                                                                                                                      \
+        asm volatile("" ::: "memory");            /* nothing below may be hoisted above the DMA: the count relies on it */       \
         f32x4_t b0, b1;                                                                                                        \
         lds_read8(sbias + P + 32 * (G) + 8 * g, b0, b1);                                                                       \
         float r[8];                                                                                                            \

@@ -4,6 +4,7 @@ bf16 pairs (tools/build_lab.sh), speed and error, one child process per library 
 share a process), interleaved A B A B so that clock drift of the box hits both.
 
     bash tools/build_lab.sh && python tools/ab_split.py            # parent
+    python tools/ab_split.py --lab tools/lab/some_one_off_build.so  # the same A/B against any other build of the library
     python tools/ab_split.py --child [--lib path.so]                # what the parent runs
 """
 import json
@@ -60,11 +61,12 @@ def main():
     if "--child" in sys.argv:
         lib = sys.argv[sys.argv.index("--lib") + 1] if "--lib" in sys.argv else None
         return child(lib)
-    if not os.path.exists(LAB):
-        sys.exit(f"{LAB} missing: run tools/build_lab.sh")
+    lab = os.path.abspath(sys.argv[sys.argv.index("--lab") + 1]) if "--lab" in sys.argv else LAB  # any one-off build to compare with
+    if not os.path.exists(lab):
+        sys.exit(f"{lab} missing: run tools/build_lab.sh")
     rows = []
     for rep in range(2):
-        for lib in (None, LAB):
+        for lib in (None, lab):
             cmd = [sys.executable, os.path.abspath(__file__), "--child"] + (["--lib", lib] if lib else [])
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=280)
             line = [l for l in r.stdout.splitlines() if l.startswith("AB ")]
@@ -73,9 +75,9 @@ def main():
             rows.append(json.loads(line[0][3:]))
             print(rows[-1], flush=True)
     for key in ("static_2048_ms", "static_256_ms", "audio_128_ms", "mfma_ceiling_tflops", "static_max_dprob"):
-        a = [r[key] for r in rows if "bf16split" not in r["lib"]]
-        b = [r[key] for r in rows if "bf16split" in r["lib"]]
-        print(f"{key:22s} fp16 split {min(a):10.4g}   bf16 split {min(b):10.4g}   ratio {min(a) / min(b):.3f}")
+        a = [r[key] for r in rows if r["lib"] == "libavcer_hip.so"]
+        b = [r[key] for r in rows if r["lib"] != "libavcer_hip.so"]
+        print(f"{key:22s} product {min(a):10.4g}   {os.path.basename(lab)} {min(b):10.4g}   ratio {min(a) / min(b):.3f}")
 
 
 if __name__ == "__main__":
