@@ -11,8 +11,8 @@ at scale 8 (6.6e-5 ... 1.02e-4 over three arithmetically equivalent builds; 1.9e
 scale 8 by 2e-4.  Round 4 splits into fp16 pairs on v_mfma_f32_16x16x32_f16 (csrc/split_dev.h: 11 + 11 significand bits,
 7e-8 per contraction, weights pre-scaled by a power of two per matrix): the x3 taps now carry the f32 mode's own error
 (layer4 1.5e-6 relative in both, tools/x3_stage_error.py), so the two modes sit at the same distance from the oracle at
-every scale and the loosened branch is gone.  tools/x3_margin_sweep.py repeats the static part over 16 further draws
-(profiles/r04_x3_margin_sweep_16seeds.txt)."""
+every scale and the loosened branch is gone.  tools/x3_margin_sweep.py --all repeats it over 48 further draws of all three
+models (profiles/r04_x3_margin_sweep_48seeds_all_models.txt: x3 worst 3.9e-6 / 6.9e-6 / 1.1e-5, f32 mode 3.9e-6 / 8.5e-6 / 1.2e-5)."""
 import numpy as np
 import pytest
 import torch
