@@ -141,7 +141,7 @@ int ensure_all_bf16(avcer_ctx* ctx, Model& m, hipStream_t st) {
     return AVCER_OK;
 }
 
-// split-bf16 copies (k_split_weight_rows: hi/lo per 32-element K group, rows permuted inside every group of 32 output
+// split-fp16 copies (k_split_weight_rows: scaled hi/lo per 32-element K group + trailer, rows permuted inside every group of 32 output
 // channels) of every GEMM weight whose K is a multiple of 32, made on the first x3 call
 // device bytes of one split copy: the data, its scale trailer (split_dev.h), rounded to 256
 inline size_t split_bytes(size_t numel) { return ((numel * 4 + 255) & ~(size_t)255) + AVCER_SPLIT_TRAILER_BYTES; }
@@ -160,7 +160,7 @@ int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
     void* dev = nullptr;
     if (hipMalloc(&dev, total) != hipSuccess) {
         (void)hipGetLastError();
-        return set_err(ctx, AVCER_ENOMEM, "hipMalloc(%zu) for split-bf16 weights failed", total);
+        return set_err(ctx, AVCER_ENOMEM, "hipMalloc(%zu) for split-fp16 weights failed", total);
     }
     m.allocs.push_back(dev);
     size_t off = 0;
@@ -198,7 +198,7 @@ struct Net {
     Model& m;
     int bf16;  // activation / weight type of the MFMA contractions
     hipStream_t st;
-    int x3 = 0;  // f32 activations, split-bf16 MFMA (AVCER_MODE_F16X3)
+    int x3 = 0;  // f32-grade activations, split-fp16 MFMA (AVCER_MODE_F16X3)
     int err = AVCER_OK;
 
     const Tensor* T(const std::string& name) {
@@ -408,8 +408,8 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     auto run_stem = [&](int f0, int nb, void** B) {
         if (net.x3) {
             // x3 mode: ONE kernel for conv 7x7/2 + BN + ReLU + max-pool 3x3/2 (fused.hip).  From u8 frames it also does the
-            // preprocessing (raw pixels are exact in bf16: two MFMAs per product, the mean lives in the shift table stem.b9);
-            // the preprocessed-tensor entry point carries arbitrary floats and goes through the planar bf16 hi / lo image.
+            // preprocessing (raw pixels are exact in fp16: two MFMAs per product, the mean lives in the shift table stem.b9);
+            // the preprocessed-tensor entry point carries arbitrary floats and goes through the planar fp16 hi / lo image.
             const Tensor* w = net.T("stem7.w");
             if (net.err != AVCER_OK) return;
             if (!w->x3) { net.err = set_err(ctx, AVCER_ESTATE, "stem7.w: split weights not prepared"); return; }
@@ -563,7 +563,7 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
         {
             // fc1 on the exact f32 MFMA in the x3 mode too.  After the 7 x 7 average pool the position-independent part
             // of the trunk's error is what is left (tools/x3_stage_error.py: 1.3e-5 relative at layer4, 4.6e-6 pooled),
-            // and a split-bf16 fc1 on top of it raised the feature / logit error by 40 % (6.4e-6) -- for a 4.3 GFLOP
+            // and round 3's split-bf16 fc1 on top of it raised the feature / logit error by 40 % (6.4e-6) -- for a 4.3 GFLOP
             // layer of 32 tiles that takes the same 50 us either way.
             const int x3_saved = net.x3;
             net.x3 = 0;
@@ -795,7 +795,7 @@ static int dynamic_forward_impl(avcer_ctx* ctx, const float* windows, int n, int
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // the recurrence keeps f32 state in every mode; AVCER_MODE_F16X3 runs its ten dependent GEMMs per layer on the
-    // split-bf16 MFMA (a 128-row tile of the f32 MFMA costs 5x the cycles, and these launches are pure latency)
+    // split-fp16 MFMA (a 128-row tile of the f32 MFMA costs 5x the cycles, and these launches are pure latency)
     const int x3 = mode == AVCER_MODE_F16X3;
     if (x3) TRY(ensure_all_x3(ctx, ctx->dyn, st));
     constexpr int T = 10, I = 512, H1 = 512, H2 = 256;
@@ -905,7 +905,7 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
     Net net{ctx, ctx->aud, bf, st, mode == AVCER_MODE_F16X3};
     // LN whose output is an MFMA operand: f32 in the f32 mode, else a bf16 / sp32 tensor
     // GELU: the library erff in the f32 mode; the short Abramowitz-Stegun erf (gemm_dev.h gelu_fast, same 5e-7 bound as
-    // the exact form's own f32 rounding) where the contractions around it are bf16 or split-bf16
+    // the exact form's own f32 rounding) where the contractions around it are bf16 or split-fp16
     const int gelu = act ? 3 : 2;
     auto ln_act = [&](const void* x, int x_kind, const std::string& p, void* y, long r, int c, int fn) {
         net.chk(k_layernorm(ctx, x, nullptr, net.F(p + ".g"), net.F(p + ".b"), act ? nullptr : y, act ? y : nullptr, r, c,

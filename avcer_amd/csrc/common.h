@@ -24,7 +24,7 @@ struct DevBuf {
 struct Tensor {
     float* f32 = nullptr;
     bf16_t* bf16 = nullptr;
-    bf16_t* x3 = nullptr;  // split-bf16 (hi/lo per 32-element K group) copy for AVCER_MODE_F16X3
+    bf16_t* x3 = nullptr;  // split-fp16 copy (scaled hi/lo per 32-element K group + trailer, split_dev.h) for AVCER_MODE_F16X3
     bf16_t* x3f = nullptr; // the same in MFMA fragment order (conv_gemm dtype 7 / 8), where the shape allows it
     size_t numel = 0;
     int64_t dims[4] = {0, 0, 0, 0};
@@ -84,15 +84,15 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
 
 int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1);
 
-// ---- fused.hip (split-bf16 mode only)
-// planes: bf16 hi plane [n][230][230][4] followed plane_bytes later by the lo plane; y: sp32 [n][55][55][64]
+// ---- fused.hip (split-fp16 mode only)
+// planes: fp16 hi plane [n][230][230][4] followed plane_bytes later by the lo plane; y: sp32 [n][55][55][64]
 int launch_stem_pool(avcer_ctx* ctx, const void* planes, size_t plane_bytes, const void* w_x3, const float* scale,
                      const float* bias, void* y, int n, hipStream_t st);
 int launch_stem_pool_u8(avcer_ctx* ctx, const uint8_t* frames, int in_h, int in_w, const void* w_x3, const float* scale,
                         const float* bias9, void* y, int n, hipStream_t st);
 // conv2 + conv3 (+ residual) of one bottleneck and conv1 of the next block (t1n / w1n null when there is none);
 // ds_cin = 0: x [M][4 planes] is the residual; ds_cin = 64: x [M][64] is the downsample operand and w3 is [4 planes][planes + 64];
-// all activations sp32, weights split-bf16 (row-permuted) with the BN scale folded in (packing.py: *.wf, c3d.w)
+// all activations sp32, weights split-fp16 (scaled, row-permuted) with the BN scale folded in (packing.py: *.wf, c3d.w)
 // Rounds a grid of 256-thread blocks takes on the chip's block slots (two per CU: `slots` = 2 x the CU count the context
 // read from the device at creation, 512 on a whole MI355X), as the form / tile choices model them.
 // Calibrated on tools/ab_layers.py (profiles/r03_ab_layers*.txt, 128- against 112-row tiles of the same layer): a grid of
@@ -117,7 +117,7 @@ int launch_bneck_tail(avcer_ctx* ctx, int planes, long M, const void* t2, const 
 int measure_ceilings(avcer_ctx* ctx, double* mfma_bf16_tflops, double* hbm_copy_tbs, hipStream_t st);
 
 // ---- kernels.hip (element-wise / reduction kernels; T selects f32 (0) or bf16 (1) activations)
-// kind: 0 = f32 [n,230,230,4], 1 = bf16, 3 = planar bf16 hi / lo (two [n,230,230,4] planes, the stem_pool input)
+// kind: 0 = f32 [n,230,230,4], 1 = bf16, 3 = planar fp16 hi / lo (two [n,230,230,4] planes, the stem_pool input)
 int k_preprocess(avcer_ctx*, const uint8_t* frames, int n, int in_h, int in_w, void* out, int kind, hipStream_t);
 int k_maxpool3s2(avcer_ctx*, const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int bf16, hipStream_t);
 int k_avgpool_hw(avcer_ctx*, const void* x, float* y, int n, int hw, int c, int bf16, hipStream_t);

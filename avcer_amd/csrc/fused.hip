@@ -1,6 +1,6 @@
-// Fused kernels of the static CNN in the split-bf16 ("x3") arithmetic (gfx950 only).
+// Fused kernels of the static CNN in the split-fp16 ("x3") arithmetic (gfx950 only; csrc/split_dev.h).
 //
-//   stem_pool_kernel   preprocessed image (planar bf16 hi / lo) -> 7x7/2 convolution + BN + ReLU + 3x3/2 max-pool
+//   stem_pool_kernel   preprocessed image (planar fp16 hi / lo) -> 7x7/2 convolution + BN + ReLU + 3x3/2 max-pool
 //                      ref: architectures/video.py:63-90,98-103,116-117
 //   bneck_kernel       the tail of one bottleneck and the head of the next one in ONE launch:
 //                        T1 --3x3 conv2+BN+ReLU--> T2 --1x1 conv3+BN, +X, ReLU--> OUT --1x1 conv1'+BN+ReLU--> T1'
@@ -20,7 +20,7 @@
 
 namespace {
 
-// a.w ~= ah.wh + ah.wl + al.wh on the bf16 MFMA with f32 accumulation (same product order as conv_gemm MODE 3)
+// a.w ~= ah.wh + ah.wl + al.wh on the f16 MFMA with f32 accumulation (same product order as conv_gemm MODE 3)
 __device__ __forceinline__ void mfma3(f32x4_t& acc, const spx8_t wh, const spx8_t wl, const spx8_t ah, const spx8_t al) {
     acc = mfma_sp(wl, ah, acc);
     acc = mfma_sp(wh, al, acc);
@@ -47,7 +47,7 @@ __device__ __forceinline__ spx8_t ldfrag(const char* tile, int row, int chunk) {
     return *reinterpret_cast<const spx8_t*>(tile + swz(row, chunk));
 }
 
-// 8 f32 values -> bf16 hi / lo fragments (value = hi + lo + O(2^-17))
+// 8 f32 values -> fp16 hi / lo fragments (value = hi + lo + O(2^-22))
 __device__ __forceinline__ void split8v(const float (&v)[8], spx8_t& hi, spx8_t& lo) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -83,7 +83,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // ------------------------------------------------------------------------------------------------ stem + max-pool
 struct StemParams {
-    const char* P;         // bf16 hi plane [n][230][230][4]; the lo plane starts plane_bytes later
+    const char* P;         // fp16 hi plane [n][230][230][4]; the lo plane starts plane_bytes later
     const uint8_t* F;      // u8 form: the frames themselves, u8 [n][in_h][in_w][3] RGB (data/utils.py:19-39 happens in the kernel)
     int in_h, in_w;
     const float* bias9;    // u8 form: [9 border classes][64]: BN shift - BN scale * sum over the VALID taps of w * channel mean
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
 
 // The stem of the x3 mode when the input is the u8 frames (avcer_static_forward): same tiling, but
 //  * the block builds its patch itself (BGR flip, PIL NEAREST resize when the frame is not 224 x 224, zeros outside the image)
-//    as RAW PIXEL VALUES: integers 0..255 are exact in bf16, so the activation has no lo half -- two MFMAs per product, one
+//    as RAW PIXEL VALUES: integers 0..255 are exact in fp16, so the activation has no lo half -- two MFMAs per product, one
 //    patch plane, no preprocessing launch and no 846 KB-per-frame image in HBM.  The mean subtraction of data/utils.py:36-38
 //    moves into the shift: sum_valid w (p - mu) = sum_valid w p - sum_valid w mu, "valid" = the taps inside the image
 //    (Conv2dSame pads the NORMALISED image with zeros, video.py:68-80): a constant per output channel and BORDER CLASS of the
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
     } while (0)
     AVCER_STEM_W(0);
     AVCER_STEM_W(1);
-    // patch chunk ci = patch row ci / 18, pixels 2 (ci % 18), + 1 of the zero-bordered 230 x 230 image: [B G R 0] x 2 as bf16
+    // patch chunk ci = patch row ci / 18, pixels 2 (ci % 18), + 1 of the zero-bordered 230 x 230 image: [B G R 0] x 2 as fp16
     {
         // every byte load of the thread is issued before the first one is used: the addresses are clamped into the frame
         // (pixels outside the image and chunks past the patch load a valid byte and are zeroed afterwards), so nothing here
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
             uint32_t wds[4];
 #pragma unroll
             for (int px = 0; px < 2; ++px) {
-                // [B G R 0]; integers up to 255 need 8 significant bits: the bf16 is exact
+                // [B G R 0]; integers up to 255 need 8 significant bits: the fp16 is exact
                 const uint32_t lo2 = (uint32_t)f2sp((float)raw[j][px][2]) | ((uint32_t)f2sp((float)raw[j][px][1]) << 16);
                 const uint32_t hi2 = (uint32_t)f2sp((float)raw[j][px][0]);
                 wds[2 * px] = ok[j][px] ? lo2 : 0u;
@@ -1165,7 +1165,7 @@ int launch_bneck_tail(avcer_ctx* ctx, int planes, long M, const void* t2, const 
     return AVCER_OK;
 }
 
-// Measured ceilings of this GPU: dense bf16 MFMA issue rate (TFLOP/s) and streaming-copy bandwidth (TB/s, read + write bytes).
+// Measured ceilings of this GPU: dense 16-bit MFMA issue rate (the f16 form; TFLOP/s) and streaming-copy bandwidth (TB/s, read + write bytes).
 int measure_ceilings(avcer_ctx* ctx, double* mfma_bf16_tflops, double* hbm_copy_tbs, hipStream_t st) {
     hipEvent_t e0, e1;
     HIP_TRY(ctx, hipEventCreate(&e0));

@@ -22,7 +22,8 @@
 //   * MFMA operands are swapped (weights = A operand, activations = B operand) so that each lane's accumulator
 //     registers hold 4 CONSECUTIVE output channels of one position.
 //   * Arithmetic: MODE 0 f32 (v_mfma_f32_32x32x2_f32, exact FMA chain); MODE 1 bf16 (v_mfma_f32_16x16x32_bf16);
-//     MODE 2/3 split-bf16 "x3": hi/lo bf16 pairs, 3 MFMAs per product, f32-grade results (see conv_gemm_kernel).
+//     MODE 2/3 split-fp16 "x3": hi/lo fp16 pairs on v_mfma_f32_16x16x32_f16, 3 MFMAs per product, f32-grade results
+//     (see conv_gemm_kernel and split_dev.h).
 //   * Epilogue through LDS: scale/bias, residual (prefetched into registers at kernel start), activation, whole-line
 //     16-byte stores in f32, bf16 or sp32.  Optional second A source (two fused 1x1 convolutions), grouped
 //     convolution via grid.y, bijective XCD-aware block remap + grouped tile order.
@@ -75,7 +76,7 @@ struct GemmParams {
 // accumulators in an f32 [128][BN] image (16-byte chunks XOR-swizzled with row&7 against write conflicts), then the
 // 256 threads walk the image row-major, 8 consecutive channels per thread: residual add, activation, one 16-byte
 // (bf16) or two 16-byte (f32) stores.  ACT: 0 none, 1 relu, 2 gelu (compile-time: erff only in the GELU variant).
-// OUT: 0 = f32, 1 = bf16, 2 = split-bf16 pairs ("sp32": per aligned group of 32 channels, 32 hi bf16 then 32 lo bf16,
+// OUT: 0 = f32, 1 = bf16, 2 = split-fp16 pairs ("sp32": per aligned group of 32 channels, 32 hi fp16 then 32 lo fp16,
 // value = hi + lo; 4 bytes per element like f32, directly consumable as MODE 3 A operand).  The residual has the
 // same storage type as the output.
 // Raw 16-byte words of the residual belonging to 8 consecutive channels of one position: {f32 x4, f32 x4},
@@ -243,7 +244,7 @@ __device__ __forceinline__ void drain_stage(const GemmParams& p, const char* sme
     }
 }
 
-// ---- direct epilogue of the split-bf16 modes (MODE 2 / 3).  Their weight rows are stored permuted inside every group of
+// ---- direct epilogue of the split-fp16 modes (MODE 2 / 3).  Their weight rows are stored permuted inside every group of
 // 32 output channels (kernels.hip split_weight_rows_kernel: stored row 16t + 4g + r = channel 8g + 4t + r), so the two
 // 16-row accumulator tiles of a group leave lane group g = lane >> 4 with the 8 CONSECUTIVE channels 8g..8g+7 of one
 // position: 16 contiguous bytes of an sp32 / bf16 row or 32 of an f32 row.  No LDS staging, no second barrier: residual
@@ -301,9 +302,9 @@ __device__ __forceinline__ void split8(const float4 x, const float4 y, spx8_t& h
 }
 
 // MODE 0: f32 operands, v_mfma_f32_32x32x2_f32.  MODE 1: bf16 operands, v_mfma_f32_16x16x32_bf16.
-// MODE 2 ("bf16x3"): f32 activations split on the fly into bf16 hi+lo, weights pre-split (per 32-element K group:
-// 32 hi then 32 lo bf16), a.w ~= ah.wh + ah.wl + al.wh on the bf16 MFMA with f32 accumulation -- f32-grade
-// results (relative error ~2^-17 per product) at a third of the bf16 MFMA rate instead of a sixteenth.
+// MODE 2 ("x3"): f32 activations split on the fly into fp16 hi+lo, weights pre-split and pre-scaled (per 32-element K group:
+// 32 hi then 32 lo fp16), a.w ~= ah.wh + ah.wl + al.wh on the f16 MFMA with f32 accumulation -- f32-grade
+// results (relative error ~2^-22 per product) at a third of the 16-bit MFMA rate instead of a sixteenth.
 // MODE 3: as MODE 2 but the activations are ALREADY stored as sp32 pairs (written by a producer's epilogue), so the
 // A fragments are read like the weights and the main loop has no conversion arithmetic at all.
 template <int MODE, int BMT, int BN, int TILE_BYTES, typename AccT, int NFN, int NFM>
@@ -538,7 +539,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
     int cur = 0;
 
     // residual tile of this thread's epilogue rows: requested now, consumed after the last MFMA
-    constexpr bool DIRECT = MODE >= 2;  // split-bf16 modes: permuted weight rows, epilogue straight from the accumulators
+    constexpr bool DIRECT = MODE >= 2;  // split-fp16 modes: permuted weight rows, epilogue straight from the accumulators
     constexpr int NFN = IS_F32 ? WN / 32 : WN / 16;
     constexpr int NFM = IS_F32 ? WM / 32 : WM / 16;
     using D = DrainMap<BMT, BN>;
@@ -551,7 +552,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
     if constexpr (DIRECT) res_prefetch_direct<OUT, NFN, NFM>(p, m_base + wm * WM, n_base + wn * WN, lane, rdir);
     else res_prefetch<OUT, BMT, BN>(p, m_base, n_base, tid, rres);
 
-    static_assert(MODE < 2 || OUT != 1, "split-bf16 modes write f32 or sp32");
+    static_assert(MODE < 2 || OUT != 1, "split-fp16 modes write f32 or sp32");
     using acc_t = typename std::conditional<IS_F32, f32x16_t, f32x4_t>::type;
     acc_t acc[NFN][NFM];
 #pragma unroll
@@ -594,7 +595,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ weights direct (dtype 7 / 8)
-// The split-bf16 contraction of sp32 activations in a second structure (round 3; tools/gemm_lab.hip is its test bench):
+// The split-fp16 contraction of sp32 activations in a second structure (round 3; tools/gemm_lab.hip is its test bench):
 //   * the WEIGHT fragments never touch LDS.  The weights are stored once more in MFMA fragment order -- [N/16][K/32][hi, lo]
 //     [64 lanes][16 B], rows permuted like every split weight -- so a wave gets a whole fragment with ONE coalesced 1 KiB
 //     load straight into the registers the MFMA reads (inline asm: hipcc would otherwise drain the LDS-DMA queue for it);
@@ -973,7 +974,7 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
     const bool wdirect = dtype >= 7;  // 7 / 8: dtype 5 / 6 with the weights in fragment order (conv_gemm_wd_kernel)
     const bool a_split = dtype == 5 || dtype == 6 || wdirect, o_split = dtype == 4 || dtype == 5 || dtype == 7;
     const int vec = 16 / es;
-    const int bk = ROWB / es;  // 32 elements (f32, split-bf16) or 64 (bf16) per K-step
+    const int bk = ROWB / es;  // 32 elements (f32, split-fp16) or 64 (bf16) per K-step
     const long M = (long)d.batch * d.out_h * d.out_w;
     const long K1 = (long)d.kh * d.kw * d.cin;
     const long K = K1 + (x2 ? d.x2_cin : 0);

@@ -27,7 +27,7 @@ __device__ __forceinline__ void dma16(Rsrc rs, char* lds_wave_base, unsigned vof
 
 // XOR swizzle of the 16-byte chunks of a 128-byte tile row.  The key f((row>>1)&7) with f = (0,1,4,5,6,7,2,3) was
 // found by exhaustive search: it makes every ds_read_b128 fragment pattern used below (bf16 16x16x32, f32 32x32x2 and
-// the two-chunk f32 row read of the split-bf16 mode) conflict-free under the MI355X 16-lane-group banking.
+// the two-chunk f32 row read of the split-fp16 mode) conflict-free under the MI355X 16-lane-group banking.
 __device__ __forceinline__ int swz_key(int row) { return (int)((0x32765410u >> (((row >> 1) & 7) * 4)) & 7u); }
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ swz_key(row)) << 4); }
 
@@ -36,7 +36,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // The same function with erf from Abramowitz & Stegun 7.1.26 (1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p |z|)):
 // 14 vector instructions, no branch, against ~45 for the library erff (two divergent branches, a two-step exp).  Against
 // float64, |gelu_fast - gelu| <= 4.7e-7 over [-8, 8] -- the same bound the exact form has from rounding its own f32 result
-// (4.5e-7) --, with up to 5e-7 absolute on erf itself near 0.  Used where the arithmetic around it is the split-bf16 or
+// (4.5e-7) --, with up to 5e-7 absolute on erf itself near 0.  Used where the arithmetic around it is the split-fp16 or
 // bf16 one (4.5e-6 relative per contraction); the f32 mode keeps erff.
 __device__ __forceinline__ float gelu_fast(float x) {
     const float z = x * 0.70710678118654752440f, a = __builtin_fabsf(z);

@@ -136,7 +136,7 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ in, T* __restrict_
     st4<T>(out, idx * 4, v);
 }
 
-// Planar split-bf16 variant (input of stem_pool_kernel): the same zero-bordered image as two bf16 planes
+// Planar split-fp16 variant (input of stem_pool_kernel): the same zero-bordered image as two fp16 planes
 // [n,230,230,4], hi = bf16(v) and lo = bf16(v - hi), so that one 8-pixel tap row is 64 contiguous bytes per plane.
 __device__ __forceinline__ void st4_planar(bf16_t* hi, bf16_t* lo, long idx, const float* vin) {
     uint16_t h[4];
@@ -851,7 +851,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attention_kernel(const T* __restr
 }
 
 // ---- MFMA attention for 64-wide heads (wav2vec2 encoder layers, TransformerLayer 2) ---------------------------------
-// One workgroup (4 waves) per (window, head).  K is kept in LDS as bf16 rows (GEMM swizzle), V transposed and key-
+// One workgroup (8 waves) per (window, head).  K is kept in LDS as 16-bit rows (GEMM swizzle; fp16 in the x3 form, bf16 else), V transposed and key-
 // permuted, both as hi (+ lo in the split mode) planes.  Each wave takes 16-query tiles:
 //   S^T tile = K . Q^T   (swapped operands: a lane then holds, for ONE query lane&15, the keys 16t + 4(lane>>4) + r)
 //   softmax over keys     in-lane over its registers + 2 shuffles across the four lane groups
@@ -929,7 +929,7 @@ __global__ void __launch_bounds__(64 * ATTM_WAVES) attention_mfma_kernel(const T
             }
         }
     }
-    // ---- stage K (row-major) and V (transposed + permuted) as bf16 planes
+    // ---- stage K (row-major) and V (transposed + permuted) as 16-bit planes
     constexpr int ITEMS = SP * (D / 8), PASSES = ITEMS / NTHR, UB = PASSES < 4 ? PASSES : 4;
     static_assert(ITEMS % NTHR == 0 && PASSES % UB == 0 && NKT % ATTM_WAVES == 0, "whole staging passes, whole batches");
     for (int p0 = 0; p0 < PASSES; p0 += UB) {
@@ -1417,7 +1417,7 @@ int k_attention(avcer_ctx* ctx, const void* qkv, void* out, int n, int s, int he
     if (in_kind == 2 || (in_kind == 1) != (out_kind == 1))
         return set_err(ctx, AVCER_EINVAL, "attention: unsupported storage combination %d -> %d", in_kind, out_kind);
     const int grid = n * heads;
-    // bf16 / split-bf16 modes: QK^T and PV on the MFMA, 64- and 32-wide heads (the f32 mode keeps exact f32 arithmetic)
+    // bf16 / split-fp16 modes: QK^T and PV on the MFMA, 64- and 32-wide heads (the f32 mode keeps exact f32 arithmetic)
     if (in_kind == 1 || out_kind == 2) {
         const int nkt = s <= 128 ? 8 : 16;
         const int sp = nkt * 16, x3 = out_kind == 2;

@@ -271,7 +271,7 @@ class Engine:
         return int(self.lib.avcer_debug_tap_copied(self.ctx))
 
     def split_weights(self, w):
-        """f32 tensor (numel a multiple of 32) -> sp32 ACTIVATION layout (hi / lo bf16 per group of 32; int16 tensor of
+        """f32 tensor (numel a multiple of 32) -> sp32 ACTIVATION layout (hi / lo fp16 per group of 32; int16 tensor of
         2 * numel entries): the A operand of conv_gemm dtypes 5 / 6.  Not valid for weights: use split_weight_rows."""
         w = self._dev(w, torch.float32)
         out = torch.empty(w.numel() * 2, dtype=torch.int16, device=self.device)
@@ -314,24 +314,24 @@ class Engine:
                                              out_kind, self._stream()))
 
     def measure_ceilings(self):
-        """(bf16 MFMA TFLOP/s of a register-only MFMA loop, TB/s of a 1 GiB streaming copy) measured on this GPU."""
+        """(f16 MFMA TFLOP/s of a register-only v_mfma_f32_16x16x32_f16 loop, TB/s of a 1 GiB streaming copy) measured on this GPU."""
         a, b = C.c_double(0.0), C.c_double(0.0)
         self._check(self.lib.avcer_measure_ceilings(self.ctx, C.byref(a), C.byref(b), self._stream()))
         return a.value, b.value
 
     def stem_pool(self, planes_hi_lo, w_split, scale, bias, n: int):
-        """Kernel-level entry of the fused stem (csrc/fused.hip): planes int16 [2, n, 230, 230, 4] (bf16 hi plane, lo plane)
+        """Kernel-level entry of the fused stem (csrc/fused.hip): planes int16 [2, n, 230, 230, 4] (fp16 hi plane, lo plane)
         -> sp32 [n, 55, 55, 64] as int16 [n, 55, 55, 128]."""
         planes = self._dev(planes_hi_lo, torch.int16)
         if tuple(planes.shape) != (2, n, 230, 230, 4):
-            raise ValueError("stem_pool: planes [2, n, 230, 230, 4] int16 (bf16 bits)")
+            raise ValueError("stem_pool: planes [2, n, 230, 230, 4] int16 (fp16 bits)")
         y = torch.empty(n, 55, 55, 128, dtype=torch.int16, device=self.device)
         self._check(self.lib.avcer_stem_pool(self.ctx, _ptr(planes), n * 230 * 230 * 4 * 2, _ptr(w_split), _ptr(scale), _ptr(bias),
                                              _ptr(y), n, self._stream()))
         return y
 
     def stem_pool_u8(self, frames_u8, w_split, scale, shifts9):
-        """The fused stem fed with u8 frames [n, h, w, 3] RGB (preprocessing inside, raw pixels as exact bf16 operands);
+        """The fused stem fed with u8 frames [n, h, w, 3] RGB (preprocessing inside, raw pixels as exact fp16 operands);
         shifts9 f32 [9, 64] from packing.stem_border_shifts.  -> sp32 [n, 55, 55, 64] as int16 [n, 55, 55, 128]."""
         fr = self._dev(frames_u8, torch.uint8)
         n, h, w = int(fr.shape[0]), int(fr.shape[1]), int(fr.shape[2])
