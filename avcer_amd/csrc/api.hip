@@ -561,16 +561,12 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
         net.tap("avgpool", pooled, (size_t)nb * 2048 * 4);
         float* fo = feats ? feats + (size_t)s0 * 512 : feat_ws;
         {
-            // fc1 on the exact f32 MFMA in the x3 mode too.  After the 7 x 7 average pool the position-independent part
-            // of the trunk's error is what is left (tools/x3_stage_error.py: 1.3e-5 relative at layer4, 4.6e-6 pooled),
-            // and round 3's split-bf16 fc1 on top of it raised the feature / logit error by 40 % (6.4e-6) -- for a 4.3 GFLOP
-            // layer of 32 tiles that takes the same 50 us either way.
-            const int x3_saved = net.x3;
-            net.x3 = 0;
+            // fc1 in the mode's own arithmetic.  Rounds 2-3 ran it on the f32 MFMA in the x3 mode as well, because a bf16-pair
+            // fc1 put 40 % on top of the pooled features' error; the fp16-pair contraction carries 7e-8 and costs a quarter
+            // of the time of the f32 MFMA on this launch-latency-bound layer (16 tiles at batch 256: 114 -> ~30 us).
             avcer_conv_desc fd = linear_desc(nb, 2048, 512, 0);
             fd.tile_n = 64;  // 128 x 64 tiles: twice the blocks of a grid that does not fill the chip anyway
             net.gemm(fd, "fc1.w", nullptr, net.F("fc1.b"), pooled, nullptr, fo, 0, 0);
-            net.x3 = x3_saved;
         }
         if (logits || probs)
             net.chk(k_small_linear(ctx, fo, net.F("fc2.w"), net.F("fc2.b"), logits ? logits + (size_t)s0 * 7 : nullptr,

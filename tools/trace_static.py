@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""The static CNN at a given batch under `rocprofv3 --kernel-trace`: every launch of the LAST forward pass with its duration
+and grid -- where a small batch (BASELINE configs[1]: 256 frames) loses against the 2048-frame pass.
+
+    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ts -o t -- python3 tools/trace_static.py run 256
+    python3 tools/trace_static.py show gpurun_out/ts
+"""
+import csv
+import glob
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def run(batch):
+    import torch
+    from avcer_amd import synth
+    from avcer_amd.engine import MODE_F16X3, Engine
+
+    eng = Engine(0)
+    eng.load_static(synth.static_state_dict(42))
+    frames = torch.from_numpy(synth.face_frames(1, batch)).cuda()
+    for _ in range(4):
+        eng.static_forward(frames, MODE_F16X3)
+        torch.cuda.synchronize()
+
+
+def show(d):
+    f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    starts = [i for i, r in enumerate(rows) if "stem_pool" in r["Kernel_Name"]]
+    first = starts[-1]
+    t0, total = int(rows[first]["Start_Timestamp"]), 0.0
+    for r in rows[first:]:
+        n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).replace("void ", "")
+        n = re.sub(r"\(.*", "", n)
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        total += dur
+        grid = int(r.get("Grid_Size_X", r.get("Grid_Size", "0")) or 0) // max(1, int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", "256")) or 256))
+        print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} us  {dur:8.1f} us  blocks {grid:6d}  {n[:90]}")
+    print(f"sum of kernel durations: {total / 1e3:.3f} ms; first launch to last end: {(int(rows[-1]['End_Timestamp']) - t0) / 1e6:.3f} ms")
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[2]) if len(sys.argv) > 2 else 256) if sys.argv[1] == "run" else show(sys.argv[2])
