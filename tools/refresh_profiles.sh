@@ -6,8 +6,6 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=gpurun_out/refresh
 rm -rf "$O" && mkdir -p "$O"
-timeout -k 10 500 python3 bench.py --steps 20 --warmup 5 > "$O/bench_line.json" 2> "$O/bench.err"
-echo "bench done" && tail -c 300 "$O/bench_line.json"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o x3 -- python3 bench.py --steps 5 --warmup 2 --no-secondary --no-cpu --no-configs --no-overlap > "$O/stats.log" 2>&1
 echo "stats done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_FETCH_SIZE" -- python3 bench.py --steps 1 --warmup 1 --no-secondary --no-cpu --no-configs --no-events --no-overlap > "$O/pmc_f.log" 2>&1
@@ -18,6 +16,10 @@ python3 tools/pmc_traffic.py "$O/pmc_FETCH_SIZE" "$O/pmc_WRITE_SIZE" --out "$O/t
 find "$O/stats" -name "*kernel_stats.csv" -exec cp {} "$O/kernel_stats.csv" \;
 # the raw counter dumps are large: keep the summaries only
 rm -rf "$O/pmc_FETCH_SIZE" "$O/pmc_WRITE_SIZE" "$O/stats"
+# the bench line quotes the PMC traffic of THESE sources: refresh the committed figure first, then take the line
+cp "$O/traffic_x3.json" profiles/r04_traffic_x3.json
+timeout -k 10 500 python3 bench.py --steps 20 --warmup 5 > "$O/bench_line.json" 2> "$O/bench.err"
+echo "bench done" && tail -c 300 "$O/bench_line.json"
 timeout -k 10 300 python3 tools/trace_step.py run > /dev/null 2>&1 || true
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/trace" -o t -- python3 tools/trace_step.py run > "$O/trace.log" 2>&1
 python3 tools/trace_step.py show "$O/trace" > "$O/step_trace.txt" 2>&1 || true
