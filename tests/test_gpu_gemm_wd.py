@@ -61,12 +61,12 @@ CONVS = [
     (2, 31, 1, 64, 6, 1, 3, 0, 2, 256, 0),      # Conv1d k6 s3 dil2 (the audio head's kind: un-padded, dilated, several taps)
     (2, 40, 1, 512, 2, 1, 2, 0, 1, 512, 2),     # Conv1d k2 s2 + gelu (feature extractor)
     (9, 55, 55, 64, 1, 1, 1, 0, 1, 256, 1),     # ragged M: 27225 positions
-    # the resident-patch form (conv_gemm_wdp_kernel: 3x3 / stride 1 / pad 1 whose halo patch fits 256 slots)
+    # more 3x3 / stride 1 / pad 1 shapes (written for round 4's resident-patch experiment, profiles/experiments/README.md)
     (5, 14, 14, 256, 3, 3, 1, 1, 1, 512, 1),    # ragged M (980 positions), two n tiles, tiles that cross image boundaries
     (11, 14, 14, 512, 3, 3, 1, 1, 1, 256, 0),   # 16 channel chunks, no activation, 17 tiles
-    (1, 14, 14, 64, 3, 3, 1, 1, 1, 256, 1),     # one image, two chunks: the shortest K loop the form takes
-    (13, 7, 7, 512, 3, 3, 1, 1, 1, 512, 1),     # stage 4 conv2: 128 positions span four images -> falls back to the gathered form
-    (2, 28, 28, 128, 3, 3, 1, 1, 1, 256, 1),    # patch too wide for the slots -> gathered form
+    (1, 14, 14, 64, 3, 3, 1, 1, 1, 256, 1),     # one image, two chunks: the shortest K loop
+    (13, 7, 7, 512, 3, 3, 1, 1, 1, 512, 1),     # stage 4 conv2: 128 positions span four images
+    (2, 28, 28, 128, 3, 3, 1, 1, 1, 256, 1),    # stage 2 geometry
 ]
 
 
