@@ -127,8 +127,8 @@ def pmc_traffic(mode, clips):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--clips", type=int, default=128, help="clips per GPU per step")
     ap.add_argument("--mode", choices=["x3", "fp32", "bf16"], default="x3", help="arithmetic of the headline value")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other arithmetic modes")
