@@ -8,6 +8,7 @@ waveform at 16 kHz go in; per-frame predictions come out.  Plotting and Grad-CAM
 from __future__ import annotations
 
 import os
+import time
 from typing import Optional, Sequence
 
 import numpy as np
@@ -30,7 +31,9 @@ def run_inference(engine, frames_bgr, wav, fps: float, detector=None, detections
     `detector`: a `face_tiles.RetinaFacePredictor` (threshold 0.8 in the reference); or pass per-frame `detections`.
     Defaults follow `run_inference`'s signature (Rule 2 weights on, Rule 1 mask off; `run.py --help` flips them).
     Returns a dict: av / vs / vd / a predictions (int32 [T], compound class per frame), `compound_prob` f64 [4,T,7],
-    `static_probs`, `dynamic_logits` [T,7], `audio_rows` / `audio_frames` (the audio table), `records` (face files)."""
+    `static_probs`, `dynamic_logits` [T,7], `audio_rows` / `audio_frames` (the audio table), `records` (face files),
+    `real_time_factor` (elapsed / video duration, the figure run.py:307 prints)."""
+    start_time = time.time()                                                # run.py:200
     frames = frames_bgr if torch.is_tensor(frames_bgr) else torch.from_numpy(np.ascontiguousarray(frames_bgr))
     total_frames = int(frames.shape[0])
     if detections is None:
@@ -53,6 +56,8 @@ def run_inference(engine, frames_bgr, wav, fps: float, detector=None, detections
     am = am.cpu().numpy()
     out = {name.lower(): am[i] for i, name in enumerate(MODEL_ORDER)}
     out.update(compound_prob=prob.cpu().numpy(), static_probs=static_probs.cpu().numpy(),
-               dynamic_logits=dynamic_logits.cpu().numpy(), audio_rows=rows, audio_frames=aud_frames, records=records,
-               real_time_factor=None)
+               dynamic_logits=dynamic_logits.cpu().numpy(), audio_rows=rows, audio_frames=aud_frames, records=records)
+    # "Real-time factor for compound expression prediction" as run.py:304-307 prints it: elapsed / video duration (the
+    # device -> host copies above have synchronised the stream, so the clock covers all the work)
+    out["real_time_factor"] = (time.time() - start_time) / (total_frames / fps)
     return out

@@ -52,6 +52,7 @@ def test_run_inference_matches_oracle_chain(engine_all, sd_static, sd_dynamic, s
     for i, name in enumerate(("av", "vs", "vd", "a")):
         np.testing.assert_array_equal(out[name], am[i])
     assert (tmp_path / "static__clip_x.csv").exists() and (tmp_path / "audio" / "clip_x.csv").exists()
+    assert 0 < out["real_time_factor"] < 60  # elapsed / video duration, as run.py:307 prints it
 
 
 def test_run_inference_needs_a_first_track(engine_all):
