@@ -3,7 +3,7 @@
 // Answers, before the split type of the fast mode moves from bf16 to fp16:
 //   1. does v_mfma_f32_16x16x32_f16 keep SUBNORMAL f16 A / B operands (lo halves of small values are subnormal)?
 //   2. does the f32 -> f16 conversion of the epilogues produce subnormals (round to nearest even) instead of flushing?
-//   3. the register-only issue rate of the f16 form next to the bf16 form on this GPU.
+//   3. the register-only issue rate of the f16 form next to the bf16 form on this GPU, and of the f32 mode's v_mfma_f32_32x32x2_f32.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -57,6 +57,22 @@ __global__ void __launch_bounds__(256) rate_kernel(float* out, int iters) {
     }
     float s = 0.f;
     for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678f) out[0] = s;
+}
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+// the f32 mode's instruction: v_mfma_f32_32x32x2_f32, 4 independent accumulators per wave (the kernel's 2 x 2 tiles)
+__global__ void __launch_bounds__(256) rate_f32_kernel(float* out, int iters) {
+    f32x16_t acc[4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    const float a = 0.001f * threadIdx.x, b = 0.002f * (threadIdx.x + 3);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][7];
     if (s == 12345.678f) out[0] = s;
 }
 
@@ -125,6 +141,17 @@ int main() {
             const double flop = 2.0 * 16 * 16 * 32 * 8.0 * iters * 4.0 * blocks;
             printf("%s 16x16x32 register-only: %.1f TFLOP/s (%.2f ms)\n", f16 ? "f16 " : "bf16", flop / ms * 1e-9, ms);
         }
+    }
+    for (int rep = 0; rep < 3; ++rep) {
+        const int it32 = 10000, waves_per_simd = 2;
+        hipEventRecord(e0);
+        rate_f32_kernel<<<256 * waves_per_simd, 256>>>(dout, it32);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double flop = 2.0 * 32 * 32 * 2 * 4.0 * it32 * 4.0 * 256 * waves_per_simd;
+        printf("f32  32x32x2 register-only (2 waves per SIMD, 4 accumulators): %.1f TFLOP/s (%.2f ms)\n", flop / ms * 1e-9, ms);
     }
     return 0;
 }
