@@ -476,6 +476,38 @@ def run_inference_bench(pipe, modes, device, do_cpu, seconds=30, fps=25, h=360, 
     return out
 
 
+def per_call_latency(pipe, modes, device, iters=30):
+    """The drop-in mirrors driven the way the reference's own loops drive its models (get_prob_video.py:91-178,
+    get_prob_audio_8_cl.py:78-101): ONE frame / LSTM window / 4 s audio window per call.  Milliseconds per call; these
+    launches are single-tile latency chains (a HIP graph of the call replays in the same time, tools/graph_probe.py)."""
+    from avcer_amd.models import DynamicModel
+
+    x = torch.randn(1, 3, 224, 224, device=device) * 50.0
+    win = torch.randn(1, 10, 512, device=device)
+    wav = torch.randn(1, 64000, device=device)
+    dyn = pipe.dynamic
+    out = {}
+
+    def ms(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) / iters * 1e3
+
+    saved = (pipe.static.mode, pipe.audio.mode, dyn.mode)
+    for name in ("x3", "fp32"):
+        pipe.static.mode = pipe.audio.mode = dyn.mode = modes[name]
+        out[name] = {"static_frame_ms": ms(lambda: pipe.static(x)), "lstm_window_ms": ms(lambda: dyn(win)),
+                     "audio_4s_window_ms": ms(lambda: pipe.audio(wav))}
+    pipe.static.mode, pipe.audio.mode, dyn.mode = saved
+    out["note"] = "one call per frame / window through StaticModel / DynamicModel / AudioModel, as INTEGRATION.md section 3 swaps them in"
+    return out
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -624,6 +656,8 @@ def main():
                                       "dtype": DTYPE[name], "max_dprob_vs_cpu_oracle": d2, "argmax_identical": s2,
                                       "meets_parity_gate": bool(d2 < 1e-4) if d2 is not None else None,
                                       "roofline": res["roofline"]}
+        if cfgs is not None:
+            cfgs["per_call_latency"] = per_call_latency(pipe, modes, device)
         if cfgs is not None and not args.no_run_inference:
             log("configs.run_inference: one 30 s video through avcer_amd/run.py")
             cfgs["run_inference"] = run_inference_bench(pipe, modes, device, do_cpu and world == 1)
