@@ -461,7 +461,7 @@ struct BneckParams {
 // conv2 / conv3 products, of the residual reads and of the output bytes; every value written is the one the full-
 // resolution evaluation would have put at that position.
 template <int P, int BM, bool NEXT, int NQX, bool PATCH, int SUB = 1>
-__global__ void __launch_bounds__(256, 2) bneck_kernel(const BneckParams p) {
+__global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const BneckParams p) {
     static_assert(SUB == 1 || (SUB == 2 && !NEXT && NQX == 0 && !PATCH), "the strided form is the plain last block of a stage");
     constexpr int NQ = P / 32;            // K-steps of a P-channel contraction
     constexpr int NQT = NQ + NQX;         // K-steps of conv3 (+ downsample)
