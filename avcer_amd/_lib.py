@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 2          # include/avcer_hip.h AVCER_ABI_VERSION: struct layouts, argument lists and buffer sizes below
+ABI_VERSION = 3          # include/avcer_hip.h AVCER_ABI_VERSION: struct layouts, argument lists and buffer sizes below
 SPLIT_TRAILER = 256      # include/avcer_hip.h AVCER_SPLIT_TRAILER: bytes behind a split weight matrix (its scale)
 
 # name -> (restype, argtypes); exactly the symbols include/avcer_hip.h declares
@@ -41,6 +41,7 @@ SIGNATURES = {
     "avcer_ctx_create": (C.c_int, [C.c_int, C.POINTER(c_ctx)]),
     "avcer_ctx_destroy": (None, [c_ctx]),
     "avcer_last_error": (C.c_char_p, [c_ctx]),
+    "avcer_x3_overflow_count": (C.c_int, [c_ctx, C.c_int, C.POINTER(C.c_int64), c_stream]),
     "avcer_load_static": (C.c_int, [c_ctx, C.c_void_p, C.c_size_t]),
     "avcer_load_dynamic": (C.c_int, [c_ctx, C.c_void_p, C.c_size_t]),
     "avcer_load_audio": (C.c_int, [c_ctx, C.c_void_p, C.c_size_t]),
@@ -88,6 +89,8 @@ SIGNATURES = {
     "avcer_gemm_stats": (C.c_int, [c_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
     "avcer_profile_enable": (C.c_int, [c_ctx, C.c_int]),
     "avcer_profile_read": (C.c_int, [c_ctx, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "avcer_profile_read_families": (C.c_int, [c_ctx, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                              C.POINTER(C.c_double)]),
     "avcer_debug_tap": (C.c_int, [c_ctx, C.c_char_p, C.c_void_p, C.c_size_t]),
     "avcer_debug_tap_copied": (C.c_int64, [c_ctx]),
 }

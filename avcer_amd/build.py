@@ -26,33 +26,38 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every translation unit to an object and link the shared library. Returns the .so path."""
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None, tag: str = "") -> str:
+    """Compile every translation unit to an object and link the shared library. Returns the .so path.
+    `extra_flags` / `out` / `tag`: lab builds only (tools/build_lab.sh: the SAME sources and flags plus e.g. a -D switch, objects
+    suffixed with `tag`, library written to `out`) -- the product build passes none of them."""
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    lib = out or LIB
+    objdir = os.path.dirname(lib) if out else CSRC
+    os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, src.replace(".hip", tag + ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for cmd, p in procs:
-        out, _ = p.communicate()
+        outp, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out))
-        if verbose and out.strip():
-            print(out)
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), outp))
+        if verbose and outp.strip():
+            print(outp)
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stdout))
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

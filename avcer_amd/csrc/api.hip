@@ -322,6 +322,12 @@ extern "C" int avcer_ctx_create(int device, avcer_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         c->block_slots = 2 * prop.multiProcessorCount;  // two 256-thread MFMA blocks per CU (partitioned modes have fewer CUs)
+    if (hipMalloc((void**)&c->ovf, 256) != hipSuccess || hipMemset(c->ovf, 0, 256) != hipSuccess) {
+        (void)hipGetLastError();
+        if (c->ovf) (void)hipFree(c->ovf);
+        delete c;
+        return AVCER_ENOMEM;
+    }
     *out = c;
     return AVCER_OK;
 }
@@ -337,10 +343,27 @@ extern "C" void avcer_ctx_destroy(avcer_ctx* ctx) {
     for (auto& b : ctx->ws)
         if (b.p) (void)hipFree(b.p);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    if (ctx->ovf) (void)hipFree(ctx->ovf);
     delete ctx;
 }
 
 extern "C" const char* avcer_last_error(const avcer_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+// The run-time signal of the x3 mode's range contract (split_dev.h): how many threads have turned a FINITE activation of
+// magnitude >= 65520 into an infinite fp16 hi half since the last reset -- every forward pass of this context, every mode-2
+// kernel-level entry.  0 = every NaN in an output came in through the input (the reference's empty audio window); > 0 = the
+// outputs since the last reset are not to be trusted: run the call again in AVCER_MODE_FP32.  Waits for `stream`.
+extern "C" int avcer_x3_overflow_count(avcer_ctx* ctx, int reset, int64_t* count, avcer_stream_t stream) {
+    if (!ctx || !count) return ctx ? set_err(ctx, AVCER_EINVAL, "x3_overflow_count: null count") : AVCER_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned host = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&host, ctx->ovf, sizeof(host), hipMemcpyDeviceToHost, st));
+    if (reset) HIP_TRY(ctx, hipMemsetAsync(ctx->ovf, 0, sizeof(host), st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    *count = (int64_t)host;
+    return AVCER_OK;
+}
 
 extern "C" int avcer_load_static(avcer_ctx* ctx, const void* blob, size_t nbytes) {
     if (!ctx) return AVCER_EINVAL;
@@ -1084,6 +1107,28 @@ extern "C" int avcer_set_static_batch(avcer_ctx* ctx, int frames) {
 extern "C" int avcer_profile_enable(avcer_ctx* ctx, int on) {
     if (!ctx) return AVCER_EINVAL;
     ctx->prof = on != 0;
+    ctx->prof_used = 0;
+    for (int f = 0; f < 8; ++f) { ctx->fam_launches[f] = 0; ctx->fam_flops[f] = 0.0; ctx->fam_bytes[f] = 0.0; }
+    return AVCER_OK;
+}
+
+// The same events by kernel family (AVCER_FAM_*): summed HIP-event milliseconds, launches, algorithmic FLOPs and compulsory
+// HBM bytes of the launches recorded since avcer_profile_enable / the last read; arrays of n_fam entries; synchronises.
+extern "C" int avcer_profile_read_families(avcer_ctx* ctx, int n_fam, double* ms, int64_t* launches, double* flops, double* bytes) {
+    if (!ctx || n_fam < 1 || n_fam > 8 || !ms || !launches || !flops || !bytes) return ctx ? set_err(ctx, AVCER_EINVAL, "profile_read_families: bad arguments") : AVCER_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int f = 0; f < n_fam; ++f) { ms[f] = 0.0; launches[f] = 0; flops[f] = 0.0; bytes[f] = 0.0; }
+    for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->prof_ev[i + 1]));
+        float t = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->prof_ev[i], ctx->prof_ev[i + 1]));
+        const int f = ctx->prof_fam[i / 2];
+        if (f < n_fam) ms[f] += t;
+    }
+    for (int f = 0; f < n_fam && f < 8; ++f) {
+        launches[f] = ctx->fam_launches[f]; flops[f] = ctx->fam_flops[f]; bytes[f] = ctx->fam_bytes[f];
+        ctx->fam_launches[f] = 0; ctx->fam_flops[f] = 0.0; ctx->fam_bytes[f] = 0.0;
+    }
     ctx->prof_used = 0;
     return AVCER_OK;
 }

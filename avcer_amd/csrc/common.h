@@ -46,12 +46,20 @@ struct avcer_ctx {
     int block_slots = 512;    // 2 x hipDeviceProp_t::multiProcessorCount: what grid_rounds() divides a grid by
     // grow-only workspace arenas (activations), one per pipeline
     DevBuf ws[8];
+    // device counter of the x3 mode's range contract: += 1 per thread that split a finite |x| >= 65520 into an fp16 pair
+    // (split_dev.h sp_commit); read and reset by avcer_x3_overflow_count
+    unsigned* ovf = nullptr;
     int64_t gemm_launches = 0;
     double gemm_flops = 0.0;
     // live HIP-event timing of conv_gemm launches (avcer_profile_*): pairs of events on the launch stream
     bool prof = false;
     std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_fam;  // kernel family of every event pair (AVCER_FAM_*)
     size_t prof_used = 0;
+    // per kernel family since the last avcer_profile_read*: launches, algorithmic FLOPs and compulsory HBM bytes
+    int64_t fam_launches[8] = {0};
+    double fam_flops[8] = {0};
+    double fam_bytes[8] = {0};
     // one-shot debug tap (avcer_debug_tap): copy the named intermediate activation to a caller buffer
     std::string tap_name;
     void* tap_dst = nullptr;
@@ -82,7 +90,10 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
                      const float* scale, const float* bias, const void* residual, void* y, hipStream_t st,
                      const void* x2 = nullptr);
 
-int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1);
+// kernel families of the MFMA launches (avcer_profile_read_families; include/avcer_hip.h AVCER_FAM_*)
+enum { FAM_GEMM = 0, FAM_GEMM_WD = 1, FAM_CHAIN = 2, FAM_TAIL = 3, FAM_STEM = 4, FAM_COUNT = 5 };
+// `flops` / `bytes`: algorithmic work and compulsory HBM traffic of the launch (operands read once + outputs written once)
+int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1, int family, double flops, double bytes);
 
 // ---- fused.hip (split-fp16 mode only)
 // planes: fp16 hi plane [n][230][230][4] followed plane_bytes later by the lo plane; y: sp32 [n][55][55][64]

@@ -48,14 +48,19 @@ __device__ __forceinline__ spx8_t ldfrag(const char* tile, int row, int chunk) {
 }
 
 // 8 f32 values -> fp16 hi / lo fragments (value = hi + lo + O(2^-22))
-__device__ __forceinline__ void split8v(const float (&v)[8], spx8_t& hi, spx8_t& lo) {
+__device__ __forceinline__ void split8v(const float (&v)[8], spx8_t& hi, spx8_t& lo, sp_flags_t& ovm) {
+    float a = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float x = sp_value(v[j]);  // one f32 number for both halves (split_dev.h)
-        const spe_t h = (spe_t)x;
-        hi[j] = h;
-        lo[j] = (spe_t)(x - (float)h);
+    for (int j = 0; j < 8; j += 2) {
+        const float x0 = sp_value(v[j]), x1 = sp_value(v[j + 1]);  // one f32 number for both halves (split_dev.h)
+        a = sp_max2(a, x0, x1);
+        const spe_t h0 = (spe_t)x0, h1 = (spe_t)x1;
+        hi[j] = h0;
+        hi[j + 1] = h1;
+        lo[j] = (spe_t)(x0 - (float)h0);
+        lo[j + 1] = (spe_t)(x1 - (float)h1);
     }
+    sp_flag(ovm, a);  // range contract: |x| < 65504 (split_dev.h sp_commit)
 }
 
 __device__ __forceinline__ void unpack8(const uint4 h, const uint4 l, float (&r)[8]) {
@@ -94,6 +99,7 @@ struct StemParams {
     const float* bias;
     char* Y;               // sp32 [n][55][55][64]
     int n;
+    unsigned* ovf;         // the context's range-contract counter (split_dev.h sp_commit)
 };
 
 constexpr int ST_TH = 8, ST_TW = 7;                       // pooled tile
@@ -202,6 +208,7 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
     }
     __syncthreads();
     // 3x3/2 max-pool over the image (no padding: video.py:103), 8 channels per thread, whole-line sp32 stores
+    sp_flags_t ovm = 0;  // range contract of the sp32 output (split_dev.h sp_commit)
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int item = pass * 256 + tid;
@@ -229,12 +236,13 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) if (anynan[j]) m[j] = NAN;  // like torch's max-pool
         spx8_t hi, lo;
-        split8v(m, hi, lo);
+        split8v(m, hi, lo, ovm);
         const long e = (((long)b * 55 + py) * 55 + px) * 64 + c8 * 8;
         char* yp = p.Y + sp32_byte(e);
         *reinterpret_cast<spx8_t*>(yp) = hi;
         *reinterpret_cast<spx8_t*>(yp + 64) = lo;
     }
+    sp_commit(p.ovf, ovm);
 }
 
 // The stem of the x3 mode when the input is the u8 frames (avcer_static_forward): same tiling, but
@@ -366,6 +374,7 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
 #undef AVCER_STEM_W
     // BN + ReLU -> f32 [256 positions][32 channels] image (over the patch and the ring: every wave is past the last barrier),
     // then the 3x3/2 max-pool (no padding: video.py:103) of those 32 channels; twice
+    sp_flags_t ovm = 0;  // range contract of the sp32 output (split_dev.h sp_commit)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -413,7 +422,7 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
 #pragma unroll
                 for (int j = 0; j < 8; ++j) if (anynan[j]) m[j] = NAN;  // like torch's max-pool
                 spx8_t hi, lo;
-                split8v(m, hi, lo);
+                split8v(m, hi, lo, ovm);
                 const long e = (((long)b * 55 + py) * 55 + px) * 64 + 32 * half + c8 * 8;
                 char* yp = p.Y + sp32_byte(e);
                 *reinterpret_cast<spx8_t*>(yp) = hi;
@@ -422,6 +431,7 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
         }
         if (half == 0) __syncthreads();  // the pool of the first half has read the image the second half overwrites
     }
+    sp_commit(p.ovf, ovm);
 }
 
 // ------------------------------------------------------------------------------------------------ bottleneck chain
@@ -437,6 +447,7 @@ struct BneckParams {
     unsigned t1_bytes;
     int M, H, Wd;       // M = nb * H * Wd positions (SUB > 1: nb * OH * OW, see bneck_kernel)
     int OH, OW;         // SUB > 1: the output grid, position (oy, ox) <-> input position (SUB oy, SUB ox)
+    unsigned* ovf;      // the context's range-contract counter (split_dev.h sp_commit)
 };
 
 // BM positions per block, 4 waves, each wave owns BM/4 positions and ALL channels (so that a position's whole T2 /
@@ -669,23 +680,24 @@ __global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const Bneck
     issue_group(0);  // the tile buffers are free: phase A ended on a barrier
 
     // residual rows of this lane: position m_t = m_base + wave*BM/4 + 16 t + (lane & 15); 16 bytes hi + 16 bytes lo per group
-    long x_row[NT];  // byte offset of this lane's piece of the residual row (SUB == 1: and of the block-output row, same shape)
-    long o_row[SUB > 1 ? NT : 1];  // SUB > 1: byte offset of the piece of the (compact) output row
-    long m_row[NT];  // position (clamped to 0 past M: loads stay in bounds, stores are predicated)
+    // 32-bit byte offsets (the launcher keeps every tensor of a pass under 4 GiB; two registers fewer per row than pointers)
+    unsigned x_row[NT];  // byte offset of this lane's piece of the residual row (SUB == 1: and of the block-output row, same shape)
+    unsigned o_row[SUB > 1 ? NT : 1];  // SUB > 1: byte offset of the piece of the (compact) output row
+    int m_row[NT];  // position (clamped to 0 past M: loads stay in bounds, stores are predicated)
     bool m_ok[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const long m = (long)m_base + wave * (BM / 4) + t * 16 + l15;
         m_ok[t] = m < p.M;
-        m_row[t] = m_ok[t] ? m : 0;
+        m_row[t] = m_ok[t] ? (int)m : 0;
         if constexpr (SUB == 1) {
-            x_row[t] = m_row[t] * (4L * P * 4) + 16 * g;
+            x_row[t] = (unsigned)(m_row[t] * (4L * P * 4) + 16 * g);
         } else {
-            const int mm = (int)m_row[t];
+            const int mm = m_row[t];
             const int ox = mm % p.OW, yb = mm / p.OW;
             const int oy = yb % p.OH, b = yb / p.OH;
-            x_row[t] = (((long)b * p.H + SUB * oy) * p.Wd + SUB * ox) * (4L * P * 4) + 16 * g;
-            o_row[t] = m_row[t] * (4L * P * 4) + 16 * g;
+            x_row[t] = (unsigned)((((long)b * p.H + SUB * oy) * p.Wd + SUB * ox) * (4L * P * 4) + 16 * g);
+            o_row[t] = (unsigned)(m_row[t] * (4L * P * 4) + 16 * g);
         }
     }
     // downsample operand: the NQX K-steps of this lane's positions as B fragments, straight from global memory
@@ -693,7 +705,7 @@ __global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const Bneck
     if constexpr (NQX > 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const char* xp = p.X + m_row[t] * (NQX * 128L) + 16 * g;
+            const char* xp = p.X + (long)m_row[t] * (NQX * 128L) + 16 * g;
 #pragma unroll
             for (int q = 0; q < NQX; ++q) {
                 xh[q][t] = *reinterpret_cast<const spx8_t*>(xp + q * 128);
@@ -710,7 +722,7 @@ __global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const Bneck
                 h[t] = make_uint4(0u, 0u, 0u, 0u);  // no residual: the downsample branch is part of the contraction
                 l[t] = make_uint4(0u, 0u, 0u, 0u);
             } else {
-                const char* rp = p.X + x_row[t] + G * 128;
+                const char* rp = p.X + (size_t)x_row[t] + G * 128;
                 h[t] = *reinterpret_cast<const uint4*>(rp);
                 l[t] = *reinterpret_cast<const uint4*>(rp + 64);
             }
@@ -720,6 +732,7 @@ __global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const Bneck
     load_res(1, rh[1], rl[1]);
 
     // T2 as B-operand fragments: K-step q = channels 32q..32q+31, lane group g holds 8g..8g+7 (weight rows were permuted)
+    sp_flags_t ovm = 0;  // lanes that split a finite |x| >= 65520 into an fp16 pair (split_dev.h sp_commit)
     spx8_t t2h[NQ][NT], t2l[NQ][NT];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -731,7 +744,7 @@ __global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const Bneck
                                 relu_nan(__builtin_fmaf(lo4[2], s2, b0.z)), relu_nan(__builtin_fmaf(lo4[3], s2, b0.w)),
                                 relu_nan(__builtin_fmaf(hi4[0], s2, b1.x)), relu_nan(__builtin_fmaf(hi4[1], s2, b1.y)),
                                 relu_nan(__builtin_fmaf(hi4[2], s2, b1.z)), relu_nan(__builtin_fmaf(hi4[3], s2, b1.w))};
-            split8v(v, t2h[q][t], t2l[q][t]);
+            split8v(v, t2h[q][t], t2l[q][t], ovm);
         }
     }
     f32x4_t acc1[NEXT ? P / 16 : 1][NT];
@@ -784,9 +797,9 @@ __global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const Bneck
                                 relu_nan(__builtin_fmaf(lo4[2], s3, b0.z) + r[2]), relu_nan(__builtin_fmaf(lo4[3], s3, b0.w) + r[3]),
                                 relu_nan(__builtin_fmaf(hi4[0], s3, b1.x) + r[4]), relu_nan(__builtin_fmaf(hi4[1], s3, b1.y) + r[5]),
                                 relu_nan(__builtin_fmaf(hi4[2], s3, b1.z) + r[6]), relu_nan(__builtin_fmaf(hi4[3], s3, b1.w) + r[7])};
-            split8v(v, oh[t], ol[t]);
+            split8v(v, oh[t], ol[t], ovm);
             if (m_ok[t]) {
-                char* yp = p.OUT + (SUB == 1 ? x_row[t] : o_row[SUB > 1 ? t : 0]) + G * 128;
+                char* yp = p.OUT + (size_t)(SUB == 1 ? x_row[t] : o_row[SUB > 1 ? t : 0]) + G * 128;
                 *reinterpret_cast<spx8_t*>(yp) = oh[t];
                 *reinterpret_cast<spx8_t*>(yp + 64) = ol[t];
             }
@@ -821,16 +834,16 @@ __global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const Bneck
                                     relu_nan(__builtin_fmaf(hi4[0], s1n, b1.x)), relu_nan(__builtin_fmaf(hi4[1], s1n, b1.y)),
                                     relu_nan(__builtin_fmaf(hi4[2], s1n, b1.z)), relu_nan(__builtin_fmaf(hi4[3], s1n, b1.w))};
                 spx8_t hi, lo;
-                split8v(v, hi, lo);
+                split8v(v, hi, lo, ovm);
                 if (m_ok[t]) {
-                    const long m = (long)m_base + wave * (BM / 4) + t * 16 + l15;
-                    char* yp = p.T1N + m * (P * 4) + q * 128 + 16 * g;
+                    char* yp = p.T1N + (long)m_row[t] * (P * 4) + q * 128 + 16 * g;  // m_row == the position wherever m_ok
                     *reinterpret_cast<spx8_t*>(yp) = hi;
                     *reinterpret_cast<spx8_t*>(yp + 64) = lo;
                 }
             }
         }
     }
+    sp_commit(p.ovf, ovm);
 }
 
 
@@ -935,6 +948,7 @@ __global__ void __launch_bounds__(512, 2) bneck_tail2_kernel(const BneckParams p
     f32x4_t acc1[P / 16];
 #pragma unroll
     for (int i = 0; i < P / 16; ++i) acc1[i] = f32x4_t{0};
+    sp_flags_t ovm = 0;  // lanes that split a finite |x| >= 65520 into an fp16 pair (split_dev.h sp_commit)
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(rh0), "+v"(rl0), "+v"(rh1), "+v"(rl1)::"memory");
     __syncthreads();  // weights of group 0 and the bias table are in LDS (this one drains everything, once)
 
@@ -967,7 +981,7 @@ __global__ void __launch_bounds__(512, 2) bneck_tail2_kernel(const BneckParams p
                             relu_nan(__builtin_fmaf(acc3[1][0], s3, b1[0]) + r[4]), relu_nan(__builtin_fmaf(acc3[1][1], s3, b1[1]) + r[5]), \
                             relu_nan(__builtin_fmaf(acc3[1][2], s3, b1[2]) + r[6]), relu_nan(__builtin_fmaf(acc3[1][3], s3, b1[3]) + r[7])}; \
         spx8_t oh, ol;                                                                                                       \
-        split8v(v, oh, ol);                                                                                                    \
+        split8v(v, oh, ol, ovm);                                                                                                    \
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, oh), outrs, o_row, (G) * 128, 0);                   \
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ol), outrs, o_row, (G) * 128 + 64, 0);              \
         asm volatile("" ::: "memory");                                                                                         \
@@ -1002,13 +1016,14 @@ __global__ void __launch_bounds__(512, 2) bneck_tail2_kernel(const BneckParams p
                             relu_nan(__builtin_fmaf(hi4[0], s1n, b1.x)), relu_nan(__builtin_fmaf(hi4[1], s1n, b1.y)),
                             relu_nan(__builtin_fmaf(hi4[2], s1n, b1.z)), relu_nan(__builtin_fmaf(hi4[3], s1n, b1.w))};
         spx8_t hi, lo;
-        split8v(v, hi, lo);
+        split8v(v, hi, lo, ovm);
         if (m_ok) {
             char* yp = p.T1N + m * (P * 4L) + q * 128 + 16 * g;
             *reinterpret_cast<spx8_t*>(yp) = hi;
             *reinterpret_cast<spx8_t*>(yp + 64) = lo;
         }
     }
+    sp_commit(p.ovf, ovm);
 }
 
 // ------------------------------------------------------------------------------------------------ on-box ceilings
@@ -1053,9 +1068,9 @@ int launch_stem_pool(avcer_ctx* ctx, const void* planes, size_t plane_bytes, con
     StemParams p;
     memset(&p, 0, sizeof(p));
     p.P = (const char*)planes; p.plane_bytes = (unsigned)plane_bytes; p.p_bytes = (unsigned)(2 * plane_bytes);
-    p.W = (const char*)w_x3; p.scale = scale; p.bias = bias; p.Y = (char*)y; p.n = n;
+    p.W = (const char*)w_x3; p.scale = scale; p.bias = bias; p.Y = (char*)y; p.n = n; p.ovf = ctx->ovf;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    TRY(prof_begin(ctx, st, &ev0, &ev1));
+    TRY(prof_begin(ctx, st, &ev0, &ev1, FAM_STEM, 2.0 * n * 112.0 * 112.0 * 64 * 147, (double)n * (2.0 * 230 * 230 * 4 * 2 + 55.0 * 55 * 64 * 4)));
     stem_pool_kernel<<<dim3(n * ST_TY * ST_TX), dim3(256), 0, st>>>(p);
     if (ev1) (void)hipEventRecord(ev1, st);
     hipError_t e = hipGetLastError();
@@ -1073,9 +1088,9 @@ int launch_stem_pool_u8(avcer_ctx* ctx, const uint8_t* frames, int in_h, int in_
     StemParams p;
     memset(&p, 0, sizeof(p));
     p.F = frames; p.in_h = in_h; p.in_w = in_w; p.bias9 = bias9;
-    p.W = (const char*)w_x3; p.scale = scale; p.Y = (char*)y; p.n = n;
+    p.W = (const char*)w_x3; p.scale = scale; p.Y = (char*)y; p.n = n; p.ovf = ctx->ovf;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    TRY(prof_begin(ctx, st, &ev0, &ev1));
+    TRY(prof_begin(ctx, st, &ev0, &ev1, FAM_STEM, 2.0 * n * 112.0 * 112.0 * 64 * 147, (double)n * ((double)in_h * in_w * 3 + 55.0 * 55 * 64 * 4)));
     stem_pool_u8_kernel<<<dim3(n * ST_TY * ST_TX), dim3(256), 0, st>>>(p);
     if (ev1) (void)hipEventRecord(ev1, st);
     hipError_t e = hipGetLastError();
@@ -1105,11 +1120,16 @@ int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t
     p.W2 = (const char*)w2; p.W3 = (const char*)w3; p.W1N = (const char*)w1n;
     p.b2 = b2; p.b3 = b3; p.b1n = b1n;
     p.t1_bytes = (unsigned)(M_in * planes * 4);
-    p.M = (int)M; p.H = h; p.Wd = w; p.OH = oh; p.OW = ow;
+    p.M = (int)M; p.H = h; p.Wd = w; p.OH = oh; p.OW = ow; p.ovf = ctx->ovf;
     constexpr int BM = 128;
     const int grid = (int)((M + BM - 1) / BM);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    TRY(prof_begin(ctx, st, &ev0, &ev1));
+    {
+        // per position: T1 in (P), residual or downsample operand in (4P | ds_cin), OUT (4P) and T1' (P) out, 4 bytes per element
+        const double bytes = 4.0 * ((double)M_in * planes + (double)M * (ds_cin ? ds_cin : 4 * planes) + (double)M * 4 * planes +
+                                    (t1n ? (double)M * planes : 0.0));
+        TRY(prof_begin(ctx, st, &ev0, &ev1, FAM_CHAIN, 2.0 * (double)M * planes * (planes * (9.0 + 4.0 + (t1n ? 4.0 : 0.0)) + 4.0 * ds_cin), bytes));
+    }
     // Resident halo patch for the conv2 phase: planes 128 only (28x28: -5..7 % per launch).  At planes 64 (55x55) the patch
     // costs the third resident block (76 KiB of LDS) and measured +2..4 %, so that form keeps the per-tap gather.
     // Worst case of the patch: the image rows 128 consecutive positions can touch (+ 2 when they cross into the next
@@ -1152,9 +1172,10 @@ int launch_bneck_tail(avcer_ctx* ctx, int planes, long M, const void* t2, const 
     memset(&p, 0, sizeof(p));
     p.T1 = (const char*)t2; p.X = (const char*)x; p.OUT = (char*)out; p.T1N = (char*)t1n;
     p.W3 = (const char*)w3; p.W1N = (const char*)w1n; p.b3 = b3; p.b1n = b1n;
-    p.M = (int)M;
+    p.M = (int)M; p.ovf = ctx->ovf;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    TRY(prof_begin(ctx, st, &ev0, &ev1));
+    // per position: T2 in (P), residual in (4P), OUT (4P) and T1' (P) out
+    TRY(prof_begin(ctx, st, &ev0, &ev1, FAM_TAIL, 2.0 * (double)M * planes * planes * 8.0, 4.0 * (double)M * planes * 10.0));
     p.t1_bytes = (unsigned)(M * 4096L);
     bneck_tail2_kernel<256><<<dim3((int)((M + 127) / 128)), dim3(512), 0, st>>>(p);
     if (ev1) (void)hipEventRecord(ev1, st);

@@ -70,6 +70,7 @@ struct GemmParams {
     int tapH4, tapW4;  // byte steps of one filter tap down / right: dil_h * x_stride_h * 4, dil_w * x_stride_w * 4
     int slots;         // host side only: block slots of the device (2 per CU), for the tile choices of the launchers
     int rsub, rH, rW;  // residual sub-sampling (avcer_conv_desc.r_sub): output (b, oy, ox) adds residual row (b, oy*rsub, ox*rsub)
+    unsigned* ovf;     // the context's range-contract counter (split_dev.h sp_commit)
 };
 
 // Epilogue, staged through LDS so that HBM sees whole 128-byte lines: every wave first parks its scaled/biased
@@ -107,7 +108,7 @@ __device__ __forceinline__ void res_load(const GemmParams& p, long m, int n0, ui
 
 template <int OUT, int ACT>
 __device__ __forceinline__ void finish8(const GemmParams& p, long m, int n0, const float4 a, const float4 b, const uint4 r0,
-                                        const uint4 r1) {
+                                        const uint4 r1, sp_flags_t& ovm) {
     float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     float r[8];
     if constexpr (OUT == 0) {
@@ -151,12 +152,15 @@ __device__ __forceinline__ void finish8(const GemmParams& p, long m, int n0, con
         uint32_t h[4], l[4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = sp_value(v[j]);  // one f32 number for both halves of the pair (split_dev.h)
+        float amax = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            amax = sp_max2(amax, v[2 * j], v[2 * j + 1]);
             const uint16_t h0 = f2sp(v[2 * j]), h1 = f2sp(v[2 * j + 1]);
             h[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
             l[j] = (uint32_t)f2sp(v[2 * j] - sp2f(h0)) | ((uint32_t)f2sp(v[2 * j + 1] - sp2f(h1)) << 16);
         }
+        sp_flag(ovm, amax);  // range contract: |x| < 65504 (split_dev.h sp_commit)
         char* yp = p.Y + sp32_byte(e);
         *reinterpret_cast<uint4*>(yp) = make_uint4(h[0], h[1], h[2], h[3]);
         *reinterpret_cast<uint4*>(yp + 64) = make_uint4(l[0], l[1], l[2], l[3]);
@@ -239,7 +243,8 @@ __device__ __forceinline__ void drain_stage(const GemmParams& p, const char* sme
         if (m < p.M) {
             const float4 a = *reinterpret_cast<const float4*>(smem + stage_off<BN>(row, 2 * c8));
             const float4 b = *reinterpret_cast<const float4*>(smem + stage_off<BN>(row, 2 * c8 + 1));
-            finish8<OUT, ACT>(p, m, n_base + c8 * 8, a, b, rr[pass][0], rr[pass][1]);
+            sp_flags_t unused = 0;  // the staged epilogue never writes sp32 (OUT == 2 belongs to the split-fp16 modes)
+            finish8<OUT, ACT>(p, m, n_base + c8 * 8, a, b, rr[pass][0], rr[pass][1], unused);
         }
     }
 }
@@ -269,7 +274,7 @@ __device__ __forceinline__ float4 scale_bias4(const f32x4_t a, const float4 s, c
 
 template <int OUT, int ACT, int NFN, int NFM>
 __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4_t (&acc)[NFN][NFM], int m0, int c0, int lane,
-                                                const uint4 (&rr)[NFN / 2][NFM][2], const float wmul) {
+                                                const uint4 (&rr)[NFN / 2][NFM][2], const float wmul, sp_flags_t& ovm) {
 #pragma unroll
     for (int j = 0; j < NFN / 2; ++j) {
         const int ch = c0 + 32 * j + 8 * (lane >> 4);  // first of this lane's 8 channels (index into scale / bias too)
@@ -285,19 +290,24 @@ __device__ __forceinline__ void epilogue_direct(const GemmParams& p, f32x4_t (&a
             if (m >= p.M) continue;
             const f32x4_t lo = acc[2 * j][fm], hi = acc[2 * j + 1][fm];
             // explicit fma: the two forms of the kernel (this one and conv_gemm_wd_kernel) must round alike whatever hipcc contracts
-            finish8<OUT, ACT>(p, m, ch, scale_bias4(lo, s0, b0), scale_bias4(hi, s1, b1), rr[j][fm][0], rr[j][fm][1]);
+            finish8<OUT, ACT>(p, m, ch, scale_bias4(lo, s0, b0), scale_bias4(hi, s1, b1), rr[j][fm][0], rr[j][fm][1], ovm);
         }
     }
 }
 
 // f32 -> split pair used by MODE 2: x = hi + lo + O(2^-22 |x|) with hi, lo fp16 (round to nearest even; split_dev.h)
-__device__ __forceinline__ void split8(const float4 x, const float4 y, spx8_t& hi, spx8_t& lo) {
+__device__ __forceinline__ void split8(const float4 x, const float4 y, spx8_t& hi, spx8_t& lo, sp_flags_t& ovm) {
     const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) amax = sp_max2(amax, v[j], v[j + 1]);
+    sp_flag(ovm, amax);  // range contract: |x| < 65504 (split_dev.h sp_commit)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const spe_t h = (spe_t)v[j];
+        const float w = sp_value(v[j]);  // one f32 number for both halves (split_dev.h)
+        const spe_t h = (spe_t)w;
         hi[j] = h;
-        lo[j] = (spe_t)(v[j] - (float)h);
+        lo[j] = (spe_t)(w - (float)h);
     }
 }
 
@@ -309,7 +319,7 @@ __device__ __forceinline__ void split8(const float4 x, const float4 y, spx8_t& h
 // A fragments are read like the weights and the main loop has no conversion arithmetic at all.
 template <int MODE, int BMT, int BN, int TILE_BYTES, typename AccT, int NFN, int NFM>
 __device__ __forceinline__ void mfma_step(const GemmParams& p, const char* smem, int cur, AccT (&acc)[NFN][NFM], int wm, int wn,
-                                      int lane) {
+                                      int lane, sp_flags_t& ovm) {
     constexpr bool IS_F32 = MODE == 0;
     constexpr int WN = BN / 2;
     constexpr int WM = BMT / 2;
@@ -349,7 +359,7 @@ __device__ __forceinline__ void mfma_step(const GemmParams& p, const char* smem,
             }
             const float4 x = *reinterpret_cast<const float4*>(sa + swz(row, 2 * g));
             const float4 y = *reinterpret_cast<const float4*>(sa + swz(row, 2 * g + 1));
-            split8(x, y, ahi[fm], alo[fm]);
+            split8(x, y, ahi[fm], alo[fm], ovm);
         }
 #pragma unroll
         for (int fn = 0; fn < NFN; ++fn) {
@@ -560,12 +570,13 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int b = 0; b < NFM; ++b) acc[a][b] = acc_t{0};
 
+    sp_flags_t ovm = 0;  // lanes that split a finite |x| >= 65520 into an fp16 pair (split_dev.h sp_commit)
     AVCER_DMA_SETUP();
     AVCER_ISSUE_TILES(0);
     __syncthreads();  // hipcc puts the s_waitcnt vmcnt(0) of the in-flight DMA in front of the barrier
     for (int step = 0; step < nk; ++step) {
         if (step + 1 < nk) AVCER_ISSUE_TILES(cur ^ 1);
-        mfma_step<MODE, BMT, BN, TILE_BYTES>(p, smem, cur, acc, wm, wn, lane);
+        mfma_step<MODE, BMT, BN, TILE_BYTES>(p, smem, cur, acc, wm, wn, lane, ovm);
         // Keep every MFMA of this K-step in front of the barrier.  Left alone, hipcc hoists the s_waitcnt vmcnt(0) +
         // s_barrier above the second half of them, so the DMA issued at the top of the step gets half a step to land.
 #pragma unroll
@@ -579,10 +590,11 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
 #undef AVCER_DMA_SETUP
 
     if constexpr (DIRECT) {
-        if (p.act == 3) epilogue_direct<OUT, 3, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir, wmul);
-        else if (p.act == 2) epilogue_direct<OUT, 2, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir, wmul);
-        else if (p.act == 1) epilogue_direct<OUT, 1, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir, wmul);
-        else epilogue_direct<OUT, 0, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir, wmul);
+        if (p.act == 3) epilogue_direct<OUT, 3, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir, wmul, ovm);
+        else if (p.act == 2) epilogue_direct<OUT, 2, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir, wmul, ovm);
+        else if (p.act == 1) epilogue_direct<OUT, 1, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir, wmul, ovm);
+        else epilogue_direct<OUT, 0, NFN, NFM>(p, acc, m_base + wm * WM, n_base + wn * WN, lane, rdir, wmul, ovm);
+        sp_commit(p.ovf, ovm);
     } else {
         // epilogue through LDS (the tile buffers are free: the loop ended on a barrier)
         stage_acc<MODE, BN>(p, smem, acc, n_base, wm * WM, wn, lane);
@@ -620,6 +632,7 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_kernel(const GemmParams p) {
 
 template <int OUT, int ACT, int NFN, int NFM>
 __device__ __forceinline__ void wd_epilogue(const GemmParams& p, f32x4_t (&acc)[NFN][NFM], int m_base, int c0, int lane, const float wmul) {
+    sp_flags_t ovm = 0;  // range contract of the sp32 output (split_dev.h sp_commit)
     // straight from the accumulators (weight rows are permuted: lane group g holds channels 8g..8g+7 of every group of 32);
     // the residual is read here, four positions at a time, into the registers the weight fragments left free
 #pragma unroll
@@ -646,10 +659,11 @@ __device__ __forceinline__ void wd_epilogue(const GemmParams& p, f32x4_t (&acc)[
                 const long m = (long)m_base + (h + f) * 16 + (lane & 15);
                 if (h + f >= NFM || m >= p.M) continue;
                 finish8<OUT, ACT>(p, m, ch, scale_bias4(acc[2 * j][h + f], s0, b0), scale_bias4(acc[2 * j + 1][h + f], s1, b1), rr[f][0],
-                                  rr[f][1]);
+                                  rr[f][1], ovm);
             }
         }
     }
+    if constexpr (OUT == 2) sp_commit(p.ovf, ovm);
 }
 
 template <int OUT, int GATHER, int NFM>
@@ -950,8 +964,11 @@ void launch_t(const GemmParams& p0, hipStream_t st) {
 
 // Live timing of the MFMA kernels (avcer_profile_enable): a pair of events around each launch, on the launch stream.
 // Records *ev0 now; the caller records *ev1 behind its launch.  Both stay null while profiling is off.
-int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1) {
+int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1, int family, double flops, double bytes) {
     *ev0 = *ev1 = nullptr;
+    ctx->fam_launches[family] += 1;
+    ctx->fam_flops[family] += flops;
+    ctx->fam_bytes[family] += bytes;
     if (!ctx->prof) return AVCER_OK;
     if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
         for (int i = 0; i < 512; ++i) {
@@ -960,6 +977,8 @@ int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1)
             ctx->prof_ev.push_back(e);
         }
     }
+    if (ctx->prof_fam.size() < ctx->prof_ev.size() / 2) ctx->prof_fam.resize(ctx->prof_ev.size() / 2, 0);
+    ctx->prof_fam[ctx->prof_used / 2] = family;
     *ev0 = ctx->prof_ev[ctx->prof_used++];
     *ev1 = ctx->prof_ev[ctx->prof_used++];
     (void)hipEventRecord(*ev0, st);
@@ -1033,7 +1052,7 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
         p.x2_bytes = (unsigned)x2_extent; p.K1 = (int)K1;
         p.sB2 = d.x2_stride_b; p.sH2 = d.x2_stride_h; p.sW2 = d.x2_stride_w; p.coff2 = d.x2_coff; p.st2 = d.x2_stride;
     }
-    p.ntn = 0; p.nwg = 0; p.groups = groups; p.slots = ctx->block_slots;
+    p.ntn = 0; p.nwg = 0; p.groups = groups; p.slots = ctx->block_slots; p.ovf = ctx->ovf;
     if (d.tile_n != 0 && d.tile_n != 64 && d.tile_n != 128 && d.tile_n != 256)
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: tile_n %d (0, 64, 128 or 256)", d.tile_n);
     p.tile_n = d.tile_n;
@@ -1053,7 +1072,12 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
              (long)(d.out_w - 1) * d.stride_w + (long)(d.kw - 1) * d.dil_w < d.in_w;
     if (wdirect && x2 && !p.fast) return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d with a second source needs a pad-free gather", dtype);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    TRY(prof_begin(ctx, st, &ev0, &ev1));
+    {
+        // compulsory traffic: the input once (each position's taps overlap), the weights once, the output (+ residual) once
+        const double in_el = (double)d.batch * d.in_h * d.in_w * d.cin * groups + (x2 ? (double)M * d.x2_cin : 0.0);
+        const double bytes = in_el * es + (double)w_extent + (double)M * d.n * groups * (dtype == 1 ? 2 : 4) * (residual ? 2 : 1);
+        TRY(prof_begin(ctx, st, &ev0, &ev1, wdirect ? FAM_GEMM_WD : FAM_GEMM, 2.0 * (double)M * (double)d.n * (double)K * groups, bytes));
+    }
     switch (dtype) {
         case 0: launch_t<0, 0>(p, st); break;  // f32
         case 1: launch_t<1, 1>(p, st); break;  // bf16 -> bf16

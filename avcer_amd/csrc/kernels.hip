@@ -41,9 +41,10 @@ __device__ __forceinline__ float wave_max(float v) {
 template <typename T> __device__ __forceinline__ float ldf(const T* p, long i);
 template <> __device__ __forceinline__ float ldf<float>(const float* p, long i) { return p[i]; }
 template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p, long i) { return bf2f(p[i]); }
-template <typename T> __device__ __forceinline__ void stf(T* p, long i, float v);
-template <> __device__ __forceinline__ void stf<float>(float* p, long i, float v) { p[i] = v; }
-template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, long i, float v) { p[i] = f2bf(v); }
+// `ovf`: the context's range-contract counter (split_dev.h sp_commit); only the sp32 forms look at it
+template <typename T> __device__ __forceinline__ void stf(T* p, long i, float v, unsigned* ovf = nullptr);
+template <> __device__ __forceinline__ void stf<float>(float* p, long i, float v, unsigned*) { p[i] = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, long i, float v, unsigned*) { p[i] = f2bf(v); }
 
 // load / store 4 consecutive elements
 template <typename T> __device__ __forceinline__ void ld4(const T* p, long i, float* v);
@@ -56,11 +57,11 @@ template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, long i,
     v[0] = bf2f((bf16_t)(t.x & 0xffff)); v[1] = bf2f((bf16_t)(t.x >> 16));
     v[2] = bf2f((bf16_t)(t.y & 0xffff)); v[3] = bf2f((bf16_t)(t.y >> 16));
 }
-template <typename T> __device__ __forceinline__ void st4(T* p, long i, const float* v);
-template <> __device__ __forceinline__ void st4<float>(float* p, long i, const float* v) {
+template <typename T> __device__ __forceinline__ void st4(T* p, long i, const float* v, unsigned* ovf = nullptr);
+template <> __device__ __forceinline__ void st4<float>(float* p, long i, const float* v, unsigned*) {
     *reinterpret_cast<float4*>(p + i) = make_float4(v[0], v[1], v[2], v[3]);
 }
-template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, long i, const float* v) {
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, long i, const float* v, unsigned*) {
     uint2 t;
     t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
     t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
@@ -75,9 +76,10 @@ template <> __device__ __forceinline__ float ldf<sp32_t>(const sp32_t* p, long i
     const char* b = reinterpret_cast<const char*>(p) + sp32_byte(i);
     return sp2f(*reinterpret_cast<const uint16_t*>(b)) + sp2f(*reinterpret_cast<const uint16_t*>(b + 64));
 }
-template <> __device__ __forceinline__ void stf<sp32_t>(sp32_t* p, long i, float v) {
+template <> __device__ __forceinline__ void stf<sp32_t>(sp32_t* p, long i, float v, unsigned* ovf) {
     char* b = reinterpret_cast<char*>(p) + sp32_byte(i);
     v = sp_value(v);  // one f32 number for both halves (split_dev.h)
+    sp_count_now(ovf, __builtin_fabsf(v));  // range contract: a finite |v| >= 65520 is counted (these kernels are HBM-bound)
     const uint16_t h = f2sp(v);
     *reinterpret_cast<uint16_t*>(b) = h;
     *reinterpret_cast<uint16_t*>(b + 64) = f2sp(v - sp2f(h));
@@ -91,13 +93,18 @@ template <> __device__ __forceinline__ void ld4<sp32_t>(const sp32_t* p, long i,
     v[2] = sp2f((uint16_t)(h.y & 0xffff)) + sp2f((uint16_t)(l.y & 0xffff));
     v[3] = sp2f((uint16_t)(h.y >> 16)) + sp2f((uint16_t)(l.y >> 16));
 }
-template <> __device__ __forceinline__ void st4<sp32_t>(sp32_t* p, long i, const float* vin) {
+template <> __device__ __forceinline__ void st4<sp32_t>(sp32_t* p, long i, const float* vin, unsigned* ovf) {
     char* b = reinterpret_cast<char*>(p) + sp32_byte(i);
     uint16_t h[4];
     uint2 hh, ll;
     float v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = sp_value(vin[j]);  // one f32 number for both halves (split_dev.h)
+    {
+        float amax = 0.f;  // range contract (split_dev.h sp_commit): these kernels are HBM-bound, the test rides along
+        amax = sp_max2(sp_max2(amax, v[0], v[1]), v[2], v[3]);
+        sp_count_now(ovf, amax);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) h[j] = f2sp(v[j]);
     hh.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
@@ -138,11 +145,16 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ in, T* __restrict_
 
 // Planar split-fp16 variant (input of stem_pool_kernel): the same zero-bordered image as two fp16 planes
 // [n,230,230,4], hi = bf16(v) and lo = bf16(v - hi), so that one 8-pixel tap row is 64 contiguous bytes per plane.
-__device__ __forceinline__ void st4_planar(bf16_t* hi, bf16_t* lo, long idx, const float* vin) {
+__device__ __forceinline__ void st4_planar(bf16_t* hi, bf16_t* lo, long idx, const float* vin, unsigned* ovf = nullptr) {
     uint16_t h[4];
     float v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = sp_value(vin[j]);  // one f32 number for both halves (split_dev.h)
+    {
+        float amax = 0.f;  // range contract (split_dev.h sp_commit)
+        amax = sp_max2(sp_max2(amax, v[0], v[1]), v[2], v[3]);
+        sp_count_now(ovf, amax);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) h[j] = f2sp(v[j]);
     uint2 hh, ll;
@@ -177,7 +189,8 @@ __global__ void preprocess_planar_kernel(const uint8_t* __restrict__ in, bf16_t*
     st4_planar(hi, lo, idx, v);
 }
 
-__global__ void pack_nchw_planar_kernel(const float* __restrict__ in, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int n) {
+__global__ void pack_nchw_planar_kernel(const float* __restrict__ in, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int n,
+                                        unsigned* ovf) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)n * PP * PP;
     if (idx >= total) return;
@@ -189,7 +202,7 @@ __global__ void pack_nchw_planar_kernel(const float* __restrict__ in, bf16_t* __
         const long o = (long)b * 3 * 224 * 224 + (long)(y - 2) * 224 + (x - 2);
         v[0] = in[o]; v[1] = in[o + 224 * 224]; v[2] = in[o + 2 * 224 * 224];
     }
-    st4_planar(hi, lo, idx, v);
+    st4_planar(hi, lo, idx, v, ovf);  // arbitrary floats: the one input that can break the fp16 range by itself
 }
 
 // Same zero-bordered image from an ALREADY preprocessed float tensor [n,3,224,224] (the tensor the reference's
@@ -427,7 +440,8 @@ __global__ void maxpool3s2p1_kernel(const T* __restrict__ x, T* __restrict__ y, 
 
 // retina_face_net.py:92-98: y += nearest-upsampled coarser level (F.interpolate(mode="nearest"): src = floor(dst*in/out))
 template <typename T>
-__global__ void upsample_add_kernel(T* __restrict__ y, const T* __restrict__ coarse, int n, int h, int w, int ch, int cw, int c) {
+__global__ void upsample_add_kernel(T* __restrict__ y, const T* __restrict__ coarse, int n, int h, int w, int ch, int cw, int c,
+                                    unsigned* ovf) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c4 = c / 4;
     const long total = (long)n * h * w * c4;
@@ -445,7 +459,7 @@ __global__ void upsample_add_kernel(T* __restrict__ y, const T* __restrict__ coa
     ld4<T>(coarse, (((long)b * ch + sy) * cw + sx) * c + cc, u);
 #pragma unroll
     for (int j = 0; j < 4; ++j) a[j] += u[j];
-    st4<T>(y, o, a);
+    st4<T>(y, o, a, ovf);
 }
 
 // retina_face.py:9-43,104-113: per position the fused head GEMM produced 32 values = class [2 anchors x 2], bbox
@@ -657,7 +671,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) conv0_ln_gelu_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ b, const float* __restrict__ g,
                                                          const float* __restrict__ beta, T* __restrict__ y, int t_in,
-                                                         int t_out, int steps_per_block) {
+                                                         int t_out, int steps_per_block, unsigned* ovf) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c0 = lane * 8;
     float wr[8][10], br[8], gr[8], ber[8];
@@ -697,8 +711,8 @@ __global__ void __launch_bounds__(256) conv0_ln_gelu_kernel(const float* __restr
             else v[j] = gelu_fast(u);
         }
         const long o = ((long)row * t_out + t) * 512 + c0;
-        st4<T>(y, o, v);
-        st4<T>(y, o + 4, v + 4);
+        st4<T>(y, o, v, ovf);
+        st4<T>(y, o + 4, v + 4, ovf);
     }
 }
 
@@ -708,7 +722,7 @@ template <typename TI, typename OB, int C>
 __global__ void __launch_bounds__(256) layernorm_kernel(const TI* __restrict__ x, const TI* __restrict__ res,
                                                       const float* __restrict__ g, const float* __restrict__ b,
                                                       float* __restrict__ yf, OB* __restrict__ yb, long rows,
-                                                      float eps, int act) {
+                                                      float eps, int act, unsigned* ovf) {
     constexpr int PER = C / 64;  // 8 or 16 consecutive elements per lane
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -751,14 +765,14 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const TI* __restrict__ x
 #pragma unroll
     for (int i = 0; i < PER; i += 4) {
         if (yf) st4<float>(yf, base + i, v + i);
-        if (yb) st4<OB>(yb, base + i, v + i);
+        if (yb) st4<OB>(yb, base + i, v + i, ovf);
     }
 }
 
 // attention_layers.py:206-211,249-254: x + pe[:, :S]; writes f32 (residual) and/or bf16 (GEMM operand).
 template <typename OB>
 __global__ void add_pe_kernel(const float* __restrict__ x, const float* __restrict__ pe, float* __restrict__ yf,
-                              OB* __restrict__ yb, long total4, int s, int c) {
+                              OB* __restrict__ yb, long total4, int s, int c, unsigned* ovf) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total4) return;
     const long e = idx * 4;
@@ -770,7 +784,7 @@ __global__ void add_pe_kernel(const float* __restrict__ x, const float* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] += p[j];
     if (yf) st4<float>(yf, e, v);
-    if (yb) st4<OB>(yb, e, v);
+    if (yb) st4<OB>(yb, e, v, ovf);
 }
 
 // ------------------------------------------------------------------------------------------------ attention
@@ -886,7 +900,7 @@ __device__ __forceinline__ int att_swz(int row, int chunk) {
 constexpr int ATTM_WAVES = 8;  // one query tile per wave at 99 tokens (7 tiles): the four-wave form ran two rounds of 2 / 2 / 2 / 1
 template <typename T, typename TO, int NKT, int X3, int D>
 __global__ void __launch_bounds__(64 * ATTM_WAVES) attention_mfma_kernel(const T* __restrict__ qkv, TO* __restrict__ out, int s, int heads,
-                                                           float scale) {
+                                                           float scale, unsigned* ovf) {
     static_assert(D == 64 || D == 32, "head dimension 64 (wav2vec2 layers, tl2) or 32 (tl1)");
     using Op = AttOp<X3>;
     using frag_t = typename Op::frag_t;
@@ -932,6 +946,7 @@ __global__ void __launch_bounds__(64 * ATTM_WAVES) attention_mfma_kernel(const T
     // ---- stage K (row-major) and V (transposed + permuted) as 16-bit planes
     constexpr int ITEMS = SP * (D / 8), PASSES = ITEMS / NTHR, UB = PASSES < 4 ? PASSES : 4;
     static_assert(ITEMS % NTHR == 0 && PASSES % UB == 0 && NKT % ATTM_WAVES == 0, "whole staging passes, whole batches");
+    float amax = 0.f;  // largest finite magnitude this thread split into an fp16 pair
     for (int p0 = 0; p0 < PASSES; p0 += UB) {
     float kvb[UB][8], vvb[UB][8];
 #pragma unroll
@@ -952,8 +967,16 @@ __global__ void __launch_bounds__(64 * ATTM_WAVES) attention_mfma_kernel(const T
     for (int u = 0; u < UB; ++u) {
         const int it = (p0 + u) * NTHR + tid;
         const int r = it / (D / 8), c = it % (D / 8);   // key row, chunk of 8 head-dim elements (K rows keep a 128-byte pitch)
-        const float (&kv)[8] = kvb[u];
-        const float (&vv)[8] = vvb[u];
+        float kv[8], vv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {  // one f32 number for both halves of every pair (split_dev.h sp_value)
+            kv[j] = sp_value(kvb[u][j]);
+            vv[j] = sp_value(vvb[u][j]);
+        }
+        if (X3) {  // range contract of the fp16 pairs (split_dev.h sp_commit)
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) amax = sp_max2(sp_max2(amax, kv[j], kv[j + 1]), vv[j], vv[j + 1]);
+        }
         uint32_t hw[4], lw[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -988,6 +1011,7 @@ __global__ void __launch_bounds__(64 * ATTM_WAVES) attention_mfma_kernel(const T
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float x = sp_value(qv[j] * scale);
+                if (X3) amax = __builtin_fmaxf(amax, __builtin_fabsf(x));
                 const elem_t hh = (elem_t)x;
                 qh[ks][j] = hh;
                 ql[ks][j] = (elem_t)(x - (float)hh);
@@ -1064,10 +1088,11 @@ __global__ void __launch_bounds__(64 * ATTM_WAVES) attention_mfma_kernel(const T
 #pragma unroll
             for (int tv = 0; tv < TV; ++tv) {
                 float o4[4] = {oc[tv][0] * inv, oc[tv][1] * inv, oc[tv][2] * inv, oc[tv][3] * inv};
-                st4<TO>(out, ((long)b * s + qrow) * e + h * D + 16 * tv + 4 * g, o4);
+                st4<TO>(out, ((long)b * s + qrow) * e + h * D + 16 * tv + 4 * g, o4, ovf);
             }
         }
     }
+    if (X3) sp_count_now(ovf, amax);
 }
 
 // ------------------------------------------------------------------------------------------------ audio head
@@ -1103,10 +1128,11 @@ __global__ void mean_time_relu_kernel(const float* __restrict__ x, float* __rest
 // The sp32 split of an activation-shaped tensor (avcer_split_weights; also the LSTM's hidden state): per group of 32
 // elements, 32 hi then 32 lo values of the split type (x = hi + lo + O(2^-22 |x|), split_dev.h); same 4 bytes per element
 // as f32, so the DMA addressing is unchanged.  No scaling: activations are stored as they are.
-__global__ void split_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, size_t n) {
+__global__ void split_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, size_t n, unsigned* ovf) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = sp_value(w[i]);
+    sp_count_now(ovf, __builtin_fabsf(v));  // range contract of an unscaled split (split_dev.h)
     const uint16_t h = f2sp(v);
     const size_t g = i >> 5, j = i & 31;
     out[g * 64 + j] = h;
@@ -1360,9 +1386,9 @@ int k_conv0_ln_gelu(avcer_ctx* ctx, const float* x, const float* w, const float*
                     void* y, int n, int t_in, int t_out, int kind, hipStream_t st) {
     const int spb = 64;
     dim3 grid(cdiv(t_out, spb), n);
-    if (kind == 1) conv0_ln_gelu_kernel<bf16_t><<<grid, 256, 0, st>>>(x, w, b, g, beta, (bf16_t*)y, t_in, t_out, spb);
-    else if (kind == 2) conv0_ln_gelu_kernel<sp32_t><<<grid, 256, 0, st>>>(x, w, b, g, beta, (sp32_t*)y, t_in, t_out, spb);
-    else conv0_ln_gelu_kernel<float><<<grid, 256, 0, st>>>(x, w, b, g, beta, (float*)y, t_in, t_out, spb);
+    if (kind == 1) conv0_ln_gelu_kernel<bf16_t><<<grid, 256, 0, st>>>(x, w, b, g, beta, (bf16_t*)y, t_in, t_out, spb, nullptr);
+    else if (kind == 2) conv0_ln_gelu_kernel<sp32_t><<<grid, 256, 0, st>>>(x, w, b, g, beta, (sp32_t*)y, t_in, t_out, spb, ctx->ovf);
+    else conv0_ln_gelu_kernel<float><<<grid, 256, 0, st>>>(x, w, b, g, beta, (float*)y, t_in, t_out, spb, nullptr);
     CHECK_LAUNCH(ctx, "conv0_ln_gelu");
     return AVCER_OK;
 }
@@ -1373,9 +1399,9 @@ int ln_launch(avcer_ctx* ctx, const void* x, const void* res, const float* g, co
               int c, float eps, int act, hipStream_t st) {
     const int grid = cdiv(rows, 4);
     if (c == 512)
-        layernorm_kernel<TI, OB, 512><<<grid, 256, 0, st>>>((const TI*)x, (const TI*)res, g, b, (float*)yf, (OB*)yb, rows, eps, act);
+        layernorm_kernel<TI, OB, 512><<<grid, 256, 0, st>>>((const TI*)x, (const TI*)res, g, b, (float*)yf, (OB*)yb, rows, eps, act, ctx->ovf);
     else if (c == 1024)
-        layernorm_kernel<TI, OB, 1024><<<grid, 256, 0, st>>>((const TI*)x, (const TI*)res, g, b, (float*)yf, (OB*)yb, rows, eps, act);
+        layernorm_kernel<TI, OB, 1024><<<grid, 256, 0, st>>>((const TI*)x, (const TI*)res, g, b, (float*)yf, (OB*)yb, rows, eps, act, ctx->ovf);
     else
         return set_err(ctx, AVCER_EINVAL, "layernorm: c=%d unsupported", c);
     return AVCER_OK;
@@ -1403,8 +1429,8 @@ int k_layernorm(avcer_ctx* ctx, const void* x, const void* res, const float* g, 
 int k_add_pe(avcer_ctx* ctx, const float* x, const float* pe, float* yf, void* yb, int n, int s, int c, int yb_kind,
              hipStream_t st) {
     const long total4 = (long)n * s * c / 4;
-    if (yb_kind == 2) add_pe_kernel<sp32_t><<<cdiv(total4, 256), 256, 0, st>>>(x, pe, yf, (sp32_t*)yb, total4, s, c);
-    else add_pe_kernel<bf16_t><<<cdiv(total4, 256), 256, 0, st>>>(x, pe, yf, (bf16_t*)yb, total4, s, c);
+    if (yb_kind == 2) add_pe_kernel<sp32_t><<<cdiv(total4, 256), 256, 0, st>>>(x, pe, yf, (sp32_t*)yb, total4, s, c, ctx->ovf);
+    else add_pe_kernel<bf16_t><<<cdiv(total4, 256), 256, 0, st>>>(x, pe, yf, (bf16_t*)yb, total4, s, c, nullptr);
     CHECK_LAUNCH(ctx, "add_pe");
     return AVCER_OK;
 }
@@ -1430,7 +1456,7 @@ int k_attention(avcer_ctx* ctx, const void* qkv, void* out, int n, int s, int he
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));               \
             attr_dev |= 1ull << (ctx->device & 63);                                                                   \
         }                                                                                                             \
-        attention_mfma_kernel<T, TO, NKT, X3, D><<<grid, 64 * ATTM_WAVES, lds_m, st>>>((const T*)qkv, (TO*)out, s, heads, scale); \
+        attention_mfma_kernel<T, TO, NKT, X3, D><<<grid, 64 * ATTM_WAVES, lds_m, st>>>((const T*)qkv, (TO*)out, s, heads, scale, ctx->ovf); \
     } while (0)
 #define ATTM_D(T, TO, NKT, X3) do { if (d == 64) ATTM(T, TO, NKT, X3, 64); else ATTM(T, TO, NKT, X3, 32); } while (0)
         if (x3) { if (nkt == 8) ATTM_D(float, sp32_t, 8, 1); else ATTM_D(float, sp32_t, 16, 1); }
@@ -1562,9 +1588,9 @@ int k_upsample_add(avcer_ctx* ctx, void* y, const void* coarse, int n, int h, in
                    hipStream_t st) {
     const long total = (long)n * h * w * (c / 4);
     const int grid = cdiv(total, 256);
-    if (kind == 1) upsample_add_kernel<bf16_t><<<grid, 256, 0, st>>>((bf16_t*)y, (const bf16_t*)coarse, n, h, w, ch, cw, c);
-    else if (kind == 2) upsample_add_kernel<sp32_t><<<grid, 256, 0, st>>>((sp32_t*)y, (const sp32_t*)coarse, n, h, w, ch, cw, c);
-    else upsample_add_kernel<float><<<grid, 256, 0, st>>>((float*)y, (const float*)coarse, n, h, w, ch, cw, c);
+    if (kind == 1) upsample_add_kernel<bf16_t><<<grid, 256, 0, st>>>((bf16_t*)y, (const bf16_t*)coarse, n, h, w, ch, cw, c, nullptr);
+    else if (kind == 2) upsample_add_kernel<sp32_t><<<grid, 256, 0, st>>>((sp32_t*)y, (const sp32_t*)coarse, n, h, w, ch, cw, c, ctx->ovf);
+    else upsample_add_kernel<float><<<grid, 256, 0, st>>>((float*)y, (const float*)coarse, n, h, w, ch, cw, c, nullptr);
     CHECK_LAUNCH(ctx, "upsample_add");
     return AVCER_OK;
 }
@@ -1578,7 +1604,7 @@ int k_face_head(avcer_ctx* ctx, const float* hd, int ld, int n, int hw, int row0
 
 int k_pack_nchw(avcer_ctx* ctx, const float* x, int n, void* out, int kind, hipStream_t st) {
     const long total = (long)n * PP * PP;
-    if (kind == 3) pack_nchw_planar_kernel<<<cdiv(total, 256), 256, 0, st>>>(x, (bf16_t*)out, (bf16_t*)out + total * 4, n);
+    if (kind == 3) pack_nchw_planar_kernel<<<cdiv(total, 256), 256, 0, st>>>(x, (bf16_t*)out, (bf16_t*)out + total * 4, n, ctx->ovf);
     else if (kind == 1) pack_nchw_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>(x, (bf16_t*)out, n);
     else pack_nchw_kernel<float><<<cdiv(total, 256), 256, 0, st>>>(x, (float*)out, n);
     CHECK_LAUNCH(ctx, "pack_nchw");
@@ -1618,7 +1644,7 @@ int k_weight_frags(avcer_ctx* ctx, const bf16_t* rows, bf16_t* out, int n, int k
 }
 
 int k_split_weights(avcer_ctx* ctx, const float* w, bf16_t* out, size_t n, hipStream_t st) {
-    split_weights_kernel<<<cdiv((long)n, 256), 256, 0, st>>>(w, out, n);
+    split_weights_kernel<<<cdiv((long)n, 256), 256, 0, st>>>(w, out, n, ctx->ovf);
     CHECK_LAUNCH(ctx, "split_weights");
     return AVCER_OK;
 }

@@ -56,5 +56,41 @@ __device__ __forceinline__ sp_f32x4_t mfma_sp(const spx8_t a, const spx8_t b, co
 #endif
 }
 
+// ---- the range contract's run-time signal (round 5; include/avcer_hip.h avcer_x3_overflow_count)
+// An activation of magnitude >= 65520 rounds to +-inf in its fp16 hi half and reaches the output as NaN -- which is also what
+// the reference legitimately returns for an empty audio window, so NaN alone does not tell a caller that the contract broke.
+// Every site that splits an f32 ACTIVATION takes the maximum magnitude of the values it splits (one v_max3_f32 per two
+// values; NaN operands do not move it: the max instructions return the other operand), compares it with the threshold and
+// ORs the wave's ballot into a wave-uniform mask (scalar registers: a per-thread running maximum cost the fused kernels 20
+// vector registers and a resident block).  Once, at the end of the kernel, a wave whose mask is not empty adds its lane
+// count to the context's device counter.  Only FINITE values count (an infinite input was counted where it became
+// infinite), so a NaN audio window leaves the counter at 0.
+constexpr float AVCER_SP_OVERFLOW = 65520.f;  // smallest magnitude that rounds to +-inf in fp16 (round to nearest even)
+typedef unsigned long long sp_flags_t;
+__device__ __forceinline__ float sp_max2(float amax, float a, float b) {
+    return __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(a)), __builtin_fabsf(b));
+}
+__device__ __forceinline__ bool sp_out_of_range(float amax) { return amax >= AVCER_SP_OVERFLOW && amax < __builtin_inff(); }
+// amax = the largest magnitude of the values this lane has just split
+__device__ __forceinline__ void sp_flag(sp_flags_t& flags, float amax) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    flags |= __ballot(sp_out_of_range(amax));
+#endif
+}
+__device__ __forceinline__ void sp_commit(unsigned* ovf, sp_flags_t flags) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (ovf != nullptr && flags != 0) {  // wave-uniform; the lane id is recomputed here (mbcnt) instead of being kept alive
+        const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (lane == (unsigned)__builtin_ctzll(__ballot(1))) atomicAdd(ovf, (unsigned)__builtin_popcountll(flags));
+    }
+#endif
+}
+// the HBM-bound element-wise kernels test and count on the spot (a rare divergent branch, no state)
+__device__ __forceinline__ void sp_count_now(unsigned* ovf, float amax) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (ovf != nullptr && sp_out_of_range(amax)) atomicAdd(ovf, 1u);
+#endif
+}
+
 // the accumulator multiplier stored behind a split weight matrix of `bytes` bytes (see above)
 __device__ __forceinline__ float split_wmul(const char* w, size_t bytes) { return *reinterpret_cast<const float*>(w + bytes); }

@@ -41,6 +41,7 @@ class Engine:
             raise AvcerError(rc, "avcer_ctx_create failed")
         self.ctx = ctx
         self.audio_classes = 0
+        self.x3_fallbacks = 0  # calls `guarded` had to repeat in MODE_FP32 (the x3 range contract was broken)
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -68,6 +69,25 @@ class Engine:
 
     def _new(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    # ------------------------------------------------------------------ x3 range contract
+    def x3_overflow_count(self, reset: bool = True) -> int:
+        """How many GPU threads have turned a finite activation of magnitude >= 65520 into an infinite fp16 half since the
+        last reset (include/avcer_hip.h avcer_x3_overflow_count).  Waits for the current stream."""
+        n = C.c_int64(0)
+        self._check(self.lib.avcer_x3_overflow_count(self.ctx, int(reset), C.byref(n), self._stream()))
+        return int(n.value)
+
+    def guarded(self, mode: int, call):
+        """`call(mode)` with the x3 mode's range contract enforced: in MODE_F16X3 the device counter is read ONCE behind the
+        call and, when an activation left fp16's range, the same call is repeated in MODE_FP32 (no range limit; a fresh call on
+        the same context).  What comes back is then what the reference's fp32 path computes -- NaN only where the input was
+        NaN (the empty audio window).  Other modes pass through."""
+        out = call(mode)
+        if mode == MODE_F16X3 and self.x3_overflow_count(reset=True):
+            self.x3_fallbacks += 1
+            out = call(MODE_FP32)
+        return out
 
     # ------------------------------------------------------------------ weights
     def _load(self, fn, tensors):
@@ -163,16 +183,31 @@ class Engine:
 
     def audio_chunks(self, wav, starts, ends, window: int, padding: str = "mean"):
         wav = self._dev(wav, torch.float32)
-        starts = self._dev(starts, torch.int32)
-        ends = self._dev(ends, torch.int32)
-        n = int(starts.numel())
-        if wav.dim() != 1 or ends.numel() != n:
-            raise ValueError("audio_chunks: wav [L], starts/ends [n]")
-        if n and (int(starts.min()) < 0 or int(ends.max()) > wav.numel() or bool((ends < starts).any())
-                  or int((ends - starts).max()) > window):
-            raise ValueError("audio_chunks: sample ranges out of bounds")
-        if padding == "repeat" and n and int((ends - starts).min()) == 0:
-            raise ZeroDivisionError("integer division or modulo by zero")  # data/utils.py:66 on an empty chunk
+        # the ranges are validated on the HOST when they come from the host (chunk_spans builds them there): a device-side
+        # `int(starts.min())` is a synchronisation in front of every launch of the audio branch
+        if not (torch.is_tensor(starts) and starts.is_cuda) and not (torch.is_tensor(ends) and ends.is_cuda):
+            hs = np.asarray(starts.cpu() if torch.is_tensor(starts) else starts).reshape(-1).astype(np.int64)
+            he = np.asarray(ends.cpu() if torch.is_tensor(ends) else ends).reshape(-1).astype(np.int64)
+            n = int(hs.size)
+            if wav.dim() != 1 or he.size != n:
+                raise ValueError("audio_chunks: wav [L], starts/ends [n]")
+            if n and (hs.min() < 0 or he.max() > wav.numel() or (he < hs).any() or (he - hs).max() > window):
+                raise ValueError("audio_chunks: sample ranges out of bounds")
+            if padding == "repeat" and n and (he - hs).min() == 0:
+                raise ZeroDivisionError("integer division or modulo by zero")  # data/utils.py:66 on an empty chunk
+            starts = torch.from_numpy(hs.astype(np.int32)).to(self.device, non_blocking=True)
+            ends = torch.from_numpy(he.astype(np.int32)).to(self.device, non_blocking=True)
+        else:
+            starts = self._dev(starts, torch.int32)
+            ends = self._dev(ends, torch.int32)
+            n = int(starts.numel())
+            if wav.dim() != 1 or ends.numel() != n:
+                raise ValueError("audio_chunks: wav [L], starts/ends [n]")
+            if n and (int(starts.min()) < 0 or int(ends.max()) > wav.numel() or bool((ends < starts).any())
+                      or int((ends - starts).max()) > window):
+                raise ValueError("audio_chunks: sample ranges out of bounds")
+            if padding == "repeat" and n and int((ends - starts).min()) == 0:
+                raise ZeroDivisionError("integer division or modulo by zero")  # data/utils.py:66 on an empty chunk
         out = self._new(n, window)
         self._check(self.lib.avcer_audio_chunks(self.ctx, _ptr(wav), _ptr(starts), _ptr(ends), n, int(window),
                                                 PAD_MODES[padding], _ptr(out), self._stream()))
@@ -259,6 +294,17 @@ class Engine:
         ms, n = C.c_double(0.0), C.c_int64(0)
         self._check(self.lib.avcer_profile_read(self.ctx, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    FAMILIES = ("conv_gemm_kernel", "conv_gemm_wd_kernel", "bneck_kernel", "bneck_tail2_kernel", "stem_pool_kernel")  # AVCER_FAM_*
+
+    def profile_read_families(self):
+        """Per kernel family since profile_enable / the last read: {name: (event ms, launches, algorithmic FLOPs, compulsory
+        HBM bytes)}; synchronises.  Use instead of profile_read."""
+        n = len(self.FAMILIES)
+        ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+        la = (C.c_int64 * n)()
+        self._check(self.lib.avcer_profile_read_families(self.ctx, n, ms, la, fl, by))
+        return {name: (ms[i], int(la[i]), fl[i], by[i]) for i, name in enumerate(self.FAMILIES)}
 
     def debug_tap(self, name: str, numel: int, dtype=torch.float32):
         """Arm a one-shot tap; returns the destination tensor (filled by the next forward pass)."""

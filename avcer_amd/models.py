@@ -7,6 +7,10 @@
 
 They return torch tensors on the engine's device, so `.cpu().detach().numpy()` at the reference's call sites keeps
 working.  All arithmetic happens in libavcer_hip.so.
+
+Every call goes through `Engine.guarded`: in the default MODE_F16X3 the library's range-contract counter is read once behind
+the call (one 4-byte copy), and a call during which an activation left fp16's range (|x| >= 65504) is repeated in MODE_FP32 --
+the mirrors return numbers wherever the reference's fp32 modules do, NaN only where the input was NaN.
 """
 from __future__ import annotations
 
@@ -33,7 +37,7 @@ class StaticModel:
         return self
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        logits, probs, feats = self.engine.static_forward_nchw(x, self.mode)
+        logits, probs, feats = self.engine.guarded(self.mode, lambda m: self.engine.static_forward_nchw(x, m))
         self.activations["features"] = feats  # what the reference's fc1 forward hook stores
         self.activations["probs"] = probs
         return logits
@@ -41,11 +45,11 @@ class StaticModel:
     forward = __call__
 
     def extract_features(self, x: torch.Tensor) -> torch.Tensor:
-        return self.engine.static_forward_nchw(x, self.mode)[2]
+        return self.engine.guarded(self.mode, lambda m: self.engine.static_forward_nchw(x, m))[2]
 
     def predict_frames(self, frames_u8: torch.Tensor):
         """Fused pth_processing + forward + softmax on raw u8 RGB tiles [N,H,W,3] (data/utils.py:19-39)."""
-        return self.engine.static_forward(frames_u8, self.mode)
+        return self.engine.guarded(self.mode, lambda m: self.engine.static_forward(frames_u8, m))
 
 
 class DynamicModel:
@@ -66,7 +70,7 @@ class DynamicModel:
         return self
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        return self.engine.dynamic_forward(x, self.mode)
+        return self.engine.guarded(self.mode, lambda m: self.engine.dynamic_forward(x, m))
 
     forward = __call__
 
@@ -91,7 +95,7 @@ class AudioModel:
     def __call__(self, x: torch.Tensor, normalize: bool = False) -> torch.Tensor:
         if x.dim() == 1:
             x = x[None]
-        out = self.engine.audio_forward(x, normalize=normalize, mode=self.mode)
+        out = self.engine.guarded(self.mode, lambda m: self.engine.audio_forward(x, normalize=normalize, mode=m))
         return out.squeeze(0) if out.shape[0] == 1 else out  # `x.squeeze()` at audio_8_cl.py:188
 
     forward = __call__

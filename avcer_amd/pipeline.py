@@ -30,13 +30,18 @@ class AVPipeline:
 
     def clip_records(self, frames_u8: torch.Tensor, wav: torch.Tensor, fps: float = 25, present=None):
         """frames_u8 [N,T,224,224,3], wav [N,L] (one window per clip).  Returns the per-clip record that is
-        all-gathered across GPUs: (static_probs [N,T,7], dyn_logits [N,T,7], audio_logits [N,C])."""
+        all-gathered across GPUs: (static_probs [N,T,7], dyn_logits [N,T,7], audio_logits [N,C]).
+        In MODE_F16X3 the range-contract counter is read once behind the launches of both branches; a batch during which an
+        activation left fp16's range is repeated in MODE_FP32 (Engine.guarded)."""
         n, t = int(frames_u8.shape[0]), int(frames_u8.shape[1])
         if present is None:
             present = np.ones((n, t), dtype=bool)
+        return self.engine.guarded(self.mode, lambda m: self._clip_records(frames_u8, wav, fps, present, m))
+
+    def _clip_records(self, frames_u8, wav, fps, present, mode):
         if not getattr(self, "overlap_branches", False):
-            stat, dyn = visual_forward(self.engine, frames_u8, present, fps, self.mode)
-            aud = self.engine.audio_forward(wav, normalize=True, mode=self.mode)
+            stat, dyn = visual_forward(self.engine, frames_u8, present, fps, mode)
+            aud = self.engine.audio_forward(wav, normalize=True, mode=mode)
             return stat, dyn, aud
         dev = self.engine.device
         main = torch.cuda.current_stream(dev)
@@ -45,8 +50,8 @@ class AVPipeline:
         side = self._audio_stream
         side.wait_stream(main)  # the inputs were produced on the caller's stream
         with torch.cuda.stream(side):
-            aud = self.engine.audio_forward(wav, normalize=True, mode=self.mode)
-        stat, dyn = visual_forward(self.engine, frames_u8, present, fps, self.mode)
+            aud = self.engine.audio_forward(wav, normalize=True, mode=mode)
+        stat, dyn = visual_forward(self.engine, frames_u8, present, fps, mode)
         main.wait_stream(side)
         aud.record_stream(main)
         return stat, dyn, aud

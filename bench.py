@@ -56,8 +56,14 @@ GUIDE = "/opt/skills/guides/MI355X_MICROARCH.md"
 PEAK_FALLBACK = {"fp32": 157.3, "bf16": 2500.0, "x3": 2500.0}  # used only where the guide file is absent
 MFMA_PASSES = {"fp32": 1, "bf16": 1, "x3": 3}  # MFMA products issued per algorithmic product
 DTYPE = {"fp32": "f32", "bf16": "bf16", "x3": "f16x3 (f16 MFMA on hi/lo-split f32 operands, f32 accumulate)"}
-KERNEL = {"fp32": "conv_gemm_kernel<0,0,*>", "bf16": "conv_gemm_kernel<1,*,*>",
-          "x3": "conv_gemm_kernel<3,*,*> (sp32 activations; <2,*,*> where the input is still f32)"}
+# what roofline.achieved aggregates: every MFMA kernel family of the step (roofline.per_family prices each one on its own)
+KERNEL = {"fp32": "all MFMA launches of a step: conv_gemm_kernel<0,0,*>",
+          "bf16": "all MFMA launches of a step: conv_gemm_kernel<1,*,*>",
+          "x3": "all MFMA launches of a step, five families: conv_gemm_wd_kernel<*,*,*> (weights direct, about half of the time), "
+                "bneck_kernel<*> (fused bottleneck chains, HBM-bound), bneck_tail2_kernel<256>, conv_gemm_kernel<3|2,*,*>, "
+                "stem_pool_u8_kernel -- see roofline.per_family"}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.2-6.3 TB/s measured for a streaming copy)
+FAMILY_BOUND = {"bneck_kernel": "hbm"}  # every other family is priced against the MFMA peak
 
 
 def log(msg):
@@ -86,7 +92,8 @@ def usable_cores() -> int:
 def peaks():
     """Dense MFMA peaks (TFLOP/s) read from the MI355X guide's chip-level table, plus the figure the device properties
     imply (CUs x 4 SIMDs x 1024 bf16 FLOP/clk x max clock) for comparison.  Returns (per-mode dict, source string)."""
-    pk, src = dict(PEAK_FALLBACK), "built-in fallback (guide not found)"
+    pk, src = dict(PEAK_FALLBACK), ("MI355X_MICROARCH.md chip-level table, constants copied into bench.py (the guide file is not on "
+                                     "this box)")
     try:
         txt = open(GUIDE).read()
         bf = re.search(r"Peak BF16/FP16 MFMA\s*\|\s*\*\*~?([0-9.]+)\s*PF dense", txt)
@@ -196,7 +203,7 @@ def timed(pipe, frames, wav, n_total, steps, warmup, device, profile):
         t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    kern_ms, launches, serial_dt = 0.0, 0, None
+    kern_ms, launches, serial_dt, fams = 0.0, 0, None, None
     if profile:
         overlap = pipe.overlap_branches
         pipe.overlap_branches = False
@@ -209,10 +216,11 @@ def timed(pipe, frames, wav, n_total, steps, warmup, device, profile):
             one_step(pipe, frames, wav, n_total)
         torch.cuda.synchronize(device)
         serial_dt = time.perf_counter() - t0
-        kern_ms, launches = pipe.engine.profile_read()
+        fams = pipe.engine.profile_read_families()
+        kern_ms, launches = sum(v[0] for v in fams.values()), sum(v[1] for v in fams.values())
         pipe.engine.profile_enable(False)
         pipe.overlap_branches = overlap
-    return dt, kern_ms, launches, serial_dt, per_rank
+    return dt, kern_ms, launches, serial_dt, per_rank, fams
 
 
 def verify_ranks(pipe, frames, wav, n_total, clips, world, rank, device, check=8):
@@ -422,8 +430,24 @@ def run_inference_bench(pipe, modes, device, do_cpu, seconds=30, fps=25, h=360, 
     dets = scripted_detections(n, h, w)
     wav = torch.from_numpy(synth.waveforms(78, 1, seconds * 16000)[0]).to(device)
     eng = pipe.engine
-    out = {"video": f"{seconds} s at {fps} fps, {w}x{h} BGR frames + 16 kHz mono, one scripted face track (no detector pass)",
-           "frames": n, "windows": None, "modes": {}}
+    out = {"video": f"{seconds} s at {fps} fps, {w}x{h} BGR frames + 16 kHz mono, one scripted face track",
+           "frames": n, "windows": None, "modes": {},
+           "structure": "audio branch queued first on its own HIP stream, then tracker (host) -> crop -> visual branch on the main "
+                        "stream, fusion behind both, one range-contract read, every device-to-host copy after the last launch"}
+
+    class DetectorThenScript:
+        """Stage 0 in the measured path (get_face_images.py:38-63): the RetinaFace-R50 network over every frame, box decoding
+        and the device-side NMS run and their rows come back to the host -- and are then replaced by the scripted boxes,
+        because the SYNTHETIC detector weights find no faces (real Resnet50_Final.pth is not in the image)."""
+
+        def __init__(self, det):
+            self.det, self.found = det, None
+
+        def batch(self, fr, rgb=False):
+            self.found = sum(len(d) for d in self.det.batch(fr, rgb=rgb))
+            return dets
+
+    detector = None
     for name in ("x3", "fp32"):
         res = arun.run_inference(eng, frames, wav, fps, detections=dets, mode=modes[name])  # warm-up (workspace growth)
         torch.cuda.synchronize(device)
@@ -435,7 +459,26 @@ def run_inference_bench(pipe, modes, device, do_cpu, seconds=30, fps=25, h=360, 
             dts.append(time.perf_counter() - t0)
         dt = sorted(dts)[1]
         out["windows"] = int(len(chunk_spans(seconds * 16000, 16000, fps, 4, 0.5)[0]))
-        out["modes"][name] = {"s": dt, "frames_per_s": n / dt, "real_time_factor": dt / seconds, "dtype": DTYPE[name]}
+        out["modes"][name] = {"s": dt, "frames_per_s": n / dt, "real_time_factor": dt / seconds, "dtype": DTYPE[name],
+                              "x3_fallbacks_to_fp32": eng.x3_fallbacks}
+        if name == "x3":  # the same video with the detector pass in front (stage 0: 51.5 GFLOP per 640 x 360 frame, 7 x the CNN)
+            from avcer_amd.face_tiles import RetinaFacePredictor
+
+            if detector is None:
+                detector = DetectorThenScript(RetinaFacePredictor(eng, synth.to_torch(synth.retina_state_dict(42)), mode=modes[name]))
+            arun.run_inference(eng, frames, wav, fps, detector=detector, mode=modes[name])  # warm-up
+            torch.cuda.synchronize(device)
+            dts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                arun.run_inference(eng, frames, wav, fps, detector=detector, mode=modes[name])
+                torch.cuda.synchronize(device)
+                dts.append(time.perf_counter() - t0)
+            dtd = sorted(dts)[1]
+            out["with_detector"] = {"mode": name, "s": dtd, "frames_per_s": n / dtd, "real_time_factor": dtd / seconds,
+                                    "detector": "RetinaFace-R50 network + decode + device NMS over all frames (synthetic weights: "
+                                                f"{detector.found} boxes kept; the scripted track is used behind it)",
+                                    "detector_gflop_per_frame": 51.5}
     if do_cpu:
         from oracle import audio as oa
         from oracle import face as oface
@@ -566,8 +609,27 @@ def main():
     def measure(name, steps, warmup):
         set_mode(name)
         log(f"timing {name}: {warmup} warm-up + {steps} steps of {args.clips} clips/GPU")
-        dt, kern_ms, launches, serial_dt, per_rank = timed(pipe, frames, wav, n_total, steps, warmup, device,
-                                                             profile=not args.no_events)
+        dt, kern_ms, launches, serial_dt, per_rank, fams = timed(pipe, frames, wav, n_total, steps, warmup, device,
+                                                                   profile=not args.no_events)
+        per_family = None
+        if fams:
+            # each family against the roof that bounds it: the fused chains of ResNet stages 1-2 move 2.5-5 KB per position
+            # for 100-160 executed FLOP per byte (below the ridge): HBM; everything else: the MFMA peak of the mode
+            per_family = []
+            for fam, (ms, n_l, fl, by) in fams.items():
+                if not n_l:
+                    continue
+                bound = FAMILY_BOUND.get(fam, "mfma") if name == "x3" else "mfma"
+                tf = fl / (ms * 1e-3) / 1e12 if ms else None
+                gbs = by / (ms * 1e-3) / 1e9 if ms else None
+                ent = {"kernel": fam, "ms_per_step": ms / steps, "launches_per_step": n_l / steps, "bound": bound,
+                       "algorithmic_tflops": tf, "compulsory_gb_per_s": gbs}
+                if bound == "hbm":
+                    ent.update(achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS if gbs else None)
+                else:
+                    ent.update(achieved=tf, peak=pk[name], unit="TFLOP/s", frac=tf / pk[name] if tf else None,
+                               frac_executed=tf * MFMA_PASSES[name] / pk[name] if tf else None)
+                per_family.append(ent)
         flops_gemm = GFLOP_CLIP_GEMM * 1e9 * args.clips * steps  # algorithmic FLOPs this rank pushed through the MFMA kernels
         ach = flops_gemm / (kern_ms * 1e-3) / 1e12 if kern_ms else None
         traffic, traffic_src, stamp = pmc_traffic(name, args.clips)
@@ -590,6 +652,9 @@ def main():
                                "MFMA-kernel launch) run right after the timed region; the timed region itself carries no "
                                "events" + ("" if args.no_overlap else " and runs the audio branch on a second HIP stream"),
                 "serial_evented_ms_per_step": serial_dt / steps * 1e3 if serial_dt else None,
+                "per_family": per_family,
+                "per_family_note": "same evented pass; compulsory_gb_per_s = every operand read once + every output written once "
+                                   "(4 bytes per sp32 element) / event time; frac of a family = achieved / peak of ITS bound",
             },
         }
         log(f"{name}: {res['clips_per_s']:.1f} clips/s, {res['ms_per_step']:.1f} ms/step")

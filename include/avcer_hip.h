@@ -50,7 +50,11 @@ enum {
 };
 /* Range contract of AVCER_MODE_F16X3 (csrc/split_dev.h).  Activations are stored unscaled as fp16 pairs: every
  * intermediate activation must satisfy |x| < 65504.  A larger value becomes +-inf in its hi half and NaN in hi + lo, and the
- * NaN reaches the outputs: an overflow is never a wrong finite number (tests/test_gpu_edges.py).  Weights are multiplied
+ * NaN reaches the outputs: an overflow is never a wrong finite number (tests/test_gpu_edges.py).  Because NaN is also what
+ * the reference legitimately returns for an empty audio window (get_prob_audio_8_cl.py:78-92), the library COUNTS the event
+ * itself: avcer_x3_overflow_count below; the host mirrors read it once per call and repeat the call in AVCER_MODE_FP32
+ * (no range limit) when it is not zero.  Below 2^-3 the lo half is an fp16 subnormal: a small element carries an ABSOLUTE
+ * error of at most 2^-25 -- the usable window of the f32-grade RELATIVE bound is [2^-3, 65504).  Weights are multiplied
  * by one power of two per matrix before the split (largest |w| -> [2^14, 2^15)); the inverse, also a power of two, rides
  * behind the split data (AVCER_SPLIT_TRAILER) and every consumer folds it into its epilogue, so no result depends on it.
  * Error bounds of the two parity-grade modes against the reference's CPU path are in DESIGN.md section 6 and asserted by
@@ -60,13 +64,23 @@ enum {
 /* Bumped whenever a struct layout, an argument list or a buffer size of this header changes incompatibly; the Python binding
  * refuses a library whose avcer_abi_version() differs (avcer_amd/_lib.py).
  *   2: avcer_conv_desc grew r_sub / r_h / r_w / tile_m, avcer_bneck_chain gained out_step, avcer_set_option left (round 3);
- *      split weight buffers carry a trailer and AVCER_MODE_BF16X3 became AVCER_MODE_F16X3 (round 4). */
-#define AVCER_ABI_VERSION 2
+ *      split weight buffers carry a trailer and AVCER_MODE_BF16X3 became AVCER_MODE_F16X3 (round 4).
+ *   3: avcer_x3_overflow_count, avcer_profile_read_families (round 5). */
+#define AVCER_ABI_VERSION 3
 int avcer_abi_version(void);
 
 int avcer_ctx_create(int device, avcer_ctx** out);
 void avcer_ctx_destroy(avcer_ctx* ctx);
 const char* avcer_last_error(const avcer_ctx* ctx);
+
+/* Run-time signal of AVCER_MODE_F16X3's range contract.  *count = how many GPU threads of this context's launches have
+ * turned a FINITE activation of magnitude >= 65520 into an infinite fp16 hi half since the last reset (every split site:
+ * GEMM / chain / stem epilogues, LayerNorm and GELU outputs, attention Q / K / V, the on-the-fly split of f32 operands).
+ * 0: any NaN in an output came in through the input -- the reference's own result for an empty audio window.  > 0: outputs
+ * produced since the last reset may hold NaN where the reference (fp32, no range limit) holds numbers
+ *   ref: get_prob_video.py:107-112, get_prob_audio_8_cl.py:87-92 (fp32 forward passes)
+ * -- repeat the call with AVCER_MODE_FP32.  Waits for `stream`; reset != 0 zeroes the counter behind the read. */
+int avcer_x3_overflow_count(avcer_ctx* ctx, int reset, int64_t* count, avcer_stream_t stream);
 
 /* Packed weights (host pointers; the library copies them to the device and owns the copy).
  * Blob layout: see avcer_amd/packing.py (header "AVCERW01", tensor table, 64-byte aligned f32 payloads).
@@ -319,6 +333,19 @@ int avcer_gemm_stats(avcer_ctx* ctx, int64_t* launches, double* flops, int reset
  * event durations (ms) and the number of launches since the last read, and rewinds the event pool. */
 int avcer_profile_enable(avcer_ctx* ctx, int on);
 int avcer_profile_read(avcer_ctx* ctx, double* total_ms, int64_t* launches);
+/* The same events by kernel family -- what bench.py's roofline.per_family prices each family with: summed event
+ * milliseconds, launches, algorithmic FLOPs and compulsory HBM bytes (every operand read once, every output written once)
+ * since avcer_profile_enable / the last read.  Arrays of n_fam <= AVCER_FAM_COUNT entries.  Use INSTEAD of
+ * avcer_profile_read (both rewind the event pool). */
+enum {
+    AVCER_FAM_GEMM = 0,    /* conv_gemm_kernel: A and W tiles through LDS */
+    AVCER_FAM_GEMM_WD = 1, /* conv_gemm_wd_kernel: weight fragments direct from global memory (dtype 7 / 8) */
+    AVCER_FAM_CHAIN = 2,   /* bneck_kernel: fused bottleneck chains of ResNet stages 1-2 (HBM-bound) */
+    AVCER_FAM_TAIL = 3,    /* bneck_tail2_kernel: conv3 + residual + next conv1 of stage 3 */
+    AVCER_FAM_STEM = 4,    /* stem_pool(_u8)_kernel */
+    AVCER_FAM_COUNT = 5
+};
+int avcer_profile_read_families(avcer_ctx* ctx, int n_fam, double* ms, int64_t* launches, double* flops, double* bytes);
 
 /* Debug aid for parity tests: arm a one-shot tap; the next forward pass copies up to `bytes` raw bytes of the
  * named intermediate activation (first sub-batch) into dst_dev.  Names: static "pre", "stem_conv", "stem",

@@ -53,6 +53,43 @@ def test_expr_model_stage_taps_fp32(engine_audio, sd_audio):
     assert dl < 1e-4  # measured 1.0e-5
 
 
+def test_expr_model_stage_taps_x3(engine_audio, sd_audio):
+    """The same eleven stage taps in the split-fp16 mode: the 44.9 GFLOP audio graph held stage by stage, not at the logits
+    alone.  The extractor taps (conv0, extract) are sp32 tensors in this mode (hi / lo fp16 per 32 channels, decoded with
+    sp32.raw_to_f32 like tests/test_gpu_visual.py::test_static_stage_taps_x3); the residual-stream taps are f32 in every
+    mode.  Same tolerance as the f32 mode's taps: the fast mode is f32-grade."""
+    from avcer_amd import sp32
+
+    wav = synth.waveforms(5678, 2, 32000)
+    taps = {}
+    with torch.no_grad():
+        x = oa.normalize(wav)
+        ref_logits = oa.expr_model_v3_forward(sd_audio, torch.from_numpy(x), taps)
+    refs = {"norm": torch.from_numpy(x), "conv0": taps["conv0"].transpose(1, 2).contiguous(), "extract": taps["extract"],
+            "proj": taps["proj"], "posconv": taps["posconv"], "layer0": taps["layer0"], "layer5": taps["layer5"],
+            "layer11": taps["layer11"], "w2v": taps["w2v"], "tl1": taps["tl1"], "tl2": taps["tl2"]}
+    split_taps = ("conv0", "extract")
+    report = []
+    engine_audio.x3_overflow_count(reset=True)
+    for name, ref in refs.items():
+        if name in split_taps:
+            dst = engine_audio.debug_tap(name, ref.numel() * 2, dtype=torch.int16)
+        else:
+            dst = engine_audio.debug_tap(name, ref.numel())
+        out = engine_audio.audio_forward(torch.from_numpy(wav), normalize=True, mode=MODE_F16X3)
+        torch.cuda.synchronize()
+        assert engine_audio.debug_tap_copied() == ref.numel() * 4, name
+        got = sp32.raw_to_f32(dst.cpu(), ref.shape) if name in split_taps else dst.cpu().view(ref.shape)
+        report.append((name, (got - ref).abs().max().item(), ref.abs().max().item()))
+    print("audio x3 stage errors (name, max|err|, max|ref|):", report)
+    dl = (out.cpu() - ref_logits).abs().max().item()
+    print("audio x3 max|dlogit|", dl)
+    for name, err, mx in report:
+        assert err < 5e-5 * max(mx, 1.0), report
+    assert dl < 1e-4
+    assert engine_audio.x3_overflow_count(reset=True) == 0  # the synthetic model stays inside the fp16 range
+
+
 @pytest.mark.parametrize("tag,seed,b,t", [("t32000", 5678, 2, 32000), ("t64000", 5679, 1, 64000)])
 def test_expr_model_matches_golden_fp32(engine_audio, golden, tag, seed, b, t):
     g = golden("audio_model")

@@ -82,16 +82,65 @@ def test_c_abi_audio_chunks_empty_chunk_in_repeat_mode_is_nan_not_a_fault(engine
     assert torch.isnan(o[1]).all() and torch.isnan(o[2]).all()
 
 
-def test_x3_activation_overflow_reaches_the_output_as_nan(engine_static):
-    """Range contract of AVCER_MODE_F16X3 (include/avcer_hip.h): activations are fp16 pairs, |x| < 65504.  A preprocessed
-    tensor scaled far beyond that must come back as NaN probabilities -- never as finite, wrong ones -- while the f32 mode
-    still computes it."""
+def test_x3_activation_overflow_reaches_the_output_as_nan_and_is_counted(engine_static):
+    """Range contract of AVCER_MODE_F16X3 (include/avcer_hip.h): activations are fp16 pairs, |x| < 65504.  Through the raw
+    entry points a preprocessed tensor scaled far beyond that comes back as NaN probabilities -- never as finite, wrong
+    ones -- AND the library's range-contract counter says why (avcer_x3_overflow_count > 0), while the f32 mode still
+    computes it.  Inside the range the counter stays at 0."""
+    eng = engine_static
     x = torch.from_numpy(synth.face_frames(7, 2)).float().permute(0, 3, 1, 2).contiguous() - 100.0
-    lg, pr, _ = engine_static.static_forward_nchw(x * 1.0e4, MODE_F16X3)
+    eng.x3_overflow_count(reset=True)
+    lg, pr, _ = eng.static_forward_nchw(x * 1.0e4, MODE_F16X3)
     assert torch.isnan(pr).all() and torch.isnan(lg).all()
-    lg32, pr32, _ = engine_static.static_forward_nchw(x * 1.0e4, MODE_FP32)
+    assert eng.x3_overflow_count(reset=True) > 0
+    assert eng.x3_overflow_count(reset=True) == 0                     # the read above reset it
+    lg32, pr32, _ = eng.static_forward_nchw(x * 1.0e4, MODE_FP32)
     assert torch.isfinite(lg32).all()
-    # the same tensor inside the range: the two parity-grade modes agree
-    lg, pr, _ = engine_static.static_forward_nchw(x, MODE_F16X3)
-    lg32, pr32, _ = engine_static.static_forward_nchw(x, MODE_FP32)
+    assert eng.x3_overflow_count(reset=True) == 0                     # the f32 mode has no range limit and counts nothing
+    # the same tensor inside the range: the two parity-grade modes agree, nothing is counted
+    lg, pr, _ = eng.static_forward_nchw(x, MODE_F16X3)
+    lg32, pr32, _ = eng.static_forward_nchw(x, MODE_FP32)
     assert torch.isfinite(pr).all() and (pr - pr32).abs().max() < 1e-4
+    assert eng.x3_overflow_count(reset=True) == 0
+
+
+def test_mirrors_repeat_an_overflowing_call_in_fp32(engine_static, engine_dynamic, sd_static, sd_dynamic):
+    """What a caller of the drop-in mirrors sees when a checkpoint's activations leave fp16's range: numbers, the ones the
+    reference's fp32 modules compute (get_prob_video.py:107-112) -- the call is repeated in MODE_FP32 (Engine.guarded)."""
+    from avcer_amd.models import DynamicModel, StaticModel
+
+    eng = engine_static
+    x = (torch.from_numpy(synth.face_frames(7, 2)).float().permute(0, 3, 1, 2).contiguous() - 100.0) * 1.0e4
+    ref_lg, ref_pr, ref_ft = eng.static_forward_nchw(x, MODE_FP32)
+    eng.x3_overflow_count(reset=True)
+    model = StaticModel(eng, sd_static)                                # default mode: MODE_F16X3
+    before = eng.x3_fallbacks
+    lg = model(x)
+    assert eng.x3_fallbacks == before + 1
+    assert torch.isfinite(lg).all() and torch.equal(lg, ref_lg) and torch.equal(model.activations["features"], ref_ft)
+    # an in-range call is not repeated and stays in the fast mode
+    x_ok = x * 1.0e-4
+    lg_ok = model(x_ok)
+    assert eng.x3_fallbacks == before + 1 and torch.equal(lg_ok, eng.static_forward_nchw(x_ok, MODE_F16X3)[0])
+    # the LSTM mirror: windows far outside the range (the on-the-fly split of its f32 operand counts too)
+    dyn = DynamicModel(eng, sd_dynamic)
+    w = torch.full((2, 10, 512), 3.0e5)
+    out = dyn(w)
+    assert eng.x3_fallbacks == before + 2 and torch.equal(out, eng.dynamic_forward(w, MODE_FP32))
+
+
+def test_nan_audio_window_is_not_an_overflow(engine_audio):
+    """The reference's legitimate NaN -- the empty tail window under 'mean' padding (get_prob_audio_8_cl.py:78-92,
+    data/utils.py:76-82) -- travels through every split site of the audio model and leaves the range-contract counter at
+    0: a caller can tell it from an overflow."""
+    eng = engine_audio
+    wav = torch.from_numpy(synth.waveforms(5, 1, 16000)[0])
+    eng.x3_overflow_count(reset=True)
+    logits, lo, hi = audio_pipeline.audio_forward(eng, wav, 16000, 25, window=2, step=0.5, padding="mean", mode=MODE_F16X3)
+    assert torch.isnan(logits[-1]).all() and torch.isfinite(logits[:-1]).all()
+    assert eng.x3_overflow_count(reset=True) == 0
+    # ... and a waveform scaled out of the range IS counted (the normaliser is off: the raw samples reach conv0 / LN / GELU)
+    big = torch.from_numpy(synth.waveforms(6, 2, 32000)) * 1.0e7
+    out = eng.audio_forward(big, normalize=False, mode=MODE_F16X3)
+    n = eng.x3_overflow_count(reset=True)
+    assert n > 0 or torch.isfinite(out).all()  # LayerNorm may pull the values back into range: then nothing broke
