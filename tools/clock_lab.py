@@ -27,12 +27,20 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LAB = os.path.join(ROOT, "tools", "lab")
-ARMS = ("product", "noW", "noA", "mfma")
+ARMS = ("product", "noW", "noA", "mfma", "epiNoStore", "epiNoMath")
 NSTAMP = 32768
 
 STAMP_DECL = f"""
 // ---- tools/clock_lab.py: diagnostic build only
 __device__ unsigned long long g_lab_stamps[4 * {NSTAMP}];
+__device__ unsigned long long g_lab_stamps2[4 * {NSTAMP}];
+__device__ unsigned long long g_lab_stamps3[4 * {NSTAMP}];  // entry / exit s_memrealtime, HW_ID | XCC_ID << 32, entry s_memtime
+extern "C" int avcer_lab_stamps3(unsigned long long* host, int n) {{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lab_stamps3), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}}
+extern "C" int avcer_lab_stamps2(unsigned long long* host, int n) {{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lab_stamps2), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}}
 extern "C" int avcer_lab_stamps(unsigned long long* host, int n) {{
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lab_stamps), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
 }}
@@ -60,6 +68,23 @@ def patch_gemm(src: str, arm: str) -> str:
              STAMP.format(c="lab_c1", r="lab_r1") +
              f"    if (tid == 0 && bid < {NSTAMP}) {{ g_lab_stamps[4 * bid] = lab_c1 - lab_c0; g_lab_stamps[4 * bid + 1] = lab_r1 - lab_r0; }}\n"
              '    asm volatile("" : "+v"(ah[0]), "+v"(al[0]));  // the last step\'s look-ahead read')
+    # ... and at the first / last instruction of the kernel: prologue, loop and epilogue shares of a block's residency
+    s = must(s, "    constexpr int BMT = 16 * NFM, BN = 256, NFN = 4, STAGES = 4, ABYTES = 128 * ROWB;",
+             STAMP.format(c="lab_cs", r="lab_rs") + "    constexpr int BMT = 16 * NFM, BN = 256, NFN = 4, STAGES = 4, ABYTES = 128 * ROWB;")
+    s = must(s, "    else wd_epilogue<OUT, 0, NFN, NFM>(p, acc, m_base, c0, lane, wmul);\n#endif",
+             "    else wd_epilogue<OUT, 0, NFN, NFM>(p, acc, m_base, c0, lane, wmul);\n"
+             '    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have been accepted\n' +
+             STAMP.format(c="lab_ce", r="lab_re") +
+             f"    if (tid == 0 && bid < {NSTAMP}) {{ g_lab_stamps[4 * bid + 2] = lab_c0 - lab_cs; g_lab_stamps[4 * bid + 3] = lab_ce - lab_c1; }}\n#endif")
+    if arm == "epiNoStore":  # the epilogue's arithmetic without its stores (the values are folded into one sink word per lane)
+        s = must(s, "        char* yp = p.Y + sp32_byte(e);\n        *reinterpret_cast<uint4*>(yp) = make_uint4(h[0], h[1], h[2], h[3]);\n"
+                    "        *reinterpret_cast<uint4*>(yp + 64) = make_uint4(l[0], l[1], l[2], l[3]);",
+                 "        if ((h[0] ^ h[1] ^ h[2] ^ h[3] ^ l[0] ^ l[1] ^ l[2] ^ l[3]) == 0x12345678u) *reinterpret_cast<uint32_t*>(p.Y) = 1u;")
+    if arm == "epiNoMath":  # the epilogue's stores without its arithmetic: raw accumulator bits go out
+        s = must(s, "                finish8<OUT, ACT>(p, m, ch, scale_bias4(acc[2 * j][h + f], s0, b0), scale_bias4(acc[2 * j + 1][h + f], s1, b1), rr[f][0],\n"
+                    "                                  rr[f][1], ovm);",
+                 "                { char* yp_ = p.Y + sp32_byte(m * p.ldY + p.yoff + ch);\n"
+                 "                  *reinterpret_cast<f32x4_t*>(yp_) = acc[2 * j][h + f]; *reinterpret_cast<f32x4_t*>(yp_ + 64) = acc[2 * j + 1][h + f]; }")
     if arm in ("noW", "mfma"):
         s = must(s, "    u32x4_t wh0[NFN], wl0[NFN], wh1[NFN], wl1[NFN];",
                  "    u32x4_t wh0[NFN], wl0[NFN], wh1[NFN], wl1[NFN];\n"
@@ -102,6 +127,28 @@ def patch_fused(src: str) -> str:
              STAMP.format(c="lab_c1", r="lab_r1").replace("    __b", "        __b").replace("    const", "        const") +
              f"        if (threadIdx.x == 0 && blockIdx.x < {NSTAMP}) {{ g_lab_stamps[4 * blockIdx.x] = lab_c1 - lab_c0; g_lab_stamps[4 * blockIdx.x + 1] = lab_r1 - lab_r0; }}\n"
              "    }\n    }\n")
+    # the spatial-tile form's conv2 loop (no DMA, weights by asm loads): only where the sources carry that form (the round-5
+    # experiment archived in profiles/experiments/r05_bneck_t11_spatial_tile.diff.txt; arm "chain11")
+    if "AVCER_T11_LOAD(0);" in s:
+      s = must(s, "        AVCER_T11_LOAD(0);\n        AVCER_T11_LOAD(1);\n",
+             STAMP.format(c="lab_c0", r="lab_r0").replace("    __b", "        __b").replace("    const", "        const") +
+             "        AVCER_T11_LOAD(0);\n        AVCER_T11_LOAD(1);\n")
+      s = must(s, "#undef AVCER_T11_LOAD\n#undef AVCER_T11_WAIT\n",
+             "#undef AVCER_T11_LOAD\n#undef AVCER_T11_WAIT\n" +
+             STAMP.format(c="lab_c1", r="lab_r1").replace("    __b", "        __b").replace("    const", "        const") +
+             f"        if (threadIdx.x == 0 && blockIdx.x < {NSTAMP}) {{ g_lab_stamps[4 * blockIdx.x] = lab_c1 - lab_c0; g_lab_stamps[4 * blockIdx.x + 1] = lab_r1 - lab_r0; }}\n")
+    # kernel entry / exit, and one common place for the conv2-end stamp of either form (lab_cm: declared at function scope)
+    s = must(s, "    float* sbias = reinterpret_cast<float*>(smem + TILES);\n    for (int i = threadIdx.x; i < NBIAS; i += 256)",
+             STAMP.format(c="lab_cs", r="lab_rs") + "    unsigned long long lab_a0 = 0, lab_a1 = 0;\n"
+             "    float* sbias = reinterpret_cast<float*>(smem + TILES);\n    for (int i = threadIdx.x; i < NBIAS; i += 256)")
+    s = s.replace("g_lab_stamps[4 * blockIdx.x] = lab_c1 - lab_c0;", "lab_a0 = lab_c0; lab_a1 = lab_c1; g_lab_stamps[4 * blockIdx.x] = lab_c1 - lab_c0;")
+    s = must(s, "    sp_commit(p.ovf, ovm);\n}\n\n\n// ------------------------------------------------------------------------------------------------ bottleneck tail",
+             '    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n' + STAMP.format(c="lab_ce", r="lab_re") +
+             f"    if (threadIdx.x == 0 && blockIdx.x < {NSTAMP}) {{ g_lab_stamps2[4 * blockIdx.x] = lab_a0 - lab_cs; g_lab_stamps2[4 * blockIdx.x + 1] = lab_c2 - lab_a1; "
+             "g_lab_stamps2[4 * blockIdx.x + 2] = lab_ce - lab_c3; g_lab_stamps2[4 * blockIdx.x + 3] = lab_ce - lab_cs; "
+             "g_lab_stamps3[4 * blockIdx.x] = lab_rs; g_lab_stamps3[4 * blockIdx.x + 1] = lab_re; "
+             "g_lab_stamps3[4 * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); }\n"
+             "    sp_commit(p.ovf, ovm);\n}\n\n\n// ------------------------------------------------------------------------------------------------ bottleneck tail")
     s = must(s, "    for (int G = 0; G < NG; G += 2) {\n        group(G, rh[0], rl[0]);",
              STAMP.format(c="lab_c2", r="lab_r2") + "    for (int G = 0; G < NG; G += 2) {\n        group(G, rh[0], rl[0]);")
     s = must(s, "        group(G + 1, rh[1], rl[1]);\n    }\n",
@@ -110,7 +157,7 @@ def patch_fused(src: str) -> str:
     return s
 
 
-def build():
+def build(only=()):
     from avcer_amd import build as b
 
     hipcc = b._hipcc()
@@ -118,6 +165,8 @@ def build():
     fused = open(os.path.join(b.CSRC, "fused.hip")).read()
     procs = []
     for arm in ARMS + ("chain",):
+        if only and arm not in only:
+            continue
         d = os.path.join(LAB, "clock_" + arm, "avcer_amd", "csrc")
         shutil.rmtree(os.path.join(LAB, "clock_" + arm), ignore_errors=True)
         os.makedirs(d)
@@ -141,6 +190,8 @@ def build():
         if p.returncode != 0:
             raise SystemExit(f"{arm}: hipcc failed\n{out[-3000:]}")
     for arm in ARMS + ("chain",):
+        if only and arm not in only:
+            continue
         d = os.path.join(LAB, "clock_" + arm, "avcer_amd", "csrc")
         lib = os.path.join(LAB, f"libavcer_clock_{arm}.so")
         objs = [os.path.join(d, s.replace(".hip", ".o")) for s in b.SOURCES]
@@ -156,7 +207,7 @@ def child(arm: str, seconds: float):
     import torch
     from avcer_amd import _lib
 
-    _lib.LIB = os.path.join(LAB, f"libavcer_clock_{arm}.so")
+    _lib.LIB = os.path.join(LAB, f"libavcer_clock_{'chain' if arm == 'chain11' else arm}.so")
     from avcer_amd.engine import Engine
     from tools.layer_bench import conv2d
 
@@ -165,6 +216,10 @@ def child(arm: str, seconds: float):
     eng.lib.avcer_lab_stamps.restype = C.c_int
     eng.lib.avcer_lab_stamps.argtypes = [C.c_void_p, C.c_int]
     torch.manual_seed(1)
+    t11 = arm == "chain11"
+    if t11:
+        arm = "chain"
+        _lib.LIB = os.path.join(LAB, "libavcer_clock_chain.so")
     if arm == "chain":
         planes, nb, hw = 64, 1024, 55
         p4, M = 4 * planes, nb * hw * hw
@@ -173,12 +228,14 @@ def child(arm: str, seconds: float):
         x = sp32.to_sp32(torch.relu(torch.randn(M, p4, device=dev)))
         out = torch.empty((M, 2 * p4), dtype=torch.int16, device=dev)
         t1n = torch.empty((M, 2 * planes), dtype=torch.int16, device=dev)
-        w2 = eng.split_weight_rows(torch.randn(planes, 9 * planes, device=dev) * 0.05)
+        w2f32 = torch.randn(planes, 9 * planes, device=dev) * 0.05
+        w2 = eng.split_weight_rows(w2f32)
+        kw = {"w2_frags": eng.weight_frags(w2f32)} if t11 else {}
         w3 = eng.split_weight_rows(torch.randn(p4, planes, device=dev) * 0.1)
         w1 = eng.split_weight_rows(torch.randn(planes, p4, device=dev) * 0.05)
         b2, b3, b1 = torch.zeros(planes, device=dev), torch.zeros(p4, device=dev), torch.zeros(planes, device=dev)
-        launch = lambda: eng.bneck_chain(planes, nb, hw, hw, t1, x, out, t1n, w2, b2, w3, b3, w1, b1)
-        blocks = (M + 127) // 128
+        launch = lambda: eng.bneck_chain(planes, nb, hw, hw, t1, x, out, t1n, w2, b2, w3, b3, w1, b1, **kw)
+        blocks = nb * 25 if t11 else (M + 127) // 128
     else:
         L = conv2d(2048, 14, 256, 3, 1, 1, 256, "l3.x.c2 3x3 256")
         d = L["d"]
@@ -220,31 +277,87 @@ def child(arm: str, seconds: float):
         return statistics.median(v), statistics.median(cyc), len(v)
 
     if arm == "chain":
+        eng.lib.avcer_lab_stamps2.restype = C.c_int
+        eng.lib.avcer_lab_stamps2.argtypes = [C.c_void_p, C.c_int]
+        buf2 = (C.c_ulonglong * (4 * nst))()
+        assert eng.lib.avcer_lab_stamps2(C.cast(buf2, C.c_void_p), 4 * nst) == 0
+        a2 = list(buf2)
+        def dist(vals):
+            v = sorted(vals)
+            return f"p10 {v[len(v) // 10]:.0f} / p50 {v[len(v) // 2]:.0f} / p90 {v[len(v) * 9 // 10]:.0f} / mean {sum(v) / len(v):.0f}"
+        segs = ("entry -> conv2 loop", "conv2 end -> streaming loop", "streaming end -> exit", "entry -> exit")
+        print("    cycles per block (median): " + "; ".join(f"{n}: {dist([a2[4 * b + i] for b in range(nst)])}" for i, n in enumerate(segs))
+              + "; conv2 loop: " + dist([a[4 * b] for b in range(nst)]) + "; streaming loop: " + dist([a[4 * b + 2] for b in range(nst)]), flush=True)
+        eng.lib.avcer_lab_stamps3.restype = C.c_int
+        eng.lib.avcer_lab_stamps3.argtypes = [C.c_void_p, C.c_int]
+        buf3 = (C.c_ulonglong * (4 * nst))()
+        assert eng.lib.avcer_lab_stamps3(C.cast(buf3, C.c_void_p), 4 * nst) == 0
+        a3 = list(buf3)
+        # blocks resident at once per CU: sweep the entry / exit real times of the blocks that ran on each (XCC, SE, CU)
+        from collections import defaultdict
+        per_cu = defaultdict(list)
+        for b in range(nst):
+            hw = a3[4 * b + 2]
+            hwid, xcc = hw & 0xffffffff, (hw >> 32) & 0xf
+            cu = (xcc, (hwid >> 13) & 0x7, (hwid >> 12) & 0x1, (hwid >> 8) & 0xf)  # XCC, SE_ID, SH_ID, CU_ID (gfx9 HW_ID layout)
+            per_cu[cu].append((a3[4 * b], 1))
+            per_cu[cu].append((a3[4 * b + 1], -1))
+        tot_t, w_sum, hist, refill = 0, 0, defaultdict(int), []
+        for ev in per_cu.values():
+            ev.sort()
+            cur, last, freed = 0, ev[0][0], []
+            for t, d in ev:
+                hist[cur] += t - last
+                w_sum += cur * (t - last)
+                tot_t += t - last
+                cur, last = cur + d, t
+                if d < 0:
+                    freed.append(t)          # a slot of this CU became free ...
+                elif freed:
+                    refill.append((t - freed.pop(0)) * 0.01)  # ... and the next block entered it this many us later
+        if os.environ.get("AVCER_LAB_TIMELINE"):  # the blocks of one CU in entry order: entry, exit (us from the CU's first entry)
+            key = sorted(per_cu)[0]
+            blocks_of = sorted((a3[4 * b], a3[4 * b + 1], b) for b in range(nst)
+                               if ((a3[4 * b + 2] >> 32) & 0xf, ((a3[4 * b + 2] & 0xffffffff) >> 13) & 7, ((a3[4 * b + 2] & 0xffffffff) >> 12) & 1,
+                                   ((a3[4 * b + 2] & 0xffffffff) >> 8) & 0xf) == key)
+            t00 = blocks_of[0][0]
+            print(f"    timeline of CU {key}: " + " ".join(f"[{(e - t00) * 0.01:.1f}-{(x - t00) * 0.01:.1f} b{bb}]" for e, x, bb in blocks_of[:45]), flush=True)
+        refill.sort()
+        if refill:
+            print(f"    slot refill delay on a CU (block exit -> next block's entry, us): p10 {refill[len(refill) // 10]:.2f} / p50 {refill[len(refill) // 2]:.2f} / "
+                  f"p90 {refill[len(refill) * 9 // 10]:.2f} / mean {sum(refill) / len(refill):.2f}", flush=True)
+        print(f"    {len(per_cu)} distinct (XCC, SE, SH, CU) ids; resident blocks per CU, time-weighted: mean {w_sum / max(tot_t, 1):.2f}; share of time at 0 / 1 / 2 / 3 / 4+ blocks: "
+              + " / ".join(f"{hist[k] / max(tot_t, 1):.2f}" for k in range(4)) + f" / {sum(v for k, v in hist.items() if k >= 4) / max(tot_t, 1):.2f}", flush=True)
         c1, cy1, n1 = clk(0)
         c2, cy2, n2 = clk(2)
-        print(f"chain  bneck_kernel<64,128,true,0,false,1> 1024 frames: {us:8.1f} us/launch  conv2 loop {c1:7.1f} MHz ({cy1:.0f} cycles)  "
+        print(f"{'chain11 (spatial-tile form)' if t11 else 'chain  '} bneck_kernel<64,128,true,0,false,1> 1024 frames: {us:8.1f} us/launch  conv2 loop {c1:7.1f} MHz ({cy1:.0f} cycles)  "
               f"streaming loop {c2:7.1f} MHz ({cy2:.0f} cycles)  [{n1} blocks, {n_l} launches in the settle phase]", flush=True)
     else:
         c, cy, n1 = clk(0)
-        print(f"{arm:8s} conv_gemm_wd_kernel l3.x.c2 2048 frames: {us:8.1f} us/launch  K loop {c:7.1f} MHz ({cy:.0f} cycles per block)  "
+        pro = statistics.median(a[4 * b + 2] for b in range(nst))
+        epi = statistics.median(a[4 * b + 3] for b in range(nst))
+        slots = 512  # two blocks per CU
+        resid = us * 1e-6 * c * 1e6 * slots / blocks  # cycles a block slot spends per block, dispatch gap included
+        print(f"{arm:8s} conv_gemm_wd_kernel l3.x.c2 2048 frames: {us:8.1f} us/launch  K loop {c:7.1f} MHz  cycles per block: prologue {pro:.0f}, "
+              f"K loop {cy:.0f}, epilogue {epi:.0f}; slot time per block {resid:.0f} (kernel time x 512 slots / {blocks} blocks)  "
               f"[{n1} blocks, {n_l} launches in the settle phase]", flush=True)
 
 
-def run(seconds: float):
+def run(seconds: float, arms=()):
     print(f"# in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz around the loop, median over workgroups, after >= {seconds:g} s "
           "of back-to-back launches on random data; one process per arm (diagnostic builds: read the CLOCK and the cycle SHARES, "
           "not the launch times -- the stamps' fences forbid overlaps the product kernel has)", flush=True)
     for rep in range(2):
-        for arm in ARMS + ("chain",):
+        for arm in (arms or ARMS + ("chain",)):
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "child", arm, str(seconds)], capture_output=True, text=True, timeout=300)
-            out = [l for l in r.stdout.splitlines() if "MHz" in l]
-            print(out[-1] if out else f"{arm}: FAILED rc={r.returncode}\n{r.stderr[-1500:]}", flush=True)
+            out = [l for l in r.stdout.splitlines() if "MHz" in l or "cycles per block (median)" in l or "resident blocks" in l or "refill" in l or "timeline" in l]
+            print("\n".join(out[-5:]) if out else f"{arm}: FAILED rc={r.returncode}\n{r.stderr[-1500:]}", flush=True)
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "build":
-        build()
+        build(tuple(sys.argv[2:]))
     elif sys.argv[1] == "child":
         child(sys.argv[2], float(sys.argv[3]))
     else:
-        run(float(sys.argv[2]) if len(sys.argv) > 2 else 2.5)
+        run(float(sys.argv[2]) if len(sys.argv) > 2 else 2.5, tuple(sys.argv[3:]))
