@@ -115,6 +115,46 @@ template <> __device__ __forceinline__ void st4<sp32_t>(sp32_t* p, long i, const
     *reinterpret_cast<uint2*>(b + 64) = ll;
 }
 
+// 8 consecutive elements (i a multiple of 8).  The sp32 forms move ONE 16-byte piece per half: 8-byte accesses run at
+// 0.54-0.70 x the 16-byte rate on this part (MI355X_MICROARCH.md), and conv0 / LayerNorm / the average pool were written
+// with the 4-element helpers above (conv0 at 2 x its write floor, the pool at 2 x its read floor: round-4 review, item 7b).
+template <typename T> __device__ __forceinline__ void ld8(const T* p, long i, float* v) {
+    ld4<T>(p, i, v);
+    ld4<T>(p, i + 4, v + 4);
+}
+template <> __device__ __forceinline__ void ld8<sp32_t>(const sp32_t* p, long i, float* v) {
+    const char* b = reinterpret_cast<const char*>(p) + sp32_byte(i);
+    const uint4 h = *reinterpret_cast<const uint4*>(b);
+    const uint4 l = *reinterpret_cast<const uint4*>(b + 64);
+    const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[2 * j] = sp2f((uint16_t)(hw[j] & 0xffff)) + sp2f((uint16_t)(lw[j] & 0xffff));
+        v[2 * j + 1] = sp2f((uint16_t)(hw[j] >> 16)) + sp2f((uint16_t)(lw[j] >> 16));
+    }
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, long i, const float* v, unsigned* ovf = nullptr) {
+    st4<T>(p, i, v, ovf);
+    st4<T>(p, i + 4, v + 4, ovf);
+}
+template <> __device__ __forceinline__ void st8<sp32_t>(sp32_t* p, long i, const float* vin, unsigned* ovf) {
+    char* b = reinterpret_cast<char*>(p) + sp32_byte(i);
+    float v[8], amax = 0.f;
+    uint32_t hw[4], lw[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = sp_value(vin[j]);  // one f32 number for both halves (split_dev.h)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        amax = sp_max2(amax, v[2 * j], v[2 * j + 1]);
+        const uint16_t h0 = f2sp(v[2 * j]), h1 = f2sp(v[2 * j + 1]);
+        hw[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        lw[j] = (uint32_t)f2sp(v[2 * j] - sp2f(h0)) | ((uint32_t)f2sp(v[2 * j + 1] - sp2f(h1)) << 16);
+    }
+    sp_count_now(ovf, amax);  // range contract (split_dev.h)
+    *reinterpret_cast<uint4*>(b) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+    *reinterpret_cast<uint4*>(b + 64) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+}
+
 // ------------------------------------------------------------------------------------------------ preprocess
 // data/utils.py:19-39.  u8 [n,in_h,in_w,3] RGB -> zero-bordered [n,230,230,4] (BGR - mean, 4th channel 0).
 // The border materialises Conv2dSame's asymmetric padding (video.py:68-80: 2 before, 3 after) plus one extra
@@ -558,15 +598,25 @@ __global__ void maxpool3s2_kernel(const T* __restrict__ x, T* __restrict__ y, in
 }
 
 // video.py:110,124: AdaptiveAvgPool2d((1,1)) over hw positions of an NHWC tensor -> f32 [n,c]
+// One thread per (frame, 8 consecutive channels): 16-byte loads (the one-channel form read an sp32 tensor two bytes at a
+// time: 3.4 TB/s); every channel still adds its positions in order 0 .. hw-1, so the sums are the same bits.
 template <typename T>
 __global__ void avgpool_kernel(const T* __restrict__ x, float* __restrict__ y, int n, int hw, int c) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)n * c) return;
-    const int cc = idx % c;
-    const int b = idx / c;
-    float s = 0.f;
-    for (int i = 0; i < hw; ++i) s += ldf<T>(x, ((long)b * hw + i) * c + cc);
-    y[idx] = s / (float)hw;
+    const int c8 = c / 8;
+    if (idx >= (long)n * c8) return;
+    const int cc = (idx % c8) * 8;
+    const long b = idx / c8;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < hw; ++i) {
+        float v[8];
+        ld8<T>(x, (b * hw + i) * c + cc, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = s[j] / (float)hw;
+    st8<float>(y, b * c + cc, s);
 }
 
 // ------------------------------------------------------------------------------------------------ tiny heads
@@ -711,8 +761,7 @@ __global__ void __launch_bounds__(256) conv0_ln_gelu_kernel(const float* __restr
             else v[j] = gelu_fast(u);
         }
         const long o = ((long)row * t_out + t) * 512 + c0;
-        st4<T>(y, o, v, ovf);
-        st4<T>(y, o + 4, v + 4, ovf);
+        st8<T>(y, o, v, ovf);
     }
 }
 
@@ -730,11 +779,11 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const TI* __restrict__ x
     const long base = row * C + lane * PER;
     float v[PER];
 #pragma unroll
-    for (int i = 0; i < PER; i += 4) ld4<TI>(x, base + i, v + i);
+    for (int i = 0; i < PER; i += 8) ld8<TI>(x, base + i, v + i);
     if (res) {
         float r[PER];
 #pragma unroll
-        for (int i = 0; i < PER; i += 4) ld4<TI>(res, base + i, r + i);
+        for (int i = 0; i < PER; i += 8) ld8<TI>(res, base + i, r + i);
 #pragma unroll
         for (int i = 0; i < PER; ++i) v[i] += r[i];
     }
@@ -763,9 +812,9 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const TI* __restrict__ x
         for (int i = 0; i < PER; ++i) v[i] = gelu_fast(v[i]);
     }
 #pragma unroll
-    for (int i = 0; i < PER; i += 4) {
-        if (yf) st4<float>(yf, base + i, v + i);
-        if (yb) st4<OB>(yb, base + i, v + i, ovf);
+    for (int i = 0; i < PER; i += 8) {
+        if (yf) st8<float>(yf, base + i, v + i);
+        if (yb) st8<OB>(yb, base + i, v + i, ovf);
     }
 }
 
@@ -1352,7 +1401,8 @@ int k_maxpool3s2(avcer_ctx* ctx, const void* x, void* y, int n, int h, int w, in
 }
 
 int k_avgpool_hw(avcer_ctx* ctx, const void* x, float* y, int n, int hw, int c, int kind, hipStream_t st) {
-    const long total = (long)n * c;
+    if (c % 8) return set_err(ctx, AVCER_EINVAL, "avgpool: c=%d must be a multiple of 8", c);
+    const long total = (long)n * (c / 8);
     const int grid = cdiv(total, 256);
     if (kind == 1) avgpool_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, y, n, hw, c);
     else if (kind == 2) avgpool_kernel<sp32_t><<<grid, 256, 0, st>>>((const sp32_t*)x, y, n, hw, c);
