@@ -152,7 +152,8 @@ int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
         return !t.x3 && is_w && t.ndim == 2 && t.dims[1] % 32 == 0 && t.dims[0] % 64 == 0;
     };
     // fragment-order copy for the weights-direct kernel (dtype 7 / 8): N a multiple of 256, an even number of K-steps
-    auto frag_ok = [](const Tensor& t) { return t.dims[0] % 256 == 0 && (t.dims[1] / 32) % 2 == 0; };
+    // (the skinny form reads the same copy: any N, a multiple of four K-steps)
+    auto frag_ok = [](const Tensor& t) { return (t.dims[0] % 256 == 0 && (t.dims[1] / 32) % 2 == 0) || (t.dims[1] / 32) % 4 == 0; };
     size_t total = 0;
     for (auto& kv : m.t)
         if (wanted(kv.first, kv.second)) total += split_bytes(kv.second.numel) * (frag_ok(kv.second) ? 2 : 1);
@@ -179,6 +180,8 @@ int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
         }
     return AVCER_OK;
 }
+
+constexpr long kSkinnyM = 256;  // positions up to which the skinny contraction (conv_gemm dtype 9 / 10) serves a launch
 
 // Which form of the x3 contraction serves a layer of M positions, N channels, K inputs: the weights-direct kernel
 // (128 x 256 tiles, dtype 7 / 8) or the LDS-staged one (128 x 128, dtype 5 / 6).  Results are bit-identical, so this is
@@ -237,9 +240,16 @@ struct Net {
             dtype = akind == 0 ? 4 : (okind == 2 ? 5 : 6);
             wp = w->x3;
             // sp32 activations: the weights-direct kernel wherever a fragment-order copy exists (one group, pad-free second source)
-            if (akind == 2 && w->x3f && d.groups <= 1 && (d.tile_n == 256 || (d.tile_n == 0 &&
-                    prefer_weights_direct((long)d.batch * d.out_h * d.out_w, d.n, K, ctx->block_slots)))) {
+            const long M = (long)d.batch * d.out_h * d.out_w;
+            if (akind == 2 && w->x3f && d.n % 256 == 0 && (K / 32) % 2 == 0 && d.groups <= 1 && (d.tile_n == 256 || (d.tile_n == 0 &&
+                    prefer_weights_direct(M, d.n, K, ctx->block_slots)))) {
                 dtype = okind == 2 ? 7 : 8;
+                wp = w->x3f;
+            }
+            // a handful of positions (one frame / one window through the mirrors): one wave per 64 x 32 tile, registers only.
+            // Bit-identical to the tiled forms, so the choice by M does not show in any result.
+            if (akind == 2 && w->x3f && !x2 && d.groups <= 1 && d.tile_n == 0 && M <= kSkinnyM && (K / 32) % 4 == 0 && d.n % 32 == 0) {
+                dtype = okind == 2 ? 9 : 10;
                 wp = w->x3f;
             }
         }

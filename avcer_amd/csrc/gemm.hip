@@ -918,6 +918,141 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------ skinny form (dtype 9 / 10)
+// The same contraction for a HANDFUL of positions (M <= 256: one frame through the drop-in mirrors).
+// There a launch of the tiled forms is one or two blocks walking K in 72-144 dependent steps of 0.66 us each -- every step waits
+// for its own LDS-DMA round trip -- and the one-frame static CNN is 65 such launches: 1.55 ms (profiles/r04_per_call_latency.json).
+// Here a block is ONE wave owning 64 positions x 32 output channels (grid: N / 32 x M / 64, so that many CUs stream weights
+// instead of one or two), nothing goes through LDS and nothing is synchronised: the activation fragments (an sp32 row IS the
+// fragment layout) and the fragment-order weights are loaded straight into a register ring FOUR K-steps deep (one wave per
+// SIMD has the whole 512-register file), so the step is paced by its 24 MFMAs, not by a memory round trip.  Same products in
+// the same order per output element as the tiled forms (the K walk follows p.tap_inner), the same epilogue arithmetic:
+// bit-identical (tests/test_gpu_gemm_wd.py), so results do not depend on which form a batch size selects.
+template <int OUT, int GATHER>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) conv_gemm_skinny_kernel(const GemmParams p) {
+    constexpr int NFM = 4, NFN = 2, D = 4;
+    const int lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
+    const int m_base = blockIdx.y * (16 * NFM), n_base = blockIdx.x * (16 * NFN);
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.X), (short)0, (int)p.x_bytes, 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.WF), (short)0, (int)p.w_bytes, 0x00020000);
+    const float wmul = split_wmul(p.WF, p.w_bytes);
+    const int nk = p.K >> 5, nq = p.Cin >> 5;
+    unsigned a_off[NFM];
+    int a_iy[GATHER == 3 ? NFM : 1], a_ix[GATHER == 3 ? NFM : 1];
+#pragma unroll
+    for (int fm = 0; fm < NFM; ++fm) {
+        const int m = m_base + fm * 16 + l15;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int ox = mm % p.OW, t = mm / p.OW;
+        const int oy = t % p.OH, b = t / p.OH;
+        const int iy = oy * p.sh - p.ph, ix = ox * p.sw - p.pw;
+        a_off[fm] = ok ? (unsigned)(((long)b * p.sB + (long)iy * p.sH + (long)ix * p.sW + p.coff) * 4) + 16u * g : OOB;
+        if constexpr (GATHER == 3) {
+            a_iy[fm] = ok ? iy : -(1 << 28);
+            a_ix[fm] = ix;
+        }
+    }
+    // weight fragments: [(n / 16)][nk][hi, lo][64 lanes][16 B]; this wave owns the two 16-row tiles of its 32 channels
+    const unsigned w_v = (unsigned)lane * 16u;
+    const unsigned w_t0 = (unsigned)(n_base / 16) * (unsigned)nk * 2048u, w_t1 = w_t0 + (unsigned)nk * 2048u;
+    // K position of the next issue: tap (ky, kx) and channel chunk kq, all scalars (the walk of launch_conv_gemm's tap_inner flag).
+    // A macro, not a lambda: captured by reference the three counters went to scratch memory (every issue then waited for them)
+    int kq = 0, kx = 0, ky = 0;
+    u32x4_t ra[D][NFM][2], rw[D][NFN][2];
+#define AVCER_SK_ISSUE(A, W)                                                                                            \
+    do {                                                                                                                \
+        const unsigned a_so = (unsigned)(ky * p.tapH4 + kx * p.tapW4 + kq * ROWB);                                      \
+        const unsigned ks = (unsigned)((ky * p.KW + kx) * nq + kq) * 2048u; /* K-step of the [N][kh][kw][Cin] rows */    \
+        _Pragma("unroll") for (int fm = 0; fm < NFM; ++fm) {                                                            \
+            unsigned vo = a_off[fm], so = a_so;                                                                         \
+            if constexpr (GATHER == 3) { /* padded: the bounds test ignores the scalar offset, and a border row's base */ \
+                                         /* offset is negative (wrapped) until its tap is added                       */ \
+                const int iy = a_iy[GATHER == 3 ? fm : 0] + ky * p.dh, ix = a_ix[GATHER == 3 ? fm : 0] + kx * p.dw;     \
+                const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.Wd);                       \
+                vo = ok ? a_off[fm] + a_so : OOB;                                                                       \
+                so = 0u;                                                                                                \
+            }                                                                                                           \
+            A[fm][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, so, 0);                                           \
+            A[fm][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, vo + 64u, so, 0);                                     \
+        }                                                                                                               \
+        W[0][0] = __builtin_amdgcn_raw_buffer_load_b128(wrs, w_v, w_t0 + ks, 0);                                        \
+        W[0][1] = __builtin_amdgcn_raw_buffer_load_b128(wrs, w_v + 1024u, w_t0 + ks, 0);                                \
+        W[1][0] = __builtin_amdgcn_raw_buffer_load_b128(wrs, w_v, w_t1 + ks, 0);                                        \
+        W[1][1] = __builtin_amdgcn_raw_buffer_load_b128(wrs, w_v + 1024u, w_t1 + ks, 0);                                \
+        if (p.tap_inner) { /* (channel chunk, ky, kx) */                                                                \
+            if (++kx == p.KW) { kx = 0; if (++ky == p.KH) { ky = 0; ++kq; } }                                           \
+        } else { /* (ky, kx, channel chunk) */                                                                          \
+            if (++kq == nq) { kq = 0; if (++kx == p.KW) { kx = 0; ++ky; } }                                             \
+        }                                                                                                               \
+    } while (0)
+    f32x4_t acc[NFN][NFM];
+#pragma unroll
+    for (int a = 0; a < NFN; ++a)
+#pragma unroll
+        for (int b = 0; b < NFM; ++b) acc[a][b] = f32x4_t{0};
+    auto compute = [&](const u32x4_t (&A)[NFM][2], const u32x4_t (&W)[NFN][2]) {
+#pragma unroll
+        for (int fn = 0; fn < NFN; ++fn) {
+            const spx8_t whi = __builtin_bit_cast(spx8_t, W[fn][0]), wlo = __builtin_bit_cast(spx8_t, W[fn][1]);
+#pragma unroll
+            for (int fm = 0; fm < NFM; ++fm) {
+                const spx8_t ahi = __builtin_bit_cast(spx8_t, A[fm][0]), alo = __builtin_bit_cast(spx8_t, A[fm][1]);
+                acc[fn][fm] = mfma_sp(wlo, ahi, acc[fn][fm]);
+                acc[fn][fm] = mfma_sp(whi, alo, acc[fn][fm]);
+                acc[fn][fm] = mfma_sp(whi, ahi, acc[fn][fm]);
+            }
+        }
+    };
+    // nk is a multiple of D (checked by the launcher): no step of the ring needs a guard of its own
+#pragma unroll
+    for (int j = 0; j < D; ++j) AVCER_SK_ISSUE(ra[j], rw[j]);
+    for (int s = 0; s < nk; s += D) {
+        const bool more = s + D < nk;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            __builtin_amdgcn_sched_barrier(0);
+            compute(ra[j], rw[j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) AVCER_SK_ISSUE(ra[j], rw[j]);  // the slot just consumed: step s + j + D
+        }
+    }
+#undef AVCER_SK_ISSUE
+    // epilogue: exactly the direct epilogue of the tiled forms, one 32-channel group per wave
+    sp_flags_t ovm = 0;
+    const int ch = n_base + 8 * g;
+    float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+    if (p.scale) { s0 = *reinterpret_cast<const float4*>(p.scale + ch); s1 = *reinterpret_cast<const float4*>(p.scale + ch + 4); }
+    if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + ch); b1 = *reinterpret_cast<const float4*>(p.bias + ch + 4); }
+    s0 = make_float4(s0.x * wmul, s0.y * wmul, s0.z * wmul, s0.w * wmul);
+    s1 = make_float4(s1.x * wmul, s1.y * wmul, s1.z * wmul, s1.w * wmul);
+    auto fin = [&](auto act) {
+        constexpr int ACT = decltype(act)::value;
+#pragma unroll
+        for (int fm = 0; fm < NFM; ++fm) {
+            const long m = (long)m_base + fm * 16 + l15;
+            if (m >= p.M) continue;
+            uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0;
+            if (p.R) res_load<OUT>(p, m, ch, r0, r1);
+            finish8<OUT, ACT>(p, m, ch, scale_bias4(acc[0][fm], s0, b0), scale_bias4(acc[1][fm], s1, b1), r0, r1, ovm);
+        }
+    };
+    if (p.act == 3) fin(std::integral_constant<int, 3>{});
+    else if (p.act == 2) fin(std::integral_constant<int, 2>{});
+    else if (p.act == 1) fin(std::integral_constant<int, 1>{});
+    else fin(std::integral_constant<int, 0>{});
+    if constexpr (OUT == 2) sp_commit(p.ovf, ovm);
+}
+
+template <int OUT>
+void launch_skinny(const GemmParams& p, hipStream_t st) {
+    const dim3 grid(p.N / 32, (p.M + 63) / 64);
+    if (p.fast && p.KH * p.KW == 1) conv_gemm_skinny_kernel<OUT, 0><<<grid, dim3(64), 0, st>>>(p);
+    else if (p.fast) conv_gemm_skinny_kernel<OUT, 2><<<grid, dim3(64), 0, st>>>(p);
+    else conv_gemm_skinny_kernel<OUT, 3><<<grid, dim3(64), 0, st>>>(p);
+}
+
 template <int OUT, int NFM>
 void launch_wd_t(GemmParams& p, hipStream_t st) {
     p.ntm = (p.M + 16 * NFM - 1) / (16 * NFM);
@@ -988,10 +1123,11 @@ int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1,
 int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const void* x, const void* w,
                      const float* scale, const float* bias, const void* residual, void* y, hipStream_t st,
                      const void* x2) {
-    if (dtype < 0 || dtype > 8) return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d", dtype);
+    if (dtype < 0 || dtype > 10) return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d", dtype);
+    const bool skinny = dtype >= 9;   // 9 / 10: dtype 7 / 8 for a handful of positions (conv_gemm_skinny_kernel)
     const int es = (dtype == 1 || dtype == 2) ? 2 : 4;
-    const bool wdirect = dtype >= 7;  // 7 / 8: dtype 5 / 6 with the weights in fragment order (conv_gemm_wd_kernel)
-    const bool a_split = dtype == 5 || dtype == 6 || wdirect, o_split = dtype == 4 || dtype == 5 || dtype == 7;
+    const bool wdirect = dtype >= 7;  // 7 / 8 (and 9 / 10): dtype 5 / 6 with the weights in fragment order (conv_gemm_wd_kernel)
+    const bool a_split = dtype == 5 || dtype == 6 || wdirect, o_split = dtype == 4 || dtype == 5 || dtype == 7 || dtype == 9;
     const int vec = 16 / es;
     const int bk = ROWB / es;  // 32 elements (f32, split-fp16) or 64 (bf16) per K-step
     const long M = (long)d.batch * d.out_h * d.out_w;
@@ -1060,7 +1196,9 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: tile_m %d (0, 112 or 128)", d.tile_m);
     p.tile_m = d.tile_m;
     p.WF = wdirect ? (const char*)w : nullptr;
-    if (wdirect && (d.n % 256 || (K / bk) % 2 || groups != 1 || d.tile_n == 64 || d.tile_n == 128))
+    if (skinny && (x2 || groups != 1 || d.n % 32 || d.cin % 32 || (K / bk) % 4 || M > 4096))
+        return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d (skinny form) needs one source, one group, K %% 128 == 0, M <= 4096 (M=%ld)", dtype, M);
+    if (wdirect && !skinny && (d.n % 256 || (K / bk) % 2 || groups != 1 || d.tile_n == 64 || d.tile_n == 128))
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d needs N %% 256 == 0, an even number of K-steps, one group (N=%d, K=%ld)",
                        dtype, d.n, K);
     p.tapH4 = (int)((long)d.dil_h * d.x_stride_h * 4);
@@ -1087,7 +1225,9 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
         case 5: launch_t<3, 2>(p, st); break;  // sp32 -> sp32
         case 6: launch_t<3, 0>(p, st); break;  // sp32 -> f32
         case 7: launch_wd<2>(p, st); break;    // sp32 -> sp32, weights direct
-        default: launch_wd<0>(p, st); break;   // sp32 -> f32, weights direct
+        case 8: launch_wd<0>(p, st); break;    // sp32 -> f32, weights direct
+        case 9: launch_skinny<2>(p, st); break;   // sp32 -> sp32, a handful of positions
+        default: launch_skinny<0>(p, st); break;  // sp32 -> f32, a handful of positions
     }
     if (ev1) (void)hipEventRecord(ev1, st);
     hipError_t e = hipGetLastError();

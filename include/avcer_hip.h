@@ -205,7 +205,10 @@ int avcer_fuse(avcer_ctx* ctx, const float* stat, const float* dyn_logits, const
  * 2 = bf16 in / f32 out; split-fp16 ("x3") arithmetic with w pre-split by avcer_split_weight_rows: 3 = f32 in / f32 out,
  * 4 = f32 in / sp32 out, 5 = sp32 in / sp32 out (+ sp32 residual), 6 = sp32 in / f32 out (+ f32 residual);
  * 7 / 8 = 5 / 6 with w in fragment order (avcer_weight_frags): the weights-direct form of the kernel, bit-identical results,
- * for n % 256 == 0, an even number of 32-element K-steps and groups <= 1 (anything else is AVCER_EINVAL: use 5 / 6).
+ * for n % 256 == 0, an even number of 32-element K-steps and groups <= 1 (anything else is AVCER_EINVAL: use 5 / 6);
+ * 9 / 10 = 5 / 6 with w in fragment order once more, the "skinny" form for a handful of positions (one frame or one window per
+ * call: one wave per 64 positions x 32 channels, registers only, no LDS), bit-identical results as well, for
+ * k % 128 == 0, groups <= 1, M <= 4096 (anything else is AVCER_EINVAL).  The networks use it for launches of M <= 256.
  * "sp32" storage = per aligned group of 32 channels, 32 fp16 hi values then 32 fp16 lo values (x = hi + lo), i.e. the
  * layout avcer_split_weights produces; 4 bytes per element. */
 typedef struct avcer_conv_desc {
@@ -305,7 +308,7 @@ int avcer_split_weight_rows(avcer_ctx* ctx, const float* w, void* out, int n, in
 /* The output of avcer_split_weight_rows once more in MFMA fragment order, the weight layout of avcer_conv_gemm dtypes 7 / 8
  * (conv_gemm_wd_kernel: weight fragments go straight from global memory to the registers, only the activation tile passes
  * through LDS): [n/16][k/32][hi, lo][64 lanes][16 bytes], lane l = stored row 16 t + (l & 15), K elements 8 (l >> 4) .. + 8,
- * then the trailer.  rows, out: device pointers, n * k * 4 + AVCER_SPLIT_TRAILER bytes each; n a multiple of 16, k of 32. */
+ * then the trailer.  Dtypes 9 / 10 read the same copy.  rows, out: device pointers, n * k * 4 + AVCER_SPLIT_TRAILER bytes each; n a multiple of 16, k of 32. */
 int avcer_weight_frags(avcer_ctx* ctx, const void* rows, void* out, int n, int k, avcer_stream_t stream);
 
 /* The attention kernel on its own (kernel-level parity tests): softmax(Q K^T * scale) V per (row block, head).

@@ -105,6 +105,81 @@ def test_dual_source_bit_identical(engine, tile_m):
     assert torch.equal(a, bb)
 
 
+# ----------------------------------------------------------------------------- the skinny form (dtype 9 / 10)
+SKINNY_LINEAR = [(1, 128, 64, 0, True), (49, 2048, 512, 1, True), (196, 256, 1024, 1, True), (199, 1024, 3072, 0, False),
+                 (64, 512, 192, 3, False), (257, 4096, 1024, 0, False)]
+SKINNY_CONVS = [
+    # b, h, w, c, kh, kw, stride, pad, dil, n, act
+    (1, 7, 7, 512, 3, 3, 1, 1, 1, 512, 1),      # stage 4 conv2 of ONE frame: 49 positions, K = 4608 (144 K-steps)
+    (1, 14, 14, 256, 3, 3, 1, 1, 1, 256, 1),    # stage 3 conv2 of one frame: 196 positions, four row tiles
+    (1, 14, 14, 256, 3, 3, 2, 1, 1, 256, 1),    # the strided conv2 of stage 3's last block
+    (2, 9, 9, 128, 3, 3, 1, 1, 1, 64, 0),       # every position next to a border, two images in one row tile
+    (1, 31, 1, 128, 4, 1, 3, 0, 2, 64, 0),      # un-padded Conv1d, dilated, several taps (the audio head's kind)
+    (1, 28, 28, 128, 1, 1, 2, 0, 1, 128, 1),    # strided 1x1
+]
+
+
+def _skinny_pair(engine, d, x, w, scale, bias, res, out_sp32):
+    """dtype 5 / 6 (LDS-staged) and 9 / 10 (skinny) on the same device tensors."""
+    dev = engine.device
+    xd = to_sp32(x).to(dev)
+    wd = w.to(dev, torch.float32).contiguous()
+    rows, frags = engine.split_weight_rows(wd), engine.weight_frags(wd)
+    m = d.batch * d.out_h * d.out_w
+    outs = []
+    for dtype, wt in ((5 if out_sp32 else 6, rows), (9 if out_sp32 else 10, frags)):
+        rd = None if res is None else (to_sp32(res).to(dev) if out_sp32 else res.to(dev).contiguous())
+        y = torch.full((m, 2 * d.n) if out_sp32 else (m, d.n), -3, dtype=torch.int16 if out_sp32 else torch.float32, device=dev)
+        engine.conv_gemm(d, dtype, xd, wt, None if scale is None else scale.to(dev), None if bias is None else bias.to(dev), rd, y)
+        torch.cuda.synchronize()
+        outs.append(y.cpu())
+    return outs
+
+
+@pytest.mark.parametrize("m,k,n,act,out_sp32", SKINNY_LINEAR)
+def test_skinny_linear_bit_identical(engine, m, k, n, act, out_sp32):
+    """The one-wave-per-tile form for a handful of positions (conv_gemm_skinny_kernel): the same bits as the tiled forms."""
+    g = torch.Generator().manual_seed(m + k + n)
+    x, w = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5
+    scale, bias = torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g)
+    res = torch.randn(m, n, generator=g)
+    d = _desc(batch=m, cin=k, x_stride_b=k, x_stride_h=k, x_stride_w=k, n=n, y_ld=n, r_ld=n, act=act, res_after_act=act >= 2)
+    a, b = _skinny_pair(engine, d, x, w, scale, bias, res, out_sp32)
+    assert torch.equal(a, b)
+    got = from_sp32(b) if out_sp32 else b
+    assert torch.isfinite(got).all() and got.abs().max() > 0.1
+
+
+@pytest.mark.parametrize("out_sp32", [True, False])
+@pytest.mark.parametrize("cfg", SKINNY_CONVS)
+def test_skinny_conv_bit_identical(engine, cfg, out_sp32):
+    b, h, w_, c, kh, kw, s, p, dil, n, act = cfg
+    g = torch.Generator().manual_seed(sum(cfg) + 1)
+    x = torch.randn(b, h, w_, c, generator=g)
+    w = torch.randn(n, kh * kw * c, generator=g) / (kh * kw * c) ** 0.5
+    scale, bias = torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g)
+    sw, pw, dw = (1, 0, 1) if w_ == 1 else (s, p, dil)
+    oh = (h + 2 * p - dil * (kh - 1) - 1) // s + 1
+    ow = (w_ + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    res = torch.randn(b * oh * ow, n, generator=g)
+    d = _desc(batch=b, in_h=h, in_w=w_, out_h=oh, out_w=ow, cin=c, kh=kh, kw=kw, stride_h=s, stride_w=sw, pad_h=p, pad_w=pw,
+              dil_h=dil, dil_w=dw, x_stride_b=h * w_ * c, x_stride_h=w_ * c, x_stride_w=c, n=n, y_ld=n, r_ld=n, act=act)
+    a, bb = _skinny_pair(engine, d, x.reshape(-1, c), w, scale, bias, res, out_sp32)
+    assert torch.equal(a, bb)
+
+
+def test_skinny_form_refuses_what_it_cannot_do(engine):
+    from avcer_amd._lib import AvcerError
+
+    dev = engine.device
+    x = to_sp32(torch.randn(64, 96)).to(dev)
+    y = torch.zeros(64, 64, device=dev)
+    w = torch.zeros(64 * 96 * 2 + 128, dtype=torch.int16, device=dev)
+    d = _desc(batch=64, cin=96, x_stride_b=96, x_stride_h=96, x_stride_w=96, n=64, y_ld=64, r_ld=64)   # 3 K-steps
+    with pytest.raises(AvcerError, match="skinny form"):
+        engine.conv_gemm(d, 10, x, w, None, None, None, y)
+
+
 def test_shapes_outside_the_form_are_refused(engine):
     from avcer_amd._lib import AvcerError
 

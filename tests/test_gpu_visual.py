@@ -136,6 +136,17 @@ def test_stage3_tail_ragged_rows_match_whole_batch(engine_static):
     assert all(torch.equal(a[:21], b) for a, b in zip(big, part))
 
 
+def test_static_one_frame_matches_its_rows_in_a_batch_x3(engine_static):
+    """One frame per call (what the drop-in mirror hands over) selects other kernels than a batch does -- the skinny
+    contraction (conv_gemm dtype 9 / 10) for every layer of <= 256 positions, the tiled forms above that: bit-identical
+    features, probabilities and logits for 1, 2 and 5 frames against the same frames inside a call of 40."""
+    frames = torch.from_numpy(synth.face_frames(17, 40))
+    big = [t.cpu() for t in engine_static.static_forward(frames, MODE_F16X3)]
+    for lo, hi in ((0, 1), (7, 9), (33, 38)):
+        part = [t.cpu() for t in engine_static.static_forward(frames[lo:hi], MODE_F16X3)]
+        assert all(torch.equal(a[lo:hi], b) for a, b in zip(big, part)), (lo, hi)
+
+
 def test_static_batch_invariance_256(engine_static):
     """BASELINE config 2 size: results must not depend on batch composition (sub-batching at 256)."""
     frames = torch.from_numpy(synth.face_frames(99, 300))
