@@ -109,6 +109,7 @@ __device__ __forceinline__ void res_load(const GemmParams& p, long m, int n0, ui
 template <int OUT, int ACT>
 __device__ __forceinline__ void finish8(const GemmParams& p, long m, int n0, const float4 a, const float4 b, const uint4 r0,
                                         const uint4 r1, sp_flags_t& ovm) {
+#pragma clang fp contract(off)
     float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     float r[8];
     if constexpr (OUT == 0) {
@@ -923,21 +924,101 @@ __global__ void __launch_bounds__(256, 2) conv_gemm_wd_kernel(const GemmParams p
 // The same contraction for a HANDFUL of positions (M <= 256: one frame through the drop-in mirrors).
 // There a launch of the tiled forms is one or two blocks walking K in 72-144 dependent steps of 0.66 us each -- every step waits
 // for its own LDS-DMA round trip -- and the one-frame static CNN is 65 such launches: 1.55 ms (profiles/r04_per_call_latency.json).
-// Here a block is ONE wave owning 64 positions x 32 output channels (grid: N / 32 x M / 64, so that many CUs stream weights
-// instead of one or two), nothing goes through LDS and nothing is synchronised: the activation fragments (an sp32 row IS the
-// fragment layout) and the fragment-order weights are loaded straight into a register ring FOUR K-steps deep (one wave per
-// SIMD has the whole 512-register file), so the step is paced by its 24 MFMAs, not by a memory round trip.  Same products in
-// the same order per output element as the tiled forms (the K walk follows p.tap_inner), the same epilogue arithmetic:
-// bit-identical (tests/test_gpu_gemm_wd.py), so results do not depend on which form a batch size selects.
-template <int OUT, int GATHER>
+// Here a block is ONE wave owning 16 NFM positions x 16 output channels (one weight fragment tile; grid N / 16 x M / (16 NFM),
+// so that hundreds of CUs stream weights instead of one or two), nothing goes through LDS and nothing is synchronised: the
+// activation fragments (an sp32 row IS the fragment layout) and the fragment-order weights are loaded straight into a
+// register ring D K-steps deep (one wave per SIMD has the whole register file: 48 KiB in flight per wave), and everything the
+// epilogue needs from memory (scale, bias, residual) is requested before the K walk.  With so few waves the launch is paced by
+// memory latency x bytes per wave, so the launcher picks the SMALLEST tile that still fits the chip in one round.  Same
+// products in the same order per output element as the tiled forms (the K walk follows p.tap_inner), the same epilogue
+// arithmetic: bit-identical (tests/test_gpu_gemm_wd.py), so results do not depend on which form a batch size selects.
+// Byte offset of the residual piece of output row m, channels n0 .. n0 + 3 (res_load's addressing)
+template <int OUT>
+__device__ __forceinline__ unsigned res_off4(const GemmParams& p, long m, int n0) {
+    if (p.rsub > 1) {
+        const int ohw = p.OH * p.OW;
+        const int b = (int)(m / ohw), rem = (int)m - b * ohw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        m = ((long)b * p.rH + (long)oy * p.rsub) * p.rW + (long)ox * p.rsub;
+    }
+    const long e = m * p.ldR + p.roff + n0;
+    return (unsigned)(OUT == 0 ? e * 4 : sp32_byte(e));
+}
+
+// finish8 for the 4 channels one lane of ONE fragment tile holds (element for element the same arithmetic)
+template <int OUT, int ACT>
+__device__ __forceinline__ void finish4(const GemmParams& p, long m, int n0, const float4 a, const uint2 r0, const uint2 r1,
+                                        sp_flags_t& ovm) {
+#pragma clang fp contract(off)
+    static_assert(OUT == 0 || OUT == 2, "f32 or sp32 output");
+    float v[4] = {a.x, a.y, a.z, a.w};
+    float r[4];
+    if constexpr (OUT == 0) {
+        r[0] = __builtin_bit_cast(float, r0.x); r[1] = __builtin_bit_cast(float, r0.y);
+        r[2] = __builtin_bit_cast(float, r1.x); r[3] = __builtin_bit_cast(float, r1.y);
+    } else {
+        const uint32_t wh[2] = {r0.x, r0.y}, wl[2] = {r1.x, r1.y};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            r[2 * j] = sp2f((uint16_t)(wh[j] & 0xffff)) + sp2f((uint16_t)(wl[j] & 0xffff));
+            r[2 * j + 1] = sp2f((uint16_t)(wh[j] >> 16)) + sp2f((uint16_t)(wl[j] >> 16));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x = p.res_after ? v[j] : v[j] + r[j];
+        if constexpr (ACT == 1) x = relu_nan(x);
+        if constexpr (ACT == 2) x = gelu_erf(x);
+        if constexpr (ACT == 3) x = gelu_fast(x);
+        v[j] = p.res_after ? x + r[j] : x;
+    }
+    const long e = m * p.ldY + p.yoff + n0;
+    if constexpr (OUT == 0) {
+        *reinterpret_cast<float4*>(p.Y + e * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        uint32_t h[2], l[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = sp_value(v[j]);
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            amax = sp_max2(amax, v[2 * j], v[2 * j + 1]);
+            const uint16_t h0 = f2sp(v[2 * j]), h1 = f2sp(v[2 * j + 1]);
+            h[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            l[j] = (uint32_t)f2sp(v[2 * j] - sp2f(h0)) | ((uint32_t)f2sp(v[2 * j + 1] - sp2f(h1)) << 16);
+        }
+        sp_flag(ovm, amax);
+        char* yp = p.Y + sp32_byte(e);
+        *reinterpret_cast<uint2*>(yp) = make_uint2(h[0], h[1]);
+        *reinterpret_cast<uint2*>(yp + 64) = make_uint2(l[0], l[1]);
+    }
+}
+
+template <int OUT, int GATHER, int NFM, int D>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) conv_gemm_skinny_kernel(const GemmParams p) {
-    constexpr int NFM = 4, NFN = 2, D = 4;
     const int lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
-    const int m_base = blockIdx.y * (16 * NFM), n_base = blockIdx.x * (16 * NFN);
+    const int nt = blockIdx.x, m_base = blockIdx.y * (16 * NFM);
     const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.X), (short)0, (int)p.x_bytes, 0x00020000);
     const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.WF), (short)0, (int)p.w_bytes, 0x00020000);
-    const float wmul = split_wmul(p.WF, p.w_bytes);
     const int nk = p.K >> 5, nq = p.Cin >> 5;
+    // stored row 16 t + 4 g + r of a 32-channel group is channel 8 g + 4 t + r (split_weight_rows_kernel): this lane's four
+    const int ch = (nt >> 1) * 32 + 8 * g + 4 * (nt & 1);
+    // everything the epilogue reads, requested now: its latency hides behind the K walk.  Buffer loads, not branches: an absent
+    // operand is a descriptor of zero bytes (a load inside `if (p.scale)` is followed by its own s_waitcnt vmcnt(0))
+    const float wmul = split_wmul(p.WF, p.w_bytes);
+    const auto srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.scale), (short)0, p.scale ? p.N * 4 : 0, 0x00020000);
+    const auto brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), (short)0, p.bias ? p.N * 4 : 0, 0x00020000);
+    const auto rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.R), (short)0, p.R ? 0x7ffffff0 : 0, 0x00020000);
+    const u32x4_t scv = __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)ch * 4u, 0, 0);
+    const u32x4_t biv = __builtin_amdgcn_raw_buffer_load_b128(brs, (unsigned)ch * 4u, 0, 0);
+    u32x2_t rr[NFM][2];  // OUT 0: four f32; OUT 2: four hi, four lo
+#pragma unroll
+    for (int fm = 0; fm < NFM; ++fm) {
+        const long m = (long)m_base + fm * 16 + l15;
+        const unsigned ro = (p.R && m < p.M) ? res_off4<OUT>(p, m, ch) : OOB;
+        rr[fm][0] = __builtin_amdgcn_raw_buffer_load_b64(rrs, ro, 0, 0);
+        rr[fm][1] = __builtin_amdgcn_raw_buffer_load_b64(rrs, ro + (OUT == 0 ? 8u : 64u), 0, 0);
+    }
     unsigned a_off[NFM];
     int a_iy[GATHER == 3 ? NFM : 1], a_ix[GATHER == 3 ? NFM : 1];
 #pragma unroll
@@ -954,88 +1035,78 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             a_ix[fm] = ix;
         }
     }
-    // weight fragments: [(n / 16)][nk][hi, lo][64 lanes][16 B]; this wave owns the two 16-row tiles of its 32 channels
+    // weight fragments: [(n / 16)][nk][hi, lo][64 lanes][16 B]
     const unsigned w_v = (unsigned)lane * 16u;
-    const unsigned w_t0 = (unsigned)(n_base / 16) * (unsigned)nk * 2048u, w_t1 = w_t0 + (unsigned)nk * 2048u;
-    // K position of the next issue: tap (ky, kx) and channel chunk kq, all scalars (the walk of launch_conv_gemm's tap_inner flag).
-    // A macro, not a lambda: captured by reference the three counters went to scratch memory (every issue then waited for them)
-    int kq = 0, kx = 0, ky = 0;
-    u32x4_t ra[D][NFM][2], rw[D][NFN][2];
+    const unsigned w_t = (unsigned)nt * (unsigned)nk * 2048u;
+    // K position of the next issue: tap (ky, kx) and channel chunk kq, all scalars (the walk of launch_conv_gemm's tap_inner
+    // flag); `left` K-steps remain to be requested.  Past the end the ring is fed from out-of-range offsets (zeros, no memory
+    // traffic), so every slot is refilled unconditionally and the counted waits stay static.
+    // A macro, not a lambda: captured by reference the counters went to scratch memory (every issue then waited for them)
+    int kq = 0, kx = 0, ky = 0, left = nk;
+    u32x4_t ra[D][NFM][2], rw[D][2];
 #define AVCER_SK_ISSUE(A, W)                                                                                            \
     do {                                                                                                                \
+        const bool live = left > 0;                                                                                     \
+        --left;                                                                                                         \
         const unsigned a_so = (unsigned)(ky * p.tapH4 + kx * p.tapW4 + kq * ROWB);                                      \
         const unsigned ks = (unsigned)((ky * p.KW + kx) * nq + kq) * 2048u; /* K-step of the [N][kh][kw][Cin] rows */    \
         _Pragma("unroll") for (int fm = 0; fm < NFM; ++fm) {                                                            \
-            unsigned vo = a_off[fm], so = a_so;                                                                         \
+            unsigned vo = live ? a_off[fm] : OOB, so = a_so;                                                            \
             if constexpr (GATHER == 3) { /* padded: the bounds test ignores the scalar offset, and a border row's base */ \
                                          /* offset is negative (wrapped) until its tap is added                       */ \
                 const int iy = a_iy[GATHER == 3 ? fm : 0] + ky * p.dh, ix = a_ix[GATHER == 3 ? fm : 0] + kx * p.dw;     \
-                const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.Wd);                       \
+                const bool ok = live & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.Wd);                \
                 vo = ok ? a_off[fm] + a_so : OOB;                                                                       \
                 so = 0u;                                                                                                \
             }                                                                                                           \
             A[fm][0] = __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, so, 0);                                           \
             A[fm][1] = __builtin_amdgcn_raw_buffer_load_b128(xrs, vo + 64u, so, 0);                                     \
         }                                                                                                               \
-        W[0][0] = __builtin_amdgcn_raw_buffer_load_b128(wrs, w_v, w_t0 + ks, 0);                                        \
-        W[0][1] = __builtin_amdgcn_raw_buffer_load_b128(wrs, w_v + 1024u, w_t0 + ks, 0);                                \
-        W[1][0] = __builtin_amdgcn_raw_buffer_load_b128(wrs, w_v, w_t1 + ks, 0);                                        \
-        W[1][1] = __builtin_amdgcn_raw_buffer_load_b128(wrs, w_v + 1024u, w_t1 + ks, 0);                                \
+        W[0] = __builtin_amdgcn_raw_buffer_load_b128(wrs, live ? w_v : OOB, w_t + ks, 0);                               \
+        W[1] = __builtin_amdgcn_raw_buffer_load_b128(wrs, live ? w_v + 1024u : OOB, w_t + ks, 0);                       \
         if (p.tap_inner) { /* (channel chunk, ky, kx) */                                                                \
             if (++kx == p.KW) { kx = 0; if (++ky == p.KH) { ky = 0; ++kq; } }                                           \
         } else { /* (ky, kx, channel chunk) */                                                                          \
             if (++kq == nq) { kq = 0; if (++kx == p.KW) { kx = 0; ++ky; } }                                             \
         }                                                                                                               \
     } while (0)
-    f32x4_t acc[NFN][NFM];
+    f32x4_t acc[NFM];
 #pragma unroll
-    for (int a = 0; a < NFN; ++a)
-#pragma unroll
-        for (int b = 0; b < NFM; ++b) acc[a][b] = f32x4_t{0};
-    auto compute = [&](const u32x4_t (&A)[NFM][2], const u32x4_t (&W)[NFN][2]) {
-#pragma unroll
-        for (int fn = 0; fn < NFN; ++fn) {
-            const spx8_t whi = __builtin_bit_cast(spx8_t, W[fn][0]), wlo = __builtin_bit_cast(spx8_t, W[fn][1]);
-#pragma unroll
-            for (int fm = 0; fm < NFM; ++fm) {
-                const spx8_t ahi = __builtin_bit_cast(spx8_t, A[fm][0]), alo = __builtin_bit_cast(spx8_t, A[fm][1]);
-                acc[fn][fm] = mfma_sp(wlo, ahi, acc[fn][fm]);
-                acc[fn][fm] = mfma_sp(whi, alo, acc[fn][fm]);
-                acc[fn][fm] = mfma_sp(whi, ahi, acc[fn][fm]);
-            }
-        }
-    };
-    // nk is a multiple of D (checked by the launcher): no step of the ring needs a guard of its own
+    for (int b = 0; b < NFM; ++b) acc[b] = f32x4_t{0};
 #pragma unroll
     for (int j = 0; j < D; ++j) AVCER_SK_ISSUE(ra[j], rw[j]);
     for (int s = 0; s < nk; s += D) {
-        const bool more = s + D < nk;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             __builtin_amdgcn_sched_barrier(0);
-            compute(ra[j], rw[j]);
+            if (s + j < nk) {
+                const spx8_t whi = __builtin_bit_cast(spx8_t, rw[j][0]), wlo = __builtin_bit_cast(spx8_t, rw[j][1]);
+#pragma unroll
+                for (int fm = 0; fm < NFM; ++fm) {
+                    const spx8_t ahi = __builtin_bit_cast(spx8_t, ra[j][fm][0]), alo = __builtin_bit_cast(spx8_t, ra[j][fm][1]);
+                    acc[fm] = mfma_sp(wlo, ahi, acc[fm]);
+                    acc[fm] = mfma_sp(whi, alo, acc[fm]);
+                    acc[fm] = mfma_sp(whi, ahi, acc[fm]);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
-            if (more) AVCER_SK_ISSUE(ra[j], rw[j]);  // the slot just consumed: step s + j + D
+            AVCER_SK_ISSUE(ra[j], rw[j]);  // the slot just consumed: step s + j + D
         }
     }
 #undef AVCER_SK_ISSUE
-    // epilogue: exactly the direct epilogue of the tiled forms, one 32-channel group per wave
+    // epilogue: the direct epilogue of the tiled forms for one fragment tile
     sp_flags_t ovm = 0;
-    const int ch = n_base + 8 * g;
-    float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0, b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-    if (p.scale) { s0 = *reinterpret_cast<const float4*>(p.scale + ch); s1 = *reinterpret_cast<const float4*>(p.scale + ch + 4); }
-    if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + ch); b1 = *reinterpret_cast<const float4*>(p.bias + ch + 4); }
-    s0 = make_float4(s0.x * wmul, s0.y * wmul, s0.z * wmul, s0.w * wmul);
-    s1 = make_float4(s1.x * wmul, s1.y * wmul, s1.z * wmul, s1.w * wmul);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (p.scale) sc = __builtin_bit_cast(float4, scv);
+    const float4 bi = __builtin_bit_cast(float4, biv);  // zeros without a bias
+    sc = make_float4(sc.x * wmul, sc.y * wmul, sc.z * wmul, sc.w * wmul);
     auto fin = [&](auto act) {
         constexpr int ACT = decltype(act)::value;
 #pragma unroll
         for (int fm = 0; fm < NFM; ++fm) {
             const long m = (long)m_base + fm * 16 + l15;
-            if (m >= p.M) continue;
-            uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0;
-            if (p.R) res_load<OUT>(p, m, ch, r0, r1);
-            finish8<OUT, ACT>(p, m, ch, scale_bias4(acc[0][fm], s0, b0), scale_bias4(acc[1][fm], s1, b1), r0, r1, ovm);
+            if (m < p.M) finish4<OUT, ACT>(p, m, ch, scale_bias4(acc[fm], sc, bi), __builtin_bit_cast(uint2, rr[fm][0]),
+                                         __builtin_bit_cast(uint2, rr[fm][1]), ovm);
         }
     };
     if (p.act == 3) fin(std::integral_constant<int, 3>{});
@@ -1045,12 +1116,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     if constexpr (OUT == 2) sp_commit(p.ovf, ovm);
 }
 
+template <int OUT, int NFM, int D>
+void launch_skinny_t(const GemmParams& p, hipStream_t st) {
+    const dim3 grid(p.N / 16, (p.M + 16 * NFM - 1) / (16 * NFM));
+    if (p.fast && p.KH * p.KW == 1) conv_gemm_skinny_kernel<OUT, 0, NFM, D><<<grid, dim3(64), 0, st>>>(p);
+    else if (p.fast) conv_gemm_skinny_kernel<OUT, 2, NFM, D><<<grid, dim3(64), 0, st>>>(p);
+    else conv_gemm_skinny_kernel<OUT, 3, NFM, D><<<grid, dim3(64), 0, st>>>(p);
+}
+
+// The smallest tile whose grid still fits the chip in one round of one wave per SIMD (bit-identical results either way)
 template <int OUT>
 void launch_skinny(const GemmParams& p, hipStream_t st) {
-    const dim3 grid(p.N / 32, (p.M + 63) / 64);
-    if (p.fast && p.KH * p.KW == 1) conv_gemm_skinny_kernel<OUT, 0><<<grid, dim3(64), 0, st>>>(p);
-    else if (p.fast) conv_gemm_skinny_kernel<OUT, 2><<<grid, dim3(64), 0, st>>>(p);
-    else conv_gemm_skinny_kernel<OUT, 3><<<grid, dim3(64), 0, st>>>(p);
+    const long simds = (long)p.slots * 2;  // block slots = 2 per CU, 4 SIMDs per CU
+    const long nt = p.N / 16;
+    if (p.tile_m == 16 || (p.tile_m == 0 && (long)((p.M + 15) / 16) * nt <= simds)) launch_skinny_t<OUT, 1, 12>(p, st);
+    else if (p.tile_m == 32 || (p.tile_m == 0 && (long)((p.M + 31) / 32) * nt <= simds)) launch_skinny_t<OUT, 2, 8>(p, st);
+    else launch_skinny_t<OUT, 4, 4>(p, st);
 }
 
 template <int OUT, int NFM>
@@ -1192,12 +1273,12 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
     if (d.tile_n != 0 && d.tile_n != 64 && d.tile_n != 128 && d.tile_n != 256)
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: tile_n %d (0, 64, 128 or 256)", d.tile_n);
     p.tile_n = d.tile_n;
-    if (d.tile_m != 0 && d.tile_m != 112 && d.tile_m != 128)
-        return set_err(ctx, AVCER_EINVAL, "conv_gemm: tile_m %d (0, 112 or 128)", d.tile_m);
+    if (skinny ? (d.tile_m != 0 && d.tile_m != 16 && d.tile_m != 32 && d.tile_m != 64) : (d.tile_m != 0 && d.tile_m != 112 && d.tile_m != 128))
+        return set_err(ctx, AVCER_EINVAL, "conv_gemm: tile_m %d (0, 112 or 128; dtype 9 / 10: 0, 16, 32 or 64)", d.tile_m);
     p.tile_m = d.tile_m;
     p.WF = wdirect ? (const char*)w : nullptr;
-    if (skinny && (x2 || groups != 1 || d.n % 32 || d.cin % 32 || (K / bk) % 4 || M > 4096))
-        return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d (skinny form) needs one source, one group, K %% 128 == 0, M <= 4096 (M=%ld)", dtype, M);
+    if (skinny && (x2 || groups != 1 || d.cin % 32 || M > 4096))
+        return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d (skinny form) needs one source, one group, cin %% 32 == 0, M <= 4096 (M=%ld)", dtype, M);
     if (wdirect && !skinny && (d.n % 256 || (K / bk) % 2 || groups != 1 || d.tile_n == 64 || d.tile_n == 128))
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d needs N %% 256 == 0, an even number of K-steps, one group (N=%d, K=%ld)",
                        dtype, d.n, K);

@@ -14,6 +14,7 @@ namespace {
 constexpr int ROWB = 128;  // bytes per tile row per K-step
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 constexpr unsigned OOB = 0xFFFFFF00u;  // voffset that always fails the buffer bounds check -> load returns 0
 
 // 16 bytes per lane, global -> LDS (wave-uniform LDS base + lane * 16); zeros when voff fails the bounds check
@@ -31,7 +32,12 @@ __device__ __forceinline__ void dma16(Rsrc rs, char* lds_wave_base, unsigned vof
 __device__ __forceinline__ int swz_key(int row) { return (int)((0x32765410u >> (((row >> 1) & 7) * 4)) & 7u); }
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ swz_key(row)) << 4); }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// (contraction off in the activations and the epilogues that call them: whether their last product fuses with the residual add
+// behind it must not depend on how a kernel's epilogue happens to be shaped -- the forms of one contraction are bit-identical)
+__device__ __forceinline__ float gelu_erf(float x) {
+#pragma clang fp contract(off)
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
 
 // The same function with erf from Abramowitz & Stegun 7.1.26 (1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p |z|)):
 // 14 vector instructions, no branch, against ~45 for the library erff (two divergent branches, a two-step exp).  Against
@@ -39,6 +45,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // (4.5e-7) --, with up to 5e-7 absolute on erf itself near 0.  Used where the arithmetic around it is the split-fp16 or
 // bf16 one (4.5e-6 relative per contraction); the f32 mode keeps erff.
 __device__ __forceinline__ float gelu_fast(float x) {
+#pragma clang fp contract(off)
     const float z = x * 0.70710678118654752440f, a = __builtin_fabsf(z);
     const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, a, 1.0f));
     float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);

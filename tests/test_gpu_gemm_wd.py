@@ -106,7 +106,8 @@ def test_dual_source_bit_identical(engine, tile_m):
 
 
 # ----------------------------------------------------------------------------- the skinny form (dtype 9 / 10)
-SKINNY_LINEAR = [(1, 128, 64, 0, True), (49, 2048, 512, 1, True), (196, 256, 1024, 1, True), (199, 1024, 3072, 0, False),
+SKINNY_LINEAR = [(1, 128, 64, 0, True), (5, 96, 64, 1, False), (40, 416, 128, 2, True),   # K-steps: 4, 3, 13 (ring depths 12 / 8 / 4)
+                 (49, 2048, 512, 1, True), (196, 256, 1024, 1, True), (199, 1024, 3072, 0, False),
                  (64, 512, 192, 3, False), (257, 4096, 1024, 0, False)]
 SKINNY_CONVS = [
     # b, h, w, c, kh, kw, stride, pad, dil, n, act
@@ -119,8 +120,8 @@ SKINNY_CONVS = [
 ]
 
 
-def _skinny_pair(engine, d, x, w, scale, bias, res, out_sp32):
-    """dtype 5 / 6 (LDS-staged) and 9 / 10 (skinny) on the same device tensors."""
+def _skinny_pair(engine, d, x, w, scale, bias, res, out_sp32, tile_m=0):
+    """dtype 5 / 6 (LDS-staged) and 9 / 10 (skinny, rows per wave tile chosen or forced) on the same device tensors."""
     dev = engine.device
     xd = to_sp32(x).to(dev)
     wd = w.to(dev, torch.float32).contiguous()
@@ -130,29 +131,32 @@ def _skinny_pair(engine, d, x, w, scale, bias, res, out_sp32):
     for dtype, wt in ((5 if out_sp32 else 6, rows), (9 if out_sp32 else 10, frags)):
         rd = None if res is None else (to_sp32(res).to(dev) if out_sp32 else res.to(dev).contiguous())
         y = torch.full((m, 2 * d.n) if out_sp32 else (m, d.n), -3, dtype=torch.int16 if out_sp32 else torch.float32, device=dev)
+        d.tile_m = tile_m if dtype >= 9 else 0
         engine.conv_gemm(d, dtype, xd, wt, None if scale is None else scale.to(dev), None if bias is None else bias.to(dev), rd, y)
         torch.cuda.synchronize()
         outs.append(y.cpu())
     return outs
 
 
+@pytest.mark.parametrize("tile_m", [0, 16, 32, 64])
 @pytest.mark.parametrize("m,k,n,act,out_sp32", SKINNY_LINEAR)
-def test_skinny_linear_bit_identical(engine, m, k, n, act, out_sp32):
+def test_skinny_linear_bit_identical(engine, m, k, n, act, out_sp32, tile_m):
     """The one-wave-per-tile form for a handful of positions (conv_gemm_skinny_kernel): the same bits as the tiled forms."""
     g = torch.Generator().manual_seed(m + k + n)
     x, w = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5
     scale, bias = torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g)
     res = torch.randn(m, n, generator=g)
     d = _desc(batch=m, cin=k, x_stride_b=k, x_stride_h=k, x_stride_w=k, n=n, y_ld=n, r_ld=n, act=act, res_after_act=act >= 2)
-    a, b = _skinny_pair(engine, d, x, w, scale, bias, res, out_sp32)
+    a, b = _skinny_pair(engine, d, x, w, scale if m != 199 else None, bias if m != 64 else None, res if m != 1 else None, out_sp32, tile_m)
     assert torch.equal(a, b)
     got = from_sp32(b) if out_sp32 else b
     assert torch.isfinite(got).all() and got.abs().max() > 0.1
 
 
+@pytest.mark.parametrize("tile_m", [16, 32, 64])
 @pytest.mark.parametrize("out_sp32", [True, False])
 @pytest.mark.parametrize("cfg", SKINNY_CONVS)
-def test_skinny_conv_bit_identical(engine, cfg, out_sp32):
+def test_skinny_conv_bit_identical(engine, cfg, out_sp32, tile_m):
     b, h, w_, c, kh, kw, s, p, dil, n, act = cfg
     g = torch.Generator().manual_seed(sum(cfg) + 1)
     x = torch.randn(b, h, w_, c, generator=g)
@@ -164,19 +168,41 @@ def test_skinny_conv_bit_identical(engine, cfg, out_sp32):
     res = torch.randn(b * oh * ow, n, generator=g)
     d = _desc(batch=b, in_h=h, in_w=w_, out_h=oh, out_w=ow, cin=c, kh=kh, kw=kw, stride_h=s, stride_w=sw, pad_h=p, pad_w=pw,
               dil_h=dil, dil_w=dw, x_stride_b=h * w_ * c, x_stride_h=w_ * c, x_stride_w=c, n=n, y_ld=n, r_ld=n, act=act)
-    a, bb = _skinny_pair(engine, d, x.reshape(-1, c), w, scale, bias, res, out_sp32)
+    a, bb = _skinny_pair(engine, d, x.reshape(-1, c), w, scale, bias, res, out_sp32, tile_m)
     assert torch.equal(a, bb)
+
+
+@pytest.mark.parametrize("out_sp32", [True, False])
+def test_skinny_subsampled_residual_bit_identical(engine, out_sp32):
+    """conv3 of a stage's last block at the even positions only: output row (b, oy, ox) adds residual row (b, 2 oy, 2 ox)."""
+    b, oh, planes, n = 2, 7, 256, 1024
+    g = torch.Generator().manual_seed(11)
+    x, w = torch.randn(b * oh * oh, planes, generator=g), torch.randn(n, planes, generator=g) / planes ** 0.5
+    scale, bias = torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g)
+    res = torch.randn(b * 4 * oh * oh, n, generator=g)
+    d = _desc(batch=b, in_h=oh, in_w=oh, out_h=oh, out_w=oh, cin=planes, x_stride_b=oh * oh * planes, x_stride_h=oh * planes,
+              x_stride_w=planes, n=n, y_ld=n, r_ld=n, act=1, r_sub=2, r_h=2 * oh, r_w=2 * oh)
+    a, bb = _skinny_pair(engine, d, x, w, scale, bias, res, out_sp32)
+    assert torch.equal(a, bb)
+    ref = torch.relu(x.double() @ w.double().T * scale.double() + bias.double()
+                     + res.double().reshape(b, 2 * oh, 2 * oh, n)[:, ::2, ::2].reshape(-1, n))
+    got = (from_sp32(bb) if out_sp32 else bb).double()
+    assert (got - ref).abs().max() < 2e-5 * ref.abs().max()
 
 
 def test_skinny_form_refuses_what_it_cannot_do(engine):
     from avcer_amd._lib import AvcerError
 
     dev = engine.device
-    x = to_sp32(torch.randn(64, 96)).to(dev)
-    y = torch.zeros(64, 64, device=dev)
-    w = torch.zeros(64 * 96 * 2 + 128, dtype=torch.int16, device=dev)
-    d = _desc(batch=64, cin=96, x_stride_b=96, x_stride_h=96, x_stride_w=96, n=64, y_ld=64, r_ld=64)   # 3 K-steps
+    x = to_sp32(torch.randn(4160, 64)).to(dev)
+    y = torch.zeros(4160, 64, device=dev)
+    w = torch.zeros(64 * 64 * 2 + 128, dtype=torch.int16, device=dev)
+    d = _desc(batch=4160, cin=64, x_stride_b=64, x_stride_h=64, x_stride_w=64, n=64, y_ld=64, r_ld=64)   # M > 4096
     with pytest.raises(AvcerError, match="skinny form"):
+        engine.conv_gemm(d, 10, x, w, None, None, None, y)
+    d = _desc(batch=64, cin=64, x_stride_b=64, x_stride_h=64, x_stride_w=64, n=64, y_ld=64, r_ld=64)
+    d.tile_m = 128
+    with pytest.raises(AvcerError, match="tile_m"):
         engine.conv_gemm(d, 10, x, w, None, None, None, y)
 
 
