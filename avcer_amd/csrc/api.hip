@@ -151,9 +151,9 @@ int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
         const bool is_w = k.size() > 3 && (k.compare(k.size() - 2, 2, ".w") == 0 || k.compare(k.size() - 3, 3, ".wf") == 0);
         return !t.x3 && is_w && t.ndim == 2 && t.dims[1] % 32 == 0 && t.dims[0] % 64 == 0;
     };
-    // fragment-order copy for the weights-direct kernel (dtype 7 / 8): N a multiple of 256, an even number of K-steps
-    // (the skinny form reads the same copy: any N, a multiple of four K-steps)
-    auto frag_ok = [](const Tensor& t) { return (t.dims[0] % 256 == 0 && (t.dims[1] / 32) % 2 == 0) || (t.dims[1] / 32) % 4 == 0; };
+    // fragment-order copy for the weights-direct kernel (dtype 7 / 8: N a multiple of 256, an even number of K-steps) and for
+    // the skinny form (dtype 9 / 10: any shape the row split exists for)
+    auto frag_ok = [](const Tensor&) { return true; };
     size_t total = 0;
     for (auto& kv : m.t)
         if (wanted(kv.first, kv.second)) total += split_bytes(kv.second.numel) * (frag_ok(kv.second) ? 2 : 1);
@@ -181,7 +181,12 @@ int ensure_all_x3(avcer_ctx* ctx, Model& m, hipStream_t st) {
     return AVCER_OK;
 }
 
-constexpr long kSkinnyM = 256;  // positions up to which the skinny contraction (conv_gemm dtype 9 / 10) serves a launch
+// When the skinny form (conv_gemm dtype 9 / 10) serves a launch: while its grid of 32-position x 16-channel wave tiles fits the
+// chip's SIMDs in one round.  tools/ab_layers.py --skinny at 1 / 4 / 16 / 64 frames and windows (profiles/r05_skinny_ab.txt):
+// below that count it beats the better tiled form on every layer shape of both networks (by 1.05-3.8x), above it it loses.
+static bool prefer_skinny(long M, int n, int block_slots) {
+    return M <= 4096 && ((M + 31) / 32) * (long)(n / 16) <= 2L * block_slots;
+}
 
 // Which form of the x3 contraction serves a layer of M positions, N channels, K inputs: the weights-direct kernel
 // (128 x 256 tiles, dtype 7 / 8) or the LDS-staged one (128 x 128, dtype 5 / 6).  Results are bit-identical, so this is
@@ -246,11 +251,14 @@ struct Net {
                 dtype = okind == 2 ? 7 : 8;
                 wp = w->x3f;
             }
-            // a handful of positions (one frame / one window through the mirrors): one wave per 64 x 32 tile, registers only.
-            // Bit-identical to the tiled forms, so the choice by M does not show in any result.
-            if (akind == 2 && w->x3f && !x2 && d.groups <= 1 && d.tile_n == 0 && M <= kSkinnyM && (K / 32) % 4 == 0 && d.n % 32 == 0) {
+            // a handful of positions (a frame or a window per call through the mirrors; the deep layers of a small batch): one
+            // wave per (16-64) x 16 tile, registers only.  Bit-identical to the tiled forms, so the choice by M does not show in
+            // any result.  tile_n is a hint for the tiled forms and does not apply.
+            if (akind == 2 && w->x3f && !x2 && d.groups <= 1 && prefer_skinny(M, d.n, ctx->block_slots)) {
                 dtype = okind == 2 ? 9 : 10;
                 wp = w->x3f;
+                d.tile_n = 0;
+                d.tile_m = 0;
             }
         }
         if (dtype < 0 || !wp) {
@@ -313,6 +321,10 @@ avcer_conv_desc conv1d_desc(int nb, int len, int c, int k, int stride, int pad, 
     return d;
 }
 
+// Stage-3 tails (conv3 + residual + the next block's conv1) of at most this many positions run as two contractions instead of
+// the fused bneck_tail2_kernel: bit-identical, and faster up to 64 frames per call (0.66 vs 0.90 ms at one frame, 2.39 vs 2.42
+// at 64, 3.51 vs 3.44 at 128: tools/tail_pair_probe.py, profiles/experiments/r05_tail_pair_probe.txt)
+constexpr long kTailPairRows = 16384;
 constexpr int kStages[4][3] = {{64, 3, 1}, {128, 4, 2}, {256, 6, 2}, {512, 3, 2}};  // video.py:105-108,165
 
 }  // namespace
@@ -423,7 +435,7 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     const size_t pre_elems = (size_t)NB * 230 * 230 * 4;
     if (back_elems * es >= 0xF0000000ull) return set_err(ctx, AVCER_EINVAL, "static_forward: %d frames per back pass", NS);
     const size_t total = pre_elems * es + 4 * (act_elems * es + 256) + 4 * (back_elems * es + 256) +
-                         (size_t)NS * (2048 + 512) * 4 + 4096;
+                         (size_t)NS * (2048 * 2 + 512) * 4 + 4096;
     void* wsp = nullptr;
     TRY(ws_reserve(ctx, 0, total, &wsp));
     Arena ar(wsp, ctx->ws[0].cap);
@@ -433,6 +445,7 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
     void* bbuf[4];
     for (auto& b : bbuf) b = ar.get(back_elems * es);
     float* pooled = (float*)ar.get((size_t)NS * 2048 * 4);
+    void* pooled_sp = ar.get((size_t)NS * 2048 * 4);
     float* feat_ws = (float*)ar.get((size_t)NS * 512 * 4);
     if (!feat_ws) return set_err(ctx, AVCER_ENOMEM, "static workspace arithmetic");
 
@@ -498,7 +511,15 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
                              X, nullptr, T1, act, act);
                 net.gemm(conv2d_desc(nb, h, h, planes, 3, 3, sub, 1, planes, 1), p + "c2.w", net.F(p + "c2.s"), net.F(p + "c2.b"), T1,
                          nullptr, T2, act, act);
-                if (b + 1 < blocks) {
+                if (b + 1 < blocks && (long)nb * h * h <= kTailPairRows) {
+                    // few positions: the same two contractions (same folded weights, same arithmetic: bit-identical) as two
+                    // launches of the skinny / tiled forms -- the fused kernel's 128-row blocks leave the chip empty here
+                    const std::string pn = "l" + std::to_string(li + 1) + "." + std::to_string(b + 1) + ".";
+                    net.gemm(conv2d_desc(nb, h, h, planes, 1, 1, 1, 0, planes * 4, 1), p + "c3.wf", nullptr, net.F(p + "c3.b"), T2, X,
+                             dst, act, act);
+                    net.gemm(conv2d_desc(nb, h, h, planes * 4, 1, 1, 1, 0, planes, 1), pn + "c1.wf", nullptr, net.F(pn + "c1.b"), dst,
+                             nullptr, T1, act, act);
+                } else if (b + 1 < blocks) {
                     const std::string pn = "l" + std::to_string(li + 1) + "." + std::to_string(b + 1) + ".";
                     const Tensor *w3 = net.T(p + "c3.wf"), *w1n = net.T(pn + "c1.wf");
                     if (net.err != AVCER_OK) return;
@@ -590,7 +611,8 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
         int h = 28, cin = 512;
         run_stage(1, nb, X, T1, T2, OUT, h, cin, nullptr, 1, kStages[1][1]);
         for (int li = 2; li < 4; ++li) run_stage(li, nb, X, T1, T2, OUT, h, cin, nullptr, 0, kStages[li][1]);
-        net.chk(k_avgpool_hw(ctx, X, pooled, nb, h * h, 2048, act, st));
+        // x3 mode: the pooled features once more as sp32 pairs, fc1's operand (the split fc1 did on the fly before)
+        net.chk(k_avgpool_hw(ctx, X, pooled, net.x3 ? pooled_sp : nullptr, nb, h * h, 2048, act, st));
         net.tap("avgpool", pooled, (size_t)nb * 2048 * 4);
         float* fo = feats ? feats + (size_t)s0 * 512 : feat_ws;
         {
@@ -599,7 +621,8 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
             // of the time of the f32 MFMA on this launch-latency-bound layer (16 tiles at batch 256: 114 -> ~30 us).
             avcer_conv_desc fd = linear_desc(nb, 2048, 512, 0);
             fd.tile_n = 64;  // 128 x 64 tiles: twice the blocks of a grid that does not fill the chip anyway
-            net.gemm(fd, "fc1.w", nullptr, net.F("fc1.b"), pooled, nullptr, fo, 0, 0);
+            if (net.x3) net.gemm(fd, "fc1.w", nullptr, net.F("fc1.b"), pooled_sp, nullptr, fo, 2, 0);
+            else net.gemm(fd, "fc1.w", nullptr, net.F("fc1.b"), pooled, nullptr, fo, 0, 0);
         }
         if (logits || probs)
             net.chk(k_small_linear(ctx, fo, net.F("fc2.w"), net.F("fc2.b"), logits ? logits + (size_t)s0 * 7 : nullptr,

@@ -131,7 +131,7 @@ int measure_ceilings(avcer_ctx* ctx, double* mfma_bf16_tflops, double* hbm_copy_
 // kind: 0 = f32 [n,230,230,4], 1 = bf16, 3 = planar fp16 hi / lo (two [n,230,230,4] planes, the stem_pool input)
 int k_preprocess(avcer_ctx*, const uint8_t* frames, int n, int in_h, int in_w, void* out, int kind, hipStream_t);
 int k_maxpool3s2(avcer_ctx*, const void* x, void* y, int n, int h, int w, int c, int oh, int ow, int bf16, hipStream_t);
-int k_avgpool_hw(avcer_ctx*, const void* x, float* y, int n, int hw, int c, int bf16, hipStream_t);
+int k_avgpool_hw(avcer_ctx*, const void* x, float* y, void* y_sp32, int n, int hw, int c, int kind, hipStream_t);
 int k_small_linear(avcer_ctx*, const float* x, const float* w, const float* b, float* logits, float* probs, int m,
                    int k, int n, int relu_in, hipStream_t);
 int k_lstm_cell(avcer_ctx*, const float* xproj, int64_t xproj_ld, const float* hproj, float* c, float* h_out,

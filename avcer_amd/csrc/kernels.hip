@@ -600,23 +600,33 @@ __global__ void maxpool3s2_kernel(const T* __restrict__ x, T* __restrict__ y, in
 // video.py:110,124: AdaptiveAvgPool2d((1,1)) over hw positions of an NHWC tensor -> f32 [n,c]
 // One thread per (frame, 8 consecutive channels): 16-byte loads (the one-channel form read an sp32 tensor two bytes at a
 // time: 3.4 TB/s); every channel still adds its positions in order 0 .. hw-1, so the sums are the same bits.
+// Positions are requested seven at a time before any is added (one frame per call is a single block: its 49 dependent
+// round trips were 19 us), and added in the same order.  ysp: the same values once more as sp32 pairs (fc1's operand in x3 mode).
 template <typename T>
-__global__ void avgpool_kernel(const T* __restrict__ x, float* __restrict__ y, int n, int hw, int c) {
+__global__ void avgpool_kernel(const T* __restrict__ x, float* __restrict__ y, sp32_t* __restrict__ ysp, int n, int hw, int c,
+                               unsigned* ovf) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c8 = c / 8;
     if (idx >= (long)n * c8) return;
     const int cc = (idx % c8) * 8;
     const long b = idx / c8;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < hw; ++i) {
-        float v[8];
-        ld8<T>(x, (b * hw + i) * c + cc, v);
+    constexpr int U = 7;
+    for (int i0 = 0; i0 < hw; i0 += U) {
+        float v[U][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] += v[j];
+        for (int u = 0; u < U; ++u) ld8<T>(x, (b * hw + min(i0 + u, hw - 1)) * c + cc, v[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i0 + u < hw) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += v[u][j];
+            }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = s[j] / (float)hw;
     st8<float>(y, b * c + cc, s);
+    if (ysp) st8<sp32_t>(ysp, b * c + cc, s, ovf);
 }
 
 // ------------------------------------------------------------------------------------------------ tiny heads
@@ -632,6 +642,9 @@ __global__ void small_linear_kernel(const float* __restrict__ x, const float* __
     float acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    // (unrolled: the loads of eight K positions are in flight together -- one row per call is one wave, and 8 dependent
+    // round trips per output were the kernel; the adds keep their order)
+#pragma unroll 8
     for (int kk = lane; kk < k; kk += 64) {
         float xv = x[(long)row * k + kk];
         if (relu_in) xv = relu_nan(xv);
@@ -1400,13 +1413,15 @@ int k_maxpool3s2(avcer_ctx* ctx, const void* x, void* y, int n, int h, int w, in
     return AVCER_OK;
 }
 
-int k_avgpool_hw(avcer_ctx* ctx, const void* x, float* y, int n, int hw, int c, int kind, hipStream_t st) {
-    if (c % 8) return set_err(ctx, AVCER_EINVAL, "avgpool: c=%d must be a multiple of 8", c);
+int k_avgpool_hw(avcer_ctx* ctx, const void* x, float* y, void* y_sp32, int n, int hw, int c, int kind, hipStream_t st) {
+    if (c % 32) return set_err(ctx, AVCER_EINVAL, "avgpool: c=%d must be a multiple of 32", c);
     const long total = (long)n * (c / 8);
-    const int grid = cdiv(total, 256);
-    if (kind == 1) avgpool_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)x, y, n, hw, c);
-    else if (kind == 2) avgpool_kernel<sp32_t><<<grid, 256, 0, st>>>((const sp32_t*)x, y, n, hw, c);
-    else avgpool_kernel<float><<<grid, 256, 0, st>>>((const float*)x, y, n, hw, c);
+    // 64 threads per block: one frame per call is 256 threads, and four CUs run them in the time of one
+    const int grid = cdiv(total, 64);
+    sp32_t* ysp = (sp32_t*)y_sp32;
+    if (kind == 1) avgpool_kernel<bf16_t><<<grid, 64, 0, st>>>((const bf16_t*)x, y, ysp, n, hw, c, ctx->ovf);
+    else if (kind == 2) avgpool_kernel<sp32_t><<<grid, 64, 0, st>>>((const sp32_t*)x, y, ysp, n, hw, c, ctx->ovf);
+    else avgpool_kernel<float><<<grid, 64, 0, st>>>((const float*)x, y, ysp, n, hw, c, ctx->ovf);
     CHECK_LAUNCH(ctx, "avgpool");
     return AVCER_OK;
 }

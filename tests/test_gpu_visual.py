@@ -128,21 +128,23 @@ def test_static_resize_path(engine_static, sd_static):
 
 def test_stage3_tail_ragged_rows_match_whole_batch(engine_static):
     """The stage-3 tail kernel (conv3 + residual + next conv1, fused.hip) on a position count that is not a multiple of its
-    128-row tile: 21 frames = 4116 positions = 32 tiles + 20 rows.  The rows of the ragged last tile are bit-identical to
-    the same frames inside a larger call (rows past M are dropped by the store descriptor, never written elsewhere)."""
-    frames = torch.from_numpy(synth.face_frames(5, 40))
+    128-row tile: 85 frames = 16660 positions = 130 tiles + 20 rows (above api.hip kTailPairRows, where the fused kernel
+    serves).  The rows of the ragged last tile are bit-identical to the same frames inside a larger call (rows past M are
+    dropped by the store descriptor, never written elsewhere)."""
+    frames = torch.from_numpy(synth.face_frames(5, 100))
     big = [t.cpu() for t in engine_static.static_forward(frames, MODE_F16X3)]
-    part = [t.cpu() for t in engine_static.static_forward(frames[:21], MODE_F16X3)]
-    assert all(torch.equal(a[:21], b) for a, b in zip(big, part))
+    part = [t.cpu() for t in engine_static.static_forward(frames[:85], MODE_F16X3)]
+    assert all(torch.equal(a[:85], b) for a, b in zip(big, part))
 
 
 def test_static_one_frame_matches_its_rows_in_a_batch_x3(engine_static):
-    """One frame per call (what the drop-in mirror hands over) selects other kernels than a batch does -- the skinny
-    contraction (conv_gemm dtype 9 / 10) for every layer of <= 256 positions, the tiled forms above that: bit-identical
-    features, probabilities and logits for 1, 2 and 5 frames against the same frames inside a call of 40."""
-    frames = torch.from_numpy(synth.face_frames(17, 40))
+    """A frame per call (what the drop-in mirror hands over) selects other kernels than a batch does -- the skinny
+    contraction (conv_gemm dtype 9 / 10) wherever a layer's grid of wave tiles fits the chip, the stage-3 tails as two
+    contractions instead of the fused kernel (api.hip kTailPairRows), fc1 on 16-row tiles: bit-identical features,
+    probabilities and logits for 1, 2, 5 and 40 frames against the same frames inside a call of 100."""
+    frames = torch.from_numpy(synth.face_frames(17, 100))
     big = [t.cpu() for t in engine_static.static_forward(frames, MODE_F16X3)]
-    for lo, hi in ((0, 1), (7, 9), (33, 38)):
+    for lo, hi in ((0, 1), (7, 9), (33, 38), (60, 100)):
         part = [t.cpu() for t in engine_static.static_forward(frames[lo:hi], MODE_F16X3)]
         assert all(torch.equal(a[lo:hi], b) for a, b in zip(big, part)), (lo, hi)
 

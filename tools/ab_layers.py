@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--f32out", action="store_true", help="f32 output (dtype 6 / 8) instead of sp32 (5 / 7)")
     ap.add_argument("--act", type=int, default=-1, help="override the layers' activation (0 none, 1 relu, 2 gelu, 3 gelu with the short erf)")
+    ap.add_argument("--skinny", action="store_true", help="arms of the skinny form (dtype 9 / 10; tiles of 16 / 32 / 64 positions) where M <= 4096")
     ap.add_argument("--lib", default="", help="a one-off experiment build of libavcer_hip.so to load instead of the in-tree one")
     a = ap.parse_args()
     if a.lib:
@@ -69,6 +70,10 @@ def main():
             y = torch.empty(ylen, device=dev)
             res = torch.randn(ylen, device=dev) if L["res"] else None
         arms = [("staged", ds, rows, 0), ("direct128", dd, frags, 128), ("direct112", dd, frags, 112), ("library", dd, frags, 0)]
+        if a.skinny:
+            if m > 4096:
+                continue
+            arms = [("staged", ds, rows, 0), ("library", dd, frags, 0)] + [(f"skinny{t}", dd + 2, frags, t) for t in (16, 32, 64)]
 
         def launch(dt, wt, tm, cnt):
             d.tile_m = tm
@@ -91,8 +96,11 @@ def main():
         best = min(med.values())
         tot["staged"] += med["staged"] * L["count"]
         tot["best"] += best * L["count"]
-        print(f"{L['name']:38s} {L['count']:3d} {med['staged']:10.1f} {med['direct128']:10.1f} {med['direct112']:10.1f} "
-              f"{med['library']:10.1f} {best / med['staged']:11.3f}")
+        if a.skinny:
+            print(f"{L['name']:38s} M={m:5d} K={k:5d} N={n:5d}  " + "  ".join(f"{nm} {v:7.1f}" for nm, v in med.items()))
+        else:
+            print(f"{L['name']:38s} {L['count']:3d} {med['staged']:10.1f} {med['direct128']:10.1f} {med['direct112']:10.1f} "
+                  f"{med['library']:10.1f} {best / med['staged']:11.3f}")
         d.tile_m = 0
         del x, w, rows, frags, y, res
     print(f"sum over the layers above (x count): staged {tot['staged'] / 1e3:.2f} ms, best arm per layer {tot['best'] / 1e3:.2f} ms")
