@@ -254,7 +254,7 @@ struct Net {
             // a handful of positions (a frame or a window per call through the mirrors; the deep layers of a small batch): one
             // wave per (16-64) x 16 tile, registers only.  Bit-identical to the tiled forms, so the choice by M does not show in
             // any result.  tile_n is a hint for the tiled forms and does not apply.
-            if (akind == 2 && w->x3f && !x2 && d.groups <= 1 && prefer_skinny(M, d.n, ctx->block_slots)) {
+            if (akind == 2 && w->x3f && !x2 && prefer_skinny(M, d.n * (d.groups > 1 ? d.groups : 1), ctx->block_slots)) {
                 dtype = okind == 2 ? 9 : 10;
                 wp = w->x3f;
                 d.tile_n = 0;

@@ -997,7 +997,10 @@ __device__ __forceinline__ void finish4(const GemmParams& p, long m, int n0, con
 template <int OUT, int GATHER, int NFM, int D>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) conv_gemm_skinny_kernel(const GemmParams p) {
     const int lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
+    // grouped convolution: the fragment tiles of all groups side by side (weight rows are stacked [groups * N][K]); group grp
+    // reads its own Cin channels of the input pixel and owns channels grp * N .. + N of the output
     const int nt = blockIdx.x, m_base = blockIdx.y * (16 * NFM);
+    const int grp = p.groups > 1 ? nt / (p.N >> 4) : 0;
     const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.X), (short)0, (int)p.x_bytes, 0x00020000);
     const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.WF), (short)0, (int)p.w_bytes, 0x00020000);
     const int nk = p.K >> 5, nq = p.Cin >> 5;
@@ -1006,8 +1009,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // everything the epilogue reads, requested now: its latency hides behind the K walk.  Buffer loads, not branches: an absent
     // operand is a descriptor of zero bytes (a load inside `if (p.scale)` is followed by its own s_waitcnt vmcnt(0))
     const float wmul = split_wmul(p.WF, p.w_bytes);
-    const auto srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.scale), (short)0, p.scale ? p.N * 4 : 0, 0x00020000);
-    const auto brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), (short)0, p.bias ? p.N * 4 : 0, 0x00020000);
+    const int n_all = p.N * (p.groups > 1 ? p.groups : 1);
+    const auto srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.scale), (short)0, p.scale ? n_all * 4 : 0, 0x00020000);
+    const auto brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), (short)0, p.bias ? n_all * 4 : 0, 0x00020000);
     const auto rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.R), (short)0, p.R ? 0x7ffffff0 : 0, 0x00020000);
     const u32x4_t scv = __builtin_amdgcn_raw_buffer_load_b128(srs, (unsigned)ch * 4u, 0, 0);
     const u32x4_t biv = __builtin_amdgcn_raw_buffer_load_b128(brs, (unsigned)ch * 4u, 0, 0);
@@ -1029,7 +1033,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         const int ox = mm % p.OW, t = mm / p.OW;
         const int oy = t % p.OH, b = t / p.OH;
         const int iy = oy * p.sh - p.ph, ix = ox * p.sw - p.pw;
-        a_off[fm] = ok ? (unsigned)(((long)b * p.sB + (long)iy * p.sH + (long)ix * p.sW + p.coff) * 4) + 16u * g : OOB;
+        a_off[fm] = ok ? (unsigned)(((long)b * p.sB + (long)iy * p.sH + (long)ix * p.sW + p.coff + grp * p.Cin) * 4) + 16u * g : OOB;
         if constexpr (GATHER == 3) {
             a_iy[fm] = ok ? iy : -(1 << 28);
             a_ix[fm] = ix;
@@ -1118,7 +1122,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 
 template <int OUT, int NFM, int D>
 void launch_skinny_t(const GemmParams& p, hipStream_t st) {
-    const dim3 grid(p.N / 16, (p.M + 16 * NFM - 1) / (16 * NFM));
+    const dim3 grid(p.N / 16 * (p.groups > 1 ? p.groups : 1), (p.M + 16 * NFM - 1) / (16 * NFM));
     if (p.fast && p.KH * p.KW == 1) conv_gemm_skinny_kernel<OUT, 0, NFM, D><<<grid, dim3(64), 0, st>>>(p);
     else if (p.fast) conv_gemm_skinny_kernel<OUT, 2, NFM, D><<<grid, dim3(64), 0, st>>>(p);
     else conv_gemm_skinny_kernel<OUT, 3, NFM, D><<<grid, dim3(64), 0, st>>>(p);
@@ -1128,8 +1132,10 @@ void launch_skinny_t(const GemmParams& p, hipStream_t st) {
 template <int OUT>
 void launch_skinny(const GemmParams& p, hipStream_t st) {
     const long simds = (long)p.slots * 2;  // block slots = 2 per CU, 4 SIMDs per CU
-    const long nt = p.N / 16;
-    if (p.tile_m == 16 || (p.tile_m == 0 && (long)((p.M + 15) / 16) * nt <= simds)) launch_skinny_t<OUT, 1, 12>(p, st);
+    // 16-position tiles while they leave half the SIMDs free (latency-bound: the smallest tile wins); past that the launch is
+    // bound by L2 -> L1 bytes (~12 TB/s over the chip) and the 32-position tile moves 6 KiB per K-step where two 16s move 8
+    const long nt = p.N / 16 * (p.groups > 1 ? p.groups : 1);
+    if (p.tile_m == 16 || (p.tile_m == 0 && (long)((p.M + 15) / 16) * nt <= simds / 2)) launch_skinny_t<OUT, 1, 12>(p, st);
     else if (p.tile_m == 32 || (p.tile_m == 0 && (long)((p.M + 31) / 32) * nt <= simds)) launch_skinny_t<OUT, 2, 8>(p, st);
     else launch_skinny_t<OUT, 4, 4>(p, st);
 }
@@ -1277,8 +1283,8 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: tile_m %d (0, 112 or 128; dtype 9 / 10: 0, 16, 32 or 64)", d.tile_m);
     p.tile_m = d.tile_m;
     p.WF = wdirect ? (const char*)w : nullptr;
-    if (skinny && (x2 || groups != 1 || d.cin % 32 || M > 4096))
-        return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d (skinny form) needs one source, one group, cin %% 32 == 0, M <= 4096 (M=%ld)", dtype, M);
+    if (skinny && (x2 || d.cin % 32 || d.n % 32 || M > 4096))
+        return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d (skinny form) needs one source, cin %% 32 == 0, n %% 32 == 0, M <= 4096 (M=%ld)", dtype, M);
     if (wdirect && !skinny && (d.n % 256 || (K / bk) % 2 || groups != 1 || d.tile_n == 64 || d.tile_n == 128))
         return set_err(ctx, AVCER_EINVAL, "conv_gemm: dtype %d needs N %% 256 == 0, an even number of K-steps, one group (N=%d, K=%ld)",
                        dtype, d.n, K);

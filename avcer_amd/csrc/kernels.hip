@@ -644,19 +644,26 @@ __global__ void small_linear_kernel(const float* __restrict__ x, const float* __
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
     // (unrolled: the loads of eight K positions are in flight together -- one row per call is one wave, and 8 dependent
     // round trips per output were the kernel; the adds keep their order)
-#pragma unroll 8
+    // and no load sits behind a branch of its own: `if (j < n) acc[j] += xv * w[..]` made n dependent round trips per K step
+    // (3 us each: 59 us for the audio head's 1024 x 8); rows past n re-read row n - 1 into accumulators nobody uses)
+#pragma unroll 4
     for (int kk = lane; kk < k; kk += 64) {
         float xv = x[(long)row * k + kk];
         if (relu_in) xv = relu_nan(xv);
+        float wv[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if (j < n) acc[j] += xv * w[(long)j * k + kk];
+        for (int j = 0; j < 16; ++j) wv[j] = w[(long)min(j, n - 1) * k + kk];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] += xv * wv[j];
     }
     float mx = -INFINITY;
+    float bj[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bj[j] = b[min(j, n - 1)];
 #pragma unroll
     for (int j = 0; j < 16; ++j)
         if (j < n) {
-            acc[j] = wave_sum(acc[j]) + b[j];
+            acc[j] = wave_sum(acc[j]) + bj[j];
             mx = fmaxf(mx, acc[j]);
         }
     if (lane == 0) {
@@ -707,8 +714,19 @@ __global__ void wav_normalize_kernel(const float* __restrict__ x, float* __restr
     const float* xr = x + (long)blockIdx.x * t;
     float* yr = y + (long)blockIdx.x * t;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+    // (every pass requests eight of a thread's samples before it uses one -- a 4 s window is one block, and 125 dependent
+    // round trips per pass were 90 us; each thread still adds its samples in the same order)
+    constexpr int U = 8;
+    const int bd = blockDim.x;
     float s = 0.f;
-    for (int i = tid; i < t; i += blockDim.x) s += xr[i];
+    for (int i = tid; i < t; i += U * bd) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = xr[min(i + u * bd, t - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i + u * bd < t) s += v[u];
+    }
     s = wave_sum(s);
     if (lane == 0) red[wv] = s;
     __syncthreads();
@@ -716,7 +734,14 @@ __global__ void wav_normalize_kernel(const float* __restrict__ x, float* __restr
     __syncthreads();
     const float mean = bc;
     float q = 0.f;
-    for (int i = tid; i < t; i += blockDim.x) { const float d = xr[i] - mean; q += d * d; }
+    for (int i = tid; i < t; i += U * bd) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = xr[min(i + u * bd, t - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i + u * bd < t) { const float d = v[u] - mean; q += d * d; }
+    }
     q = wave_sum(q);
     __syncthreads();
     if (lane == 0) red[wv] = q;
@@ -724,7 +749,14 @@ __global__ void wav_normalize_kernel(const float* __restrict__ x, float* __restr
     if (tid == 0) { float a = 0.f; for (int i = 0; i < nw; ++i) a += red[i]; bc = sqrtf(a / (float)t + 1e-7f); }
     __syncthreads();
     const float sd = bc;
-    for (int i = tid; i < t; i += blockDim.x) yr[i] = (xr[i] - mean) / sd;
+    for (int i = tid; i < t; i += U * bd) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = xr[min(i + u * bd, t - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i + u * bd < t) yr[i + u * bd] = (v[u] - mean) / sd;
+    }
 }
 
 // wav2vec2 feature-extractor layer 0: Conv1d(1 -> 512, k=10, stride 5, bias) -> LayerNorm(512) -> GELU, fused.

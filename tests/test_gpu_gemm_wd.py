@@ -190,6 +190,35 @@ def test_skinny_subsampled_residual_bit_identical(engine, out_sp32):
     assert (got - ref).abs().max() < 2e-5 * ref.abs().max()
 
 
+@pytest.mark.parametrize("tile_m", [0, 16, 64])
+@pytest.mark.parametrize("out_sp32", [True, False])
+def test_skinny_grouped_bit_identical(engine, out_sp32, tile_m):
+    """The wav2vec2 pos-conv shape (groups of 64 channels, 16 taps, zero padding, GELU then residual) as one skinny launch:
+    the fragment tiles of all groups side by side."""
+    b, s, groups, cin, k = 2, 37, 4, 64, 16
+    ctot = groups * cin
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(b * s, ctot, generator=g)
+    w = torch.randn(ctot, k * cin, generator=g) / (k * cin) ** 0.5
+    bias, res = torch.randn(ctot, generator=g), torch.randn(b * s, ctot, generator=g)
+    d = _desc(batch=b, in_h=s, in_w=1, out_h=s, out_w=1, cin=cin, kh=k, kw=1, pad_h=k // 2, x_stride_b=s * ctot,
+              x_stride_h=ctot, x_stride_w=ctot, n=64, y_ld=ctot, r_ld=ctot, act=2, res_after_act=1, groups=groups)
+    dev = engine.device
+    xd, wd = to_sp32(x).to(dev), w.to(dev).contiguous()
+    rows, frags = engine.split_weight_rows(wd), engine.weight_frags(wd)
+    outs = []
+    for dtype, wt in ((5 if out_sp32 else 6, rows), (9 if out_sp32 else 10, frags)):
+        rd = to_sp32(res).to(dev) if out_sp32 else res.to(dev)
+        y = torch.full((b * s, 2 * ctot) if out_sp32 else (b * s, ctot), -3, dtype=torch.int16 if out_sp32 else torch.float32, device=dev)
+        d.tile_m = tile_m if dtype >= 9 else 0
+        engine.conv_gemm(d, dtype, xd, wt, None, bias.to(dev), rd, y)
+        torch.cuda.synchronize()
+        outs.append(y.cpu())
+    assert torch.equal(outs[0], outs[1])
+    got = from_sp32(outs[1]) if out_sp32 else outs[1]
+    assert torch.isfinite(got).all() and got.abs().max() > 0.1
+
+
 def test_skinny_form_refuses_what_it_cannot_do(engine):
     from avcer_amd._lib import AvcerError
 

@@ -4,6 +4,7 @@ and grid -- where a small batch (BASELINE configs[1]: 256 frames) loses against 
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ts -o t -- python3 tools/trace_static.py run 256
     python3 tools/trace_static.py show gpurun_out/ts
+    ... run 1 audio | run 1 lstm; show <dir> wav_normalize | show <dir> gather_windows  (first kernel of the pass as the marker)
 """
 import csv
 import glob
@@ -14,23 +15,33 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(batch):
+def run(batch, what="static"):
     import torch
     from avcer_amd import synth
     from avcer_amd.engine import MODE_F16X3, Engine
 
     eng = Engine(0)
-    eng.load_static(synth.static_state_dict(42))
-    frames = torch.from_numpy(synth.face_frames(1, batch)).cuda()
+    if what == "audio":   # `batch` windows of 4 s
+        eng.load_audio(synth.audio_state_dict(42))
+        wav = torch.from_numpy(synth.waveforms(5678, batch, 64000)).cuda()
+        call = lambda: eng.audio_forward(wav, True, MODE_F16X3)
+    elif what == "lstm":  # `batch` windows of 10 feature rows
+        eng.load_dynamic(synth.dynamic_state_dict(42))
+        win = torch.randn(batch, 10, 512, device="cuda")
+        call = lambda: eng.dynamic_forward(win, MODE_F16X3)
+    else:
+        eng.load_static(synth.static_state_dict(42))
+        frames = torch.from_numpy(synth.face_frames(1, batch)).cuda()
+        call = lambda: eng.static_forward(frames, MODE_F16X3)
     for _ in range(4):
-        eng.static_forward(frames, MODE_F16X3)
+        call()
         torch.cuda.synchronize()
 
 
-def show(d):
+def show(d, marker="stem_pool"):
     f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-    starts = [i for i, r in enumerate(rows) if "stem_pool" in r["Kernel_Name"]]
+    starts = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
     first = starts[-1]
     t0, total = int(rows[first]["Start_Timestamp"]), 0.0
     for r in rows[first:]:
@@ -44,4 +55,7 @@ def show(d):
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[2]) if len(sys.argv) > 2 else 256) if sys.argv[1] == "run" else show(sys.argv[2])
+    if sys.argv[1] == "run":
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 256, sys.argv[3] if len(sys.argv) > 3 else "static")
+    else:
+        show(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "stem_pool")
