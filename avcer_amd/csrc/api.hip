@@ -851,8 +851,8 @@ static int dynamic_forward_impl(avcer_ctx* ctx, const float* windows, int n, int
     const int x3 = mode == AVCER_MODE_F16X3;
     if (x3) TRY(ensure_all_x3(ctx, ctx->dyn, st));
     constexpr int T = 10, I = 512, H1 = 512, H2 = 256;
-    const size_t total = ((size_t)n * T * 4 * H1 + (size_t)n * 4 * H1 + (size_t)n * T * H1 + (size_t)n * H1 +
-                          (size_t)n * T * 4 * H2 + (size_t)n * H2 * 2) * 4 + 8 * 256;
+    const size_t total = ((size_t)n * T * 4 * H1 + (size_t)n * 4 * H1 + (size_t)n * T * H1 * 2 + (size_t)n * H1 +
+                          (size_t)n * T * 4 * H2 + (size_t)n * H2 * 3) * 4 + 10 * 256;
     void* wsp = nullptr;
     TRY(ws_reserve(ctx, 1, total, &wsp));
     Arena ar(wsp, ctx->ws[1].cap);
@@ -863,22 +863,30 @@ static int dynamic_forward_impl(avcer_ctx* ctx, const float* windows, int n, int
     float* xp2 = (float*)ar.get((size_t)n * T * 4 * H2 * 4);
     float* h2 = (float*)ar.get((size_t)n * H2 * 4);
     float* c2 = (float*)ar.get((size_t)n * H2 * 4);
-    if (!c2) return set_err(ctx, AVCER_ENOMEM, "dynamic workspace arithmetic");
+    // x3 mode: h of both layers once more as sp32 pairs, written by the cell kernel -- the operand of the next step's recurrent
+    // contraction (and of layer 2's input projection), which then runs on the sp32 forms: at a window or a few hundred per call
+    // that is the skinny one (9 us a step where the 128-row tile of the f32-operand form took 22)
+    void* h1s = ar.get((size_t)n * T * H1 * 4);
+    void* h2s = ar.get((size_t)n * H2 * 4);
+    if (!h2s) return set_err(ctx, AVCER_ENOMEM, "dynamic workspace arithmetic");
+    const int ak = x3 ? 2 : 0;
     Net net{ctx, ctx->dyn, 0, st, x3};
     net.gemm(linear_desc((long)n * T, I, 4 * H1, 0), "lstm1.wih.w", nullptr, net.F("lstm1.b"), windows, nullptr, xp1, 0, 0);
     for (int t = 0; t < T; ++t) {
         if (t > 0) {
             avcer_conv_desc d = linear_desc(n, H1, 4 * H1, 0);
             d.x_stride_b = (int64_t)T * H1;  // rows of h_{t-1} inside the [n, T, H1] sequence buffer
-            net.gemm(d, "lstm1.whh.w", nullptr, nullptr, h1 + (size_t)(t - 1) * H1, nullptr, hp, 0, 0);
+            const void* hprev = x3 ? (const void*)((const char*)h1s + (size_t)(t - 1) * H1 * 4) : (const void*)(h1 + (size_t)(t - 1) * H1);
+            net.gemm(d, "lstm1.whh.w", nullptr, nullptr, hprev, nullptr, hp, ak, 0);
         }
         net.chk(k_lstm_cell(ctx, xp1 + (size_t)t * 4 * H1, (int64_t)T * 4 * H1, hp, c1, h1 + (size_t)t * H1,
-                            (int64_t)T * H1, n, H1, t == 0, st));
+                            x3 ? (char*)h1s + (size_t)t * H1 * 4 : nullptr, (int64_t)T * H1, n, H1, t == 0, st));
     }
-    net.gemm(linear_desc((long)n * T, H1, 4 * H2, 0), "lstm2.wih.w", nullptr, net.F("lstm2.b"), h1, nullptr, xp2, 0, 0);
+    net.gemm(linear_desc((long)n * T, H1, 4 * H2, 0), "lstm2.wih.w", nullptr, net.F("lstm2.b"), x3 ? h1s : (const void*)h1, nullptr,
+             xp2, ak, 0);
     for (int t = 0; t < T; ++t) {
-        if (t > 0) net.gemm(linear_desc(n, H2, 4 * H2, 0), "lstm2.whh.w", nullptr, nullptr, h2, nullptr, hp, 0, 0);
-        net.chk(k_lstm_cell(ctx, xp2 + (size_t)t * 4 * H2, (int64_t)T * 4 * H2, hp, c2, h2, H2, n, H2, t == 0, st));
+        if (t > 0) net.gemm(linear_desc(n, H2, 4 * H2, 0), "lstm2.whh.w", nullptr, nullptr, x3 ? h2s : (const void*)h2, nullptr, hp, ak, 0);
+        net.chk(k_lstm_cell(ctx, xp2 + (size_t)t * 4 * H2, (int64_t)T * 4 * H2, hp, c2, h2, x3 ? h2s : nullptr, H2, n, H2, t == 0, st));
     }
     net.chk(k_small_linear(ctx, h2, net.F("fc.w"), net.F("fc.b"), logits, nullptr, n, H2, 7, 0, st));
     return net.err;

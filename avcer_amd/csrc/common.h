@@ -91,7 +91,7 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
                      const void* x2 = nullptr);
 
 // kernel families of the MFMA launches (avcer_profile_read_families; include/avcer_hip.h AVCER_FAM_*)
-enum { FAM_GEMM = 0, FAM_GEMM_WD = 1, FAM_CHAIN = 2, FAM_TAIL = 3, FAM_STEM = 4, FAM_COUNT = 5 };
+enum { FAM_GEMM = 0, FAM_GEMM_WD = 1, FAM_CHAIN = 2, FAM_TAIL = 3, FAM_STEM = 4, FAM_SKINNY = 5, FAM_COUNT = 6 };
 // `flops` / `bytes`: algorithmic work and compulsory HBM traffic of the launch (operands read once + outputs written once)
 int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1, int family, double flops, double bytes);
 
@@ -134,7 +134,7 @@ int k_maxpool3s2(avcer_ctx*, const void* x, void* y, int n, int h, int w, int c,
 int k_avgpool_hw(avcer_ctx*, const void* x, float* y, void* y_sp32, int n, int hw, int c, int kind, hipStream_t);
 int k_small_linear(avcer_ctx*, const float* x, const float* w, const float* b, float* logits, float* probs, int m,
                    int k, int n, int relu_in, hipStream_t);
-int k_lstm_cell(avcer_ctx*, const float* xproj, int64_t xproj_ld, const float* hproj, float* c, float* h_out,
+int k_lstm_cell(avcer_ctx*, const float* xproj, int64_t xproj_ld, const float* hproj, float* c, float* h_out, void* h_sp,
                 int64_t h_ld, int n, int hid, int first, hipStream_t);
 int k_wav_normalize(avcer_ctx*, const float* x, float* y, int n, int t, hipStream_t);
 int k_conv0_ln_gelu(avcer_ctx*, const float* x, const float* w, const float* b, const float* g, const float* beta,

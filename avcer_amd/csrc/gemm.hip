@@ -1301,7 +1301,7 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
         // compulsory traffic: the input once (each position's taps overlap), the weights once, the output (+ residual) once
         const double in_el = (double)d.batch * d.in_h * d.in_w * d.cin * groups + (x2 ? (double)M * d.x2_cin : 0.0);
         const double bytes = in_el * es + (double)w_extent + (double)M * d.n * groups * (dtype == 1 ? 2 : 4) * (residual ? 2 : 1);
-        TRY(prof_begin(ctx, st, &ev0, &ev1, wdirect ? FAM_GEMM_WD : FAM_GEMM, 2.0 * (double)M * (double)d.n * (double)K * groups, bytes));
+        TRY(prof_begin(ctx, st, &ev0, &ev1, skinny ? FAM_SKINNY : wdirect ? FAM_GEMM_WD : FAM_GEMM, 2.0 * (double)M * (double)d.n * (double)K * groups, bytes));
     }
     switch (dtype) {
         case 0: launch_t<0, 0>(p, st); break;  // f32

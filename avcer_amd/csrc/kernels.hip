@@ -686,8 +686,10 @@ __global__ void small_linear_kernel(const float* __restrict__ x, const float* __
 // ------------------------------------------------------------------------------------------------ LSTM cell
 // torch.nn.LSTM cell (video.py:173-178), gate order i,f,g,o.  xproj already holds x W_ih^T + b_ih + b_hh.
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// h_sp: h once more as sp32 pairs (same row stride), the operand of the next step's recurrent contraction in the x3 mode
 __global__ void lstm_cell_kernel(const float* __restrict__ xproj, long xproj_ld, const float* __restrict__ hproj,
-                                 float* __restrict__ c, float* __restrict__ h_out, long h_ld, int n, int hid, int first) {
+                                 float* __restrict__ c, float* __restrict__ h_out, sp32_t* __restrict__ h_sp, long h_ld, int n,
+                                 int hid, int first, unsigned* ovf) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)n * hid) return;
     const int j = idx % hid;
@@ -702,7 +704,9 @@ __global__ void lstm_cell_kernel(const float* __restrict__ xproj, long xproj_ld,
     }
     const float cn = sigmoidf_(gf) * cp + sigmoidf_(gi) * tanhf(gg);
     c[idx] = cn;
-    h_out[(long)r * h_ld + j] = sigmoidf_(go) * tanhf(cn);
+    const float hn = sigmoidf_(go) * tanhf(cn);
+    h_out[(long)r * h_ld + j] = hn;
+    if (h_sp) stf<sp32_t>(h_sp, (long)r * h_ld + j, hn, ovf);
 }
 
 // ------------------------------------------------------------------------------------------------ audio front end
@@ -1466,9 +1470,11 @@ int k_small_linear(avcer_ctx* ctx, const float* x, const float* w, const float* 
     return AVCER_OK;
 }
 
-int k_lstm_cell(avcer_ctx* ctx, const float* xproj, int64_t xproj_ld, const float* hproj, float* c, float* h_out,
+int k_lstm_cell(avcer_ctx* ctx, const float* xproj, int64_t xproj_ld, const float* hproj, float* c, float* h_out, void* h_sp,
                 int64_t h_ld, int n, int hid, int first, hipStream_t st) {
-    lstm_cell_kernel<<<cdiv((long)n * hid, 256), 256, 0, st>>>(xproj, xproj_ld, hproj, c, h_out, h_ld, n, hid, first);
+    if (h_sp && h_ld % 32) return set_err(ctx, AVCER_EINVAL, "lstm_cell: sp32 rows need a stride in whole groups of 32");
+    lstm_cell_kernel<<<cdiv((long)n * hid, 256), 256, 0, st>>>(xproj, xproj_ld, hproj, c, h_out, (sp32_t*)h_sp, h_ld, n, hid, first,
+                                                               ctx->ovf);
     CHECK_LAUNCH(ctx, "lstm_cell");
     return AVCER_OK;
 }

@@ -295,7 +295,8 @@ class Engine:
         self._check(self.lib.avcer_profile_read(self.ctx, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
-    FAMILIES = ("conv_gemm_kernel", "conv_gemm_wd_kernel", "bneck_kernel", "bneck_tail2_kernel", "stem_pool_kernel")  # AVCER_FAM_*
+    FAMILIES = ("conv_gemm_kernel", "conv_gemm_wd_kernel", "bneck_kernel", "bneck_tail2_kernel", "stem_pool_kernel",
+                "conv_gemm_skinny_kernel")  # AVCER_FAM_*
 
     def profile_read_families(self):
         """Per kernel family since profile_enable / the last read: {name: (event ms, launches, algorithmic FLOPs, compulsory

@@ -59,9 +59,9 @@ DTYPE = {"fp32": "f32", "bf16": "bf16", "x3": "f16x3 (f16 MFMA on hi/lo-split f3
 # what roofline.achieved aggregates: every MFMA kernel family of the step (roofline.per_family prices each one on its own)
 KERNEL = {"fp32": "all MFMA launches of a step: conv_gemm_kernel<0,0,*>",
           "bf16": "all MFMA launches of a step: conv_gemm_kernel<1,*,*>",
-          "x3": "all MFMA launches of a step, five families: conv_gemm_wd_kernel<*,*,*> (weights direct, about half of the time), "
+          "x3": "all MFMA launches of a step, six families: conv_gemm_wd_kernel<*,*,*> (weights direct, about half of the time), "
                 "bneck_kernel<*> (fused bottleneck chains, HBM-bound), bneck_tail2_kernel<256>, conv_gemm_kernel<3|2,*,*>, "
-                "stem_pool_u8_kernel -- see roofline.per_family"}
+                "stem_pool_u8_kernel, conv_gemm_skinny_kernel<*> (launches of few positions: the LSTM steps) -- see roofline.per_family"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.2-6.3 TB/s measured for a streaming copy)
 FAMILY_BOUND = {"bneck_kernel": "hbm"}  # every other family is priced against the MFMA peak
 

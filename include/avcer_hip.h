@@ -346,7 +346,8 @@ enum {
     AVCER_FAM_CHAIN = 2,   /* bneck_kernel: fused bottleneck chains of ResNet stages 1-2 (HBM-bound) */
     AVCER_FAM_TAIL = 3,    /* bneck_tail2_kernel: conv3 + residual + next conv1 of stage 3 */
     AVCER_FAM_STEM = 4,    /* stem_pool(_u8)_kernel */
-    AVCER_FAM_COUNT = 5
+    AVCER_FAM_SKINNY = 5,  /* conv_gemm_skinny_kernel: one wave per tile, registers only (dtype 9 / 10; launches of few positions) */
+    AVCER_FAM_COUNT = 6
 };
 int avcer_profile_read_families(avcer_ctx* ctx, int n_fam, double* ms, int64_t* launches, double* flops, double* bytes);
 

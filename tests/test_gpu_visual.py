@@ -201,3 +201,17 @@ def test_lstm_split_bf16_mode(engine, sd_dynamic, golden):
     d = np.abs(out - golden("lstm")["logits"]).max()
     print("lstm x3 max|dlogit|", d)
     assert d < 2e-5  # measured 1.8e-6
+
+
+def test_lstm_one_window_matches_its_row_in_a_batch_x3(engine, sd_dynamic):
+    """A window per call (the drop-in mirror) runs its recurrent contractions on the skinny form, a few thousand windows on the
+    tiled ones: the same bits for the same window either way."""
+    from avcer_amd.engine import MODE_F16X3
+    engine.load_dynamic(sd_dynamic)
+    g = torch.Generator().manual_seed(3)
+    w = torch.relu(torch.randn(3000, 10, 512, generator=g))
+    big = engine.dynamic_forward(w, MODE_F16X3).cpu()
+    for lo, hi in ((0, 1), (17, 22), (2000, 2300)):
+        part = engine.dynamic_forward(w[lo:hi], MODE_F16X3).cpu()
+        assert torch.equal(big[lo:hi], part), (lo, hi)
+    assert torch.isfinite(big).all()
