@@ -938,7 +938,7 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
     const size_t rows = (size_t)NB * S;
     const size_t e0 = (size_t)NB * len[1] * C * es, e1 = (size_t)NB * len[2] * C * es;
     const size_t total = (size_t)NB * t * 4 + e0 + 2 * e1 + rows * E * 4 * 4 + rows * E * es * 2 + rows * 3 * E * es +
-                         rows * FF * es + rows * E * es + (size_t)NB * (L1 + L2 + L3 + 1) * E * 4 + 32 * 256;
+                         rows * FF * es + rows * E * es + (size_t)NB * (L1 + 2 * L2 + L3 + 1) * E * 4 + 34 * 256;
     void* wsp = nullptr;
     TRY(ws_reserve(ctx, 2, total, &wsp));
     Arena ar(wsp, ctx->ws[2].cap);
@@ -957,6 +957,7 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
     void* ATT = ar.get(rows * E * es);
     float* c1o = (float*)ar.get((size_t)NB * L1 * E * 4);
     float* mp = (float*)ar.get((size_t)NB * L2 * E * 4);
+    void* mps = ar.get((size_t)NB * L2 * E * 4);  // x3 mode: the pooled head activations as sp32 pairs (td4's operand)
     float* c2o = (float*)ar.get((size_t)NB * L3 * E * 4);
     float* pooled = (float*)ar.get((size_t)NB * E * 4);
     if (!pooled) return set_err(ctx, AVCER_ENOMEM, "audio workspace arithmetic");
@@ -1055,9 +1056,9 @@ extern "C" int avcer_audio_forward(avcer_ctx* ctx, const float* wav, int n, int 
         // ---- head: Conv1d k5 s3 dil2 + BN -> MaxPool(5) -> ReLU -> Conv1d k3 + BN -> mean -> ReLU -> Linear
         net.gemm(conv1d_desc(nb, S, E, 5, 3, 0, 2, L1, E, 0), "td0.w", net.F("td0.s"), net.F("td0.b"),
                  act ? Xb : (void*)Xf, nullptr, c1o, act, 0);
-        net.chk(k_maxpool1d_relu(ctx, c1o, mp, nb, L1, L2, E, 5, st));
-        net.gemm(conv1d_desc(nb, L2, E, 3, 1, 0, 1, L3, E, 0), "td4.w", net.F("td4.s"), net.F("td4.b"), mp, nullptr, c2o,
-                 0, 0);
+        net.chk(k_maxpool1d_relu(ctx, c1o, mp, net.x3 ? mps : nullptr, nb, L1, L2, E, 5, st));
+        net.gemm(conv1d_desc(nb, L2, E, 3, 1, 0, 1, L3, E, 0), "td4.w", net.F("td4.s"), net.F("td4.b"), net.x3 ? mps : (const void*)mp,
+                 nullptr, c2o, net.x3 ? 2 : 0, 0);
         net.tap("td0", c1o, (size_t)nb * L1 * E * 4);
         net.tap("mp", mp, (size_t)nb * L2 * E * 4);
         net.tap("td4", c2o, (size_t)nb * L3 * E * 4);

@@ -144,7 +144,7 @@ int k_layernorm(avcer_ctx*, const void* x, const void* res, const float* g, cons
 int k_add_pe(avcer_ctx*, const float* x, const float* pe, float* yf, void* yb, int n, int s, int c, int yb_kind, hipStream_t);
 int k_attention(avcer_ctx*, const void* qkv, void* out, int n, int s, int heads, int d, float scale, int in_kind,
                 int out_kind, hipStream_t);
-int k_maxpool1d_relu(avcer_ctx*, const float* x, float* y, int n, int t_in, int t_out, int c, int k, hipStream_t);
+int k_maxpool1d_relu(avcer_ctx*, const float* x, float* y, void* y_sp32, int n, int t_in, int t_out, int c, int k, hipStream_t);
 int k_mean_time_relu(avcer_ctx*, const float* x, float* y, int n, int t, int c, hipStream_t);
 int k_f32_to_bf16(avcer_ctx*, const float* x, bf16_t* y, size_t n, hipStream_t);
 int k_frame_mean(avcer_ctx*, const float* win_logits, const int32_t* lo, const int32_t* hi, int n_win, int c,

@@ -1195,8 +1195,9 @@ __global__ void __launch_bounds__(64 * ATTM_WAVES) attention_mfma_kernel(const T
 
 // ------------------------------------------------------------------------------------------------ audio head
 // audio_8_cl.py:151-152: MaxPool1d(5) (stride 5, floor) then ReLU over time of [n, t_in, c].
-__global__ void maxpool1d_relu_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int t_in, int t_out,
-                                      int c, int k) {
+// ysp: the same values once more as sp32 pairs (the operand of the head's second convolution in the x3 mode)
+__global__ void maxpool1d_relu_kernel(const float* __restrict__ x, float* __restrict__ y, sp32_t* __restrict__ ysp, int n, int t_in,
+                                      int t_out, int c, int k, unsigned* ovf) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)n * t_out * c) return;
     const int cc = idx % c;
@@ -1209,7 +1210,9 @@ __global__ void maxpool1d_relu_kernel(const float* __restrict__ x, float* __rest
         m = fmaxf(m, v);
         nan |= v != v;
     }
-    y[idx] = nan ? NAN : relu_nan(m);
+    const float r = nan ? NAN : relu_nan(m);
+    y[idx] = r;
+    if (ysp) stf<sp32_t>(ysp, idx, r, ovf);
 }
 
 // audio_8_cl.py:155-156: AdaptiveAvgPool1d(1) then ReLU: [n, t, c] -> [n, c]
@@ -1588,8 +1591,9 @@ int k_attention(avcer_ctx* ctx, const void* qkv, void* out, int n, int s, int he
     return AVCER_OK;
 }
 
-int k_maxpool1d_relu(avcer_ctx* ctx, const float* x, float* y, int n, int t_in, int t_out, int c, int k, hipStream_t st) {
-    maxpool1d_relu_kernel<<<cdiv((long)n * t_out * c, 256), 256, 0, st>>>(x, y, n, t_in, t_out, c, k);
+int k_maxpool1d_relu(avcer_ctx* ctx, const float* x, float* y, void* y_sp32, int n, int t_in, int t_out, int c, int k, hipStream_t st) {
+    if (y_sp32 && c % 32) return set_err(ctx, AVCER_EINVAL, "maxpool1d_relu: sp32 rows need c in whole groups of 32");
+    maxpool1d_relu_kernel<<<cdiv((long)n * t_out * c, 256), 256, 0, st>>>(x, y, (sp32_t*)y_sp32, n, t_in, t_out, c, k, ctx->ovf);
     CHECK_LAUNCH(ctx, "maxpool1d_relu");
     return AVCER_OK;
 }

@@ -160,6 +160,19 @@ def test_audio_batch_invariance_128(engine_audio):
     assert torch.isfinite(big).all()
 
 
+@pytest.mark.parametrize("seconds", [2, 4])
+def test_audio_one_window_matches_its_row_in_a_batch_x3(engine_audio, seconds):
+    """A window per call (the drop-in mirror) runs most of its contractions on the skinny form (conv_gemm dtype 9 / 10: the deep
+    extractor layers, pos-conv as one grouped launch, out-proj, ffn2, the head), 40 windows on the tiled ones: the same bits
+    for the same window."""
+    wav = torch.from_numpy(synth.waveforms(9, 40, 16000 * seconds))
+    big = engine_audio.audio_forward(wav, True, MODE_F16X3).cpu()
+    for lo, hi in ((0, 1), (11, 14)):
+        part = engine_audio.audio_forward(wav[lo:hi], True, MODE_F16X3).cpu()
+        assert torch.equal(big[lo:hi], part), (lo, hi)
+    assert torch.isfinite(big).all()
+
+
 def test_seven_class_variant(engine, golden):
     """Row f3: the 7-class ExprModelV2 weights load through the same packer/kernels (n_classes comes from the blob)."""
     from avcer_amd.engine import Engine
