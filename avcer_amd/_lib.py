@@ -78,7 +78,7 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
     "avcer_face_nms": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float,
                                  C.c_void_p, C.c_void_p, c_stream]),
-    "avcer_bneck_chain": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8 +
+    "avcer_bneck_chain": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 9 +
                           [c_stream]),
     "avcer_stem_pool": (C.c_int, [c_ctx, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_stream]),
     "avcer_stem_pool_u8": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -557,7 +557,7 @@ static int static_forward_impl(avcer_ctx* ctx, const uint8_t* frames, const floa
                 }
                 net.chk(launch_bneck(ctx, planes, nb, h, h, T1, X, first ? cin : 0, sub, dst, next ? T2 : nullptr, w2->x3,
                                      net.F(p + "c2.b"), w3->x3, net.F(first ? p + "c3d.b" : p + "c3.b"), next ? w1n->x3 : nullptr,
-                                     next ? net.F(pn + "c1.b") : nullptr, st));
+                                     next ? net.F(pn + "c1.b") : nullptr, st, w2->x3f));
                 std::swap(T1, T2);  // the next block's T1 was written into T2
                 if (dst == OUT) std::swap(X, OUT);
                 else X = dst;
@@ -1213,11 +1213,11 @@ extern "C" int avcer_conv_gemm_dual(avcer_ctx* ctx, const avcer_conv_desc* d, in
 
 extern "C" int avcer_bneck_chain(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin,
                                  int out_step, void* out, void* t1n, const void* w2, const float* b2, const void* w3, const float* b3,
-                                 const void* w1n, const float* b1n, avcer_stream_t stream) {
+                                 const void* w1n, const float* b1n, const void* w2_frags, avcer_stream_t stream) {
     if (!ctx) return AVCER_EINVAL;
     if (nb <= 0 || h <= 0 || w <= 0) return set_err(ctx, AVCER_EINVAL, "bneck_chain: bad geometry");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return launch_bneck(ctx, planes, nb, h, w, t1, x, ds_cin, out_step, out, t1n, w2, b2, w3, b3, w1n, b1n, (hipStream_t)stream);
+    return launch_bneck(ctx, planes, nb, h, w, t1, x, ds_cin, out_step, out, t1n, w2, b2, w3, b3, w1n, b1n, (hipStream_t)stream, w2_frags);
 }
 
 extern "C" int avcer_stem_pool(avcer_ctx* ctx, const void* planes_hi_lo, size_t plane_bytes, const void* w, const float* scale,

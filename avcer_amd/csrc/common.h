@@ -117,9 +117,11 @@ inline double grid_rounds(long tiles, long slots) {
     return (double)whole + (rest == 0 ? 0.0 : (2 * rest <= slots ? 0.25 + 0.7 * f : 1.0));
 }
 
+// w2_frags: the conv2 weights once more in MFMA fragment order (k_weight_frags), or null: selects the spatial-tile form
+// where it applies (planes 64, 55 x 55 images, a next conv1)
 int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, int out_step,
                  void* out, void* t1n, const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n,
-                 const float* b1n, hipStream_t st);
+                 const float* b1n, hipStream_t st, const void* w2_frags = nullptr);
 
 // conv3 + residual + ReLU of a planes-256 bottleneck and conv1 of the next block in one launch (t2 = conv2 output [M][256])
 int launch_bneck_tail(avcer_ctx* ctx, int planes, long M, const void* t2, const void* x, void* out, void* t1n, const void* w3,

@@ -18,6 +18,8 @@
 #include "common.h"
 #include "gemm_dev.h"
 
+#include <algorithm>
+
 namespace {
 
 // a.w ~= ah.wh + ah.wl + al.wh on the f16 MFMA with f32 accumulation (same product order as conv_gemm MODE 3)
@@ -441,6 +443,7 @@ struct BneckParams {
     char* OUT;          // sp32 [M][4P]
     char* T1N;          // sp32 [M][P]: conv1 output of the NEXT block (null when there is none)
     const char* W2;     // [P][9P] split, rows permuted, BN scale folded into the rows
+    const char* W2F;    // the same in MFMA fragment order (avcer_weight_frags): the T11 form loads it straight into registers
     const char* W3;     // [4P][P] split, rows permuted, BN scale folded
     const char* W1N;    // [P][4P] split, rows permuted, BN scale folded (next block's conv1)
     const float *b2, *b3, *b1n;  // folded BN shifts, natural channel order
@@ -448,6 +451,7 @@ struct BneckParams {
     int M, H, Wd;       // M = nb * H * Wd positions (SUB > 1: nb * OH * OW, see bneck_kernel)
     int OH, OW;         // SUB > 1: the output grid, position (oy, ox) <-> input position (SUB oy, SUB ox)
     unsigned* ovf;      // the context's range-contract counter (split_dev.h sp_commit)
+    int nblocks;        // logical blocks (tiles); the grid may be smaller: a block then walks tiles blockIdx.x, + gridDim.x, ...
 };
 
 // BM positions per block, 4 waves, each wave owns BM/4 positions and ALL channels (so that a position's whole T2 /
@@ -471,28 +475,56 @@ struct BneckParams {
 // grids (the 3x3 taps of an even position touch odd ones; the residual is picked at the even position).  A quarter of the
 // conv2 / conv3 products, of the residual reads and of the output bytes; every value written is the one the full-
 // resolution evaluation would have put at that position.
-template <int P, int BM, bool NEXT, int NQX, bool PATCH, int SUB = 1>
+//
+// T11 (round 5; planes 64 on the 55 x 55 images of stage 1): in-kernel stamps (tools/clock_lab.py,
+// profiles/r05_inkernel_clock_shares.txt) put 48 % of a block's residency into the conv2 loop -- 18 K-steps of 24 MFMAs per
+// wave, each waiting 1.7 us for its own LDS-DMA tile behind the other blocks' HBM streams -- and 32 % into the streaming loop.
+// Here a block is an 11 x 11 SPATIAL tile of one image (25 tiles per image, 121 of 128 rows used): its 13 x 13 halo patch
+// of T1 (both 32-channel chunks, 44 KiB: three blocks still share a CU) is copied to LDS ONCE, a tap is a constant slot
+// offset on the fragment reads, and the conv2 weights never touch LDS: every wave loads its W2 fragments (fragment-order
+// copy, 1 KiB per load, L2-resident) straight into registers two K-steps ahead.  After the patch barrier the conv2 phase has
+// no barrier, no DMA and no wait on HBM.  Same K order (tap, channel chunk) as the gather form: bit-identical results.
+template <int P, int BM, bool NEXT, int NQX, bool PATCH, int SUB = 1, bool T11 = false>
 __global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const BneckParams p) {
     static_assert(SUB == 1 || (SUB == 2 && !NEXT && NQX == 0 && !PATCH), "the strided form is the plain last block of a stage");
+    static_assert(!T11 || (P == 64 && BM == 128 && !PATCH && SUB == 1), "the spatial-tile form serves planes 64 at full resolution");
     constexpr int NQ = P / 32;            // K-steps of a P-channel contraction
     constexpr int NQT = NQ + NQX;         // K-steps of conv3 (+ downsample)
     constexpr int PSLOTS = PATCH ? (P == 64 ? 456 : 304) : 0;  // patch slots (x 128 B): 10 rows x 30 (28x28); 8 x 57 would serve 55x55
+    constexpr int T11_E = 11, T11_PW = T11_E + 2, T11_SLOTS = 176;  // tile edge, patch edge, patch slots per chunk plane (169 used: 22 DMA pieces)
     constexpr int NT = BM / 64;           // 16-position tiles per wave
     constexpr int NG = 4 * P / 32;        // 32-channel groups of the block output
     constexpr int TILE_A = (BM + P) * ROWB;
     constexpr int TILE_B = (32 * NQT + P) * ROWB;
-    constexpr int PHASE_A = PATCH ? PSLOTS * ROWB + 2 * P * ROWB : 2 * TILE_A;  // patch + two weight tiles, or two full stages
+    constexpr int PHASE_A = T11 ? NQ * T11_SLOTS * ROWB : (PATCH ? PSLOTS * ROWB + 2 * P * ROWB : 2 * TILE_A);  // patch (+ two weight tiles), or two full stages
     constexpr int TILES = PHASE_A > 2 * TILE_B ? PHASE_A : 2 * TILE_B;
     constexpr int NBIAS = 6 * P;  // b2 [P], b1n [P], b3 [4P]: read back as broadcast float4 pairs in the epilogues
     __shared__ __attribute__((aligned(16))) char smem[TILES + NBIAS * 4];
     float* sbias = reinterpret_cast<float*>(smem + TILES);
     for (int i = threadIdx.x; i < NBIAS; i += 256)
         sbias[i] = i < P ? p.b2[i] : (i < 2 * P ? (NEXT ? p.b1n[i - P] : 0.f) : p.b3[i - 2 * P]);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    sp_flags_t ovm = 0;  // lanes that split a finite |x| >= 65520 into an fp16 pair (split_dev.h sp_commit)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
     const int lrow8 = lane >> 3, slot = lane & 7;
-    const int m_base = xcd_remap(blockIdx.x, gridDim.x) * BM;
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int m_base = blk * BM;  // linear forms: first position of the block
+    // T11: image and tile origin of this block; row r of the block <-> tile position (r / 11, r % 11), rows 121..127 idle
+    const int t11_b = T11 ? blk / 25 : 0, t11_y0 = T11 ? ((blk % 25) / 5) * T11_E : 0, t11_x0 = T11 ? (blk % 5) * T11_E : 0;
+    // block row -> position index of the [nb][H][Wd] grid (clamped to a valid one where the row is idle / past M)
+    auto row_pos = [&](int r, bool& ok) -> int {
+        if constexpr (T11) {
+            ok = r < T11_E * T11_E;
+            const int rr = ok ? r : T11_E * T11_E - 1;
+            const int ry = rr / T11_E, rx = rr - ry * T11_E;
+            return (t11_b * 55 + t11_y0 + ry) * 55 + t11_x0 + rx;
+        } else {
+            const long m = (long)m_base + r;
+            ok = m < p.M;
+            return ok ? (int)m : 0;
+        }
+    };
 
     // accumulator multipliers of the three scaled weight splits (trailers behind the matrices: split_dev.h)
     const float s2 = split_wmul(p.W2, P * 9 * P * 4), s3 = split_wmul(p.W3, 4 * P * (P + 32 * NQX) * 4);
@@ -517,7 +549,116 @@ __global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const Bneck
     for (int i = 0; i < P / 16; ++i)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc2[i][t] = f32x4_t{0};
-    if constexpr (PATCH) {
+    spx8_t t2h[NQ][NT], t2l[NQ][NT];  // T2 as the B operand of conv3 (filled behind phase A)
+    if constexpr (T11) {
+        // ---- the halo patch: slot sl = py * 13 + px <-> image position (y0 - 1 + py, x0 - 1 + px); one plane per 32-channel chunk
+        constexpr int PIECES = T11_SLOTS / 8;  // 22 DMA pieces of 8 slots per plane
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int i = 0; i < (PIECES + 3) / 4; ++i) {
+                const int ii = wave + 4 * i;
+                const int sl = ii * 8 + lrow8;
+                const int py = sl / T11_PW, px = sl - py * T11_PW;
+                const int y = t11_y0 - 1 + py, x = t11_x0 - 1 + px;
+                const bool ok = sl < T11_PW * T11_PW && (unsigned)y < 55u && (unsigned)x < 55u;
+                const unsigned off = ok ? (unsigned)(((t11_b * 55 + y) * 55 + x) * (P * 4) + q * ROWB + ((slot ^ swz_key(sl)) << 4)) : OOB;
+                if (ii < PIECES) dma16(t1rs, smem + q * (T11_SLOTS * ROWB) + ii * 1024, off);
+            }
+        // ---- conv2, CHANNEL-split across the waves: wave w owns output-channel tile w (16 stored rows of W2) for ALL 128 rows of
+        // the block.  Its weight fragments (fragment-order copy: tile i, K-step ks, hi | lo = 1 KiB at ((i * 18 + ks) * 2 + hl) *
+        // 1024, lane * 16 inside) go straight into a four-slot register ring three K-steps ahead -- every byte of W2 enters the CU
+        // once per block (the first spatial-tile form had each wave own 32 positions x all 64 channels: every wave loaded all of
+        // W2, 588 KB per block through the L2 -> CU path that bounds this kernel, and was no faster for it).  Loaded by inline
+        // asm: left to itself hipcc sinks every load next to its use and the loop waits an L2 round trip per step; the counted
+        // waits name the registers they release, nothing else of this wave is in flight here (the patch DMA was drained at the
+        // barrier).  tools/audit_asm_loads.py walks this kernel's ISA too.  The activation fragments of all eight position
+        // tiles come from the patch (a tap = a constant slot offset).
+        constexpr int NKS = 9 * NQ, RING = 4, NPT = BM / 16;
+        const unsigned lane16 = (unsigned)lane * 16u;
+        const char* w2f = p.W2F + (size_t)wave * (NKS * 2048);
+        u32x4_t wq[RING][2];
+#define AVCER_T11_LOAD(KS)                                                                                              \
+    do {                                                                                                                \
+        const char* a_ = w2f + (size_t)(KS) * 2048;                                                                     \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wq[(KS) % RING][0]) : "v"(lane16), "s"(a_) : "memory");    \
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(wq[(KS) % RING][1]) : "v"(lane16), "s"(a_) : "memory"); \
+    } while (0)
+#define AVCER_T11_WAIT(N, KS) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(wq[(KS) % RING][0]), "+v"(wq[(KS) % RING][1]) :: "memory")
+        static_assert(P == 64, "four waves, four channel tiles");
+        int sb8[NPT];  // patch slot of this lane's position in each of the block's eight position tiles, at tap (0, 0)
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) {
+            const int r = min(t * 16 + l15, T11_E * T11_E - 1);
+            const int ry = r / T11_E, rx = r - ry * T11_E;
+            sb8[t] = (ry + 1) * T11_PW + rx + 1;
+        }
+        f32x4_t acc2c[NPT];
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) acc2c[t] = f32x4_t{0};
+        __syncthreads();  // the patch has landed (hipcc drains the DMA in front of the barrier) and the bias table is written
+        AVCER_T11_LOAD(0);
+        AVCER_T11_LOAD(1);
+        AVCER_T11_LOAD(2);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 3 < NKS) { AVCER_T11_LOAD(ks + 3); }
+            const int tap = ks / NQ, q = ks % NQ;
+            const int toff = (tap / 3 - 1) * T11_PW + (tap % 3 - 1);
+            const char* plane = smem + q * (T11_SLOTS * ROWB);
+            // the fragments of step ks are in their registers; the loads of up to three later steps may fly
+            if (ks + 3 < NKS) AVCER_T11_WAIT(6, ks);
+            else if (ks + 2 < NKS) AVCER_T11_WAIT(4, ks);
+            else if (ks + 1 < NKS) AVCER_T11_WAIT(2, ks);
+            else AVCER_T11_WAIT(0, ks);
+            __builtin_amdgcn_sched_barrier(0);
+            const spx8_t wh = __builtin_bit_cast(spx8_t, wq[ks % RING][0]), wl = __builtin_bit_cast(spx8_t, wq[ks % RING][1]);
+#pragma unroll
+            for (int t = 0; t < NPT; ++t) {
+                const spx8_t ah = ldfrag(plane, sb8[t] + toff, g), al = ldfrag(plane, sb8[t] + toff, 4 + g);
+                mfma3(acc2c[t], wh, wl, ah, al);
+            }
+        }
+#undef AVCER_T11_LOAD
+#undef AVCER_T11_WAIT
+        pin(acc2c);
+        __syncthreads();  // every wave is done with the patch
+        // ---- T2 = relu(bn2(.)) of this wave's 16 channels x 128 rows -> LDS as sp32 rows (two 32-channel planes of 128 rows, the
+        // fragment layout and swizzle of every other tile here); each wave then reads the B fragments of ITS 32 rows back.
+        // Stored row 16 t + 4 g + r of a 32-channel group is channel 8 g + 4 t + r: lane group g of tile (wave & 1) holds
+        // channels 8 g + 4 (wave & 1) .. + 3 of group wave >> 1 -- half of the 16-byte piece lane group g reads back.
+        {
+            const int qw = wave >> 1, half = wave & 1;
+            const float4 b4 = *reinterpret_cast<const float4*>(sbias + 32 * qw + 8 * g + 4 * half);
+            char* t2p = smem + qw * (BM * ROWB);
+#pragma unroll
+            for (int t = 0; t < NPT; ++t) {
+                const f32x4_t a4 = acc2c[t];
+                const float x0 = sp_value(relu_nan(__builtin_fmaf(a4[0], s2, b4.x))), x1 = sp_value(relu_nan(__builtin_fmaf(a4[1], s2, b4.y)));
+                const float x2 = sp_value(relu_nan(__builtin_fmaf(a4[2], s2, b4.z))), x3 = sp_value(relu_nan(__builtin_fmaf(a4[3], s2, b4.w)));
+                sp_flag(ovm, sp_max2(sp_max2(0.f, x0, x1), x2, x3));
+                typedef __attribute__((ext_vector_type(4))) spe_t spx4_t;
+                spx4_t h4, l4;
+                h4[0] = (spe_t)x0; h4[1] = (spe_t)x1; h4[2] = (spe_t)x2; h4[3] = (spe_t)x3;
+                l4[0] = (spe_t)(x0 - (float)h4[0]); l4[1] = (spe_t)(x1 - (float)h4[1]);
+                l4[2] = (spe_t)(x2 - (float)h4[2]); l4[3] = (spe_t)(x3 - (float)h4[3]);
+                const int row = t * 16 + l15;
+                *reinterpret_cast<spx4_t*>(t2p + swz(row, g) + 8 * half) = h4;
+                *reinterpret_cast<spx4_t*>(t2p + swz(row, 4 + g) + 8 * half) = l4;
+            }
+        }
+        __syncthreads();  // T2 is complete
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int row = wave * (BM / 4) + t * 16 + l15;
+                t2h[q][t] = ldfrag(smem + q * (BM * ROWB), row, g);
+                t2l[q][t] = ldfrag(smem + q * (BM * ROWB), row, 4 + g);
+            }
+        __syncthreads();  // ... and read: the streaming phase's weight tiles overwrite it
+    } else if constexpr (PATCH) {
         // virtual rows: image b, row y (-1 .. H) -> b * (H + 2) + y + 1; a virtual row has W + 2 slots (x = -1 .. W)
         const int PW = p.Wd + 2, VH = p.H + 2;
         const int m_last = min(m_base + BM, p.M) - 1;
@@ -687,9 +828,7 @@ __global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const Bneck
     bool m_ok[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const long m = (long)m_base + wave * (BM / 4) + t * 16 + l15;
-        m_ok[t] = m < p.M;
-        m_row[t] = m_ok[t] ? (int)m : 0;
+        m_row[t] = row_pos(wave * (BM / 4) + t * 16 + l15, m_ok[t]);
         if constexpr (SUB == 1) {
             x_row[t] = (unsigned)(m_row[t] * (4L * P * 4) + 16 * g);
         } else {
@@ -732,10 +871,9 @@ __global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const Bneck
     load_res(1, rh[1], rl[1]);
 
     // T2 as B-operand fragments: K-step q = channels 32q..32q+31, lane group g holds 8g..8g+7 (weight rows were permuted)
-    sp_flags_t ovm = 0;  // lanes that split a finite |x| >= 65520 into an fp16 pair (split_dev.h sp_commit)
-    spx8_t t2h[NQ][NT], t2l[NQ][NT];
+    // (the spatial-tile form has read them back from LDS already)
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+    for (int q = 0; q < (T11 ? 0 : NQ); ++q) {
         const float4 b0 = *reinterpret_cast<const float4*>(sbias + 32 * q + 8 * g), b1 = *reinterpret_cast<const float4*>(sbias + 32 * q + 8 * g + 4);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -1102,7 +1240,7 @@ int launch_stem_pool_u8(avcer_ctx* ctx, const uint8_t* frames, int in_h, int in_
 
 int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, int out_step,
                  void* out, void* t1n, const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n,
-                 const float* b1n, hipStream_t st) {
+                 const float* b1n, hipStream_t st, const void* w2_frags) {
     if (out_step != 1 && out_step != 2) return set_err(ctx, AVCER_EINVAL, "bneck: out_step %d (1 or 2)", out_step);
     if (out_step == 2 && (t1n || ds_cin)) return set_err(ctx, AVCER_EINVAL, "bneck: the strided form is the last block of a stage (no next conv1, no downsample)");
     const int oh = (h - 1) / out_step + 1, ow = (w - 1) / out_step + 1;
@@ -1117,12 +1255,16 @@ int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t
     if (M_in * planes * 4L >= (long)OOB) return set_err(ctx, AVCER_EINVAL, "bneck: M=%ld too large for one pass", M_in);
     BneckParams p;
     p.T1 = (const char*)t1; p.X = (const char*)x; p.OUT = (char*)out; p.T1N = (char*)t1n;
-    p.W2 = (const char*)w2; p.W3 = (const char*)w3; p.W1N = (const char*)w1n;
+    p.W2 = (const char*)w2; p.W2F = (const char*)w2_frags; p.W3 = (const char*)w3; p.W1N = (const char*)w1n;
     p.b2 = b2; p.b3 = b3; p.b1n = b1n;
     p.t1_bytes = (unsigned)(M_in * planes * 4);
     p.M = (int)M; p.H = h; p.Wd = w; p.OH = oh; p.OW = ow; p.ovf = ctx->ovf;
     constexpr int BM = 128;
-    const int grid = (int)((M + BM - 1) / BM);
+    // The spatial-tile form (bneck_kernel<..., T11>): planes 64 with a next conv1 on 55 x 55 images (5 x 5 tiles of 11 x 11),
+    // when the caller brought the fragment-order copy of the conv2 weights; one block per tile.
+    const bool t11 = planes == 64 && h == 55 && w == 55 && out_step == 1 && t1n && w2_frags;
+    p.nblocks = t11 ? nb * 25 : (int)((M + BM - 1) / BM);
+    const int grid = p.nblocks;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     {
         // per position: T1 in (P), residual or downsample operand in (4P | ds_cin), OUT (4P) and T1' (P) out, 4 bytes per element
@@ -1140,9 +1282,11 @@ int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t
         if (planes == 64) bneck_kernel<64, BM, false, 0, false, 2><<<dim3(grid), dim3(256), 0, st>>>(p);
         else bneck_kernel<128, BM, false, 0, false, 2><<<dim3(grid), dim3(256), 0, st>>>(p);
     } else if (ds_cin) {
-        bneck_kernel<64, BM, true, 2, false><<<dim3(grid), dim3(256), 0, st>>>(p);
+        if (t11) bneck_kernel<64, BM, true, 2, false, 1, true><<<dim3(grid), dim3(256), 0, st>>>(p);
+        else bneck_kernel<64, BM, true, 2, false><<<dim3(grid), dim3(256), 0, st>>>(p);
     } else if (planes == 64) {
-        if (t1n) bneck_kernel<64, BM, true, 0, false><<<dim3(grid), dim3(256), 0, st>>>(p);
+        if (t11) bneck_kernel<64, BM, true, 0, false, 1, true><<<dim3(grid), dim3(256), 0, st>>>(p);
+        else if (t1n) bneck_kernel<64, BM, true, 0, false><<<dim3(grid), dim3(256), 0, st>>>(p);
         else bneck_kernel<64, BM, false, 0, false><<<dim3(grid), dim3(256), 0, st>>>(p);
     } else {
         if (t1n) {

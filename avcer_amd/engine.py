@@ -348,11 +348,13 @@ class Engine:
                                                   _ptr(bias), _ptr(residual), _ptr(y), self._stream()))
 
     def bneck_chain(self, planes: int, nb: int, h: int, w: int, t1, x, out, t1n, w2, b2, w3, b3, w1n=None, b1n=None, ds_cin: int = 0,
-                    out_step: int = 1):
+                    out_step: int = 1, w2_frags=None):
         """Kernel-level entry of the fused bottleneck chain (csrc/fused.hip); all tensors already on the device.
-        out_step = 2: the last block of a stage, evaluated at the even positions only (out is the compact grid)."""
+        out_step = 2: the last block of a stage, evaluated at the even positions only (out is the compact grid).
+        w2_frags: `weight_frags` of the conv2 matrix: selects the spatial-tile form where it applies (planes 64, 55 x 55)."""
         self._check(self.lib.avcer_bneck_chain(self.ctx, planes, nb, h, w, _ptr(t1), _ptr(x), int(ds_cin), int(out_step), _ptr(out),
-                                               _ptr(t1n), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), _ptr(w1n), _ptr(b1n), self._stream()))
+                                               _ptr(t1n), _ptr(w2), _ptr(b2), _ptr(w3), _ptr(b3), _ptr(w1n), _ptr(b1n),
+                                               _ptr(w2_frags), self._stream()))
 
     def attention(self, qkv, out, n: int, s: int, heads: int, head_dim: int, scale: float, in_kind: int, out_kind: int):
         """Kernel-level entry of the attention kernel: qkv [n, s, 3 * heads * head_dim] -> out [n, s, heads * head_dim];

@@ -65,7 +65,7 @@ enum {
  * refuses a library whose avcer_abi_version() differs (avcer_amd/_lib.py).
  *   2: avcer_conv_desc grew r_sub / r_h / r_w / tile_m, avcer_bneck_chain gained out_step, avcer_set_option left (round 3);
  *      split weight buffers carry a trailer and AVCER_MODE_BF16X3 became AVCER_MODE_F16X3 (round 4).
- *   3: avcer_x3_overflow_count, avcer_profile_read_families (round 5). */
+ *   3: avcer_x3_overflow_count, avcer_profile_read_families; avcer_bneck_chain gained w2_frags (round 5). */
 #define AVCER_ABI_VERSION 3
 int avcer_abi_version(void);
 
@@ -266,6 +266,10 @@ int avcer_conv_gemm_dual(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, co
  *   out_step = 2 (t1n NULL, ds_cin 0): the LAST block of a stage, whose output only the next stage's stride-2 1x1
  *   convolutions read (video.py:12-19,140-149): T2 and OUT are evaluated at positions (2 oy, 2 ox) alone and out is the compact
  *   sp32 [nb, (h+1)/2, (w+1)/2, 4*planes]; t1 and x keep their [nb,h,w] grids.  out_step = 1: every position.
+ *   w2_frags (may be NULL): the conv2 weights once more in MFMA fragment order (avcer_weight_frags of the same matrix).  With
+ *   it, planes 64 on 55 x 55 images with a next conv1 runs the spatial-tile form (11 x 11 tiles, resident halo patch, the
+ *   conv2 output channels split across the block's waves so that every weight fragment goes straight into the registers of
+ *   ONE wave); results are bit-identical to the form without it.
  *
  * avcer_stem_pool: conv 7x7/2 (TF-"same" padding) + BN + ReLU + max-pool 3x3/2 in one launch,
  *   ref: architectures/video.py:63-90,98-103,116-117.  planes_hi_lo: two fp16 planes [n,230,230,4] (hi, then lo plane_bytes
@@ -273,7 +277,7 @@ int avcer_conv_gemm_dual(avcer_ctx* ctx, const avcer_conv_desc* d, int dtype, co
  *   8 pixels x 4 channels); scale / bias f32 [64]; y sp32 [n,55,55,64]. */
 int avcer_bneck_chain(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, int out_step,
                       void* out, void* t1n, const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n,
-                      const float* b1n, avcer_stream_t stream);
+                      const float* b1n, const void* w2_frags, avcer_stream_t stream);
 int avcer_stem_pool(avcer_ctx* ctx, const void* planes_hi_lo, size_t plane_bytes, const void* w, const float* scale,
                     const float* bias, void* y, int n, avcer_stream_t stream);
 /* The same launch fed with the u8 frames themselves ([n,in_h,in_w,3] RGB; data/utils.py:19-39 -- NEAREST resize to 224, BGR flip,

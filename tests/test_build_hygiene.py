@@ -56,10 +56,11 @@ def _audit_module():
     return mod
 
 
-@pytest.mark.parametrize("src,kernel,instances", [("fused.hip", "bneck_tail2_kernel", 1), ("gemm.hip", "conv_gemm_wd_kernel", 16)])
+@pytest.mark.parametrize("src,kernel,instances", [("fused.hip", "bneck_tail2_kernel", 1), ("gemm.hip", "conv_gemm_wd_kernel", 16),
+                                                 ("fused.hip", "ELb0ELi1ELb1EE", 2)])  # the two T11 instantiations of bneck_kernel
 def test_asm_loaded_registers_are_untouched_until_their_wait(src, kernel, instances, tmp_path):
     """Every kernel that loads into VGPRs by inline asm (the residual ring of bneck_tail2_kernel, the weight fragments of all
-    sixteen conv_gemm_wd_kernel instantiations): only the kernel's counted `s_waitcnt vmcnt(N)` protects those registers, so
+    sixteen conv_gemm_wd_kernel instantiations and of the two spatial-tile (T11) forms of bneck_kernel): only the kernel's counted `s_waitcnt vmcnt(N)` protects those registers, so
     tools/audit_asm_loads.py walks the generated ISA's control-flow graph with the queue of outstanding vector-memory
     operations as its state and checks that no instruction reads or writes a register with an asm load in flight."""
     asm = tmp_path / (src + ".s")

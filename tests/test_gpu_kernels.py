@@ -435,6 +435,48 @@ def test_bneck_chain_first_block_with_downsample(engine):
     assert e0 < 2e-5 * max(1.0, out.abs().max().item()) and e1 < 2e-5 * max(1.0, t1n.abs().max().item())
 
 
+@pytest.mark.parametrize("ds", [False, True])
+@pytest.mark.parametrize("nb", [1, 3])
+def test_bneck_chain_spatial_tile_form(engine, nb, ds):
+    """The spatial-tile form of the planes-64 chain (bneck_kernel<..., T11>: 11 x 11 tiles of the 55 x 55 image, resident
+    13 x 13 halo patch, conv2 weight fragments loaded straight into registers -- selected by passing `w2_frags`): every output
+    element must be BIT-IDENTICAL to the gather form's (same products in the same order), image borders, tile seams and the
+    seven idle rows of every tile included; and both are held to float64 convolutions.  With and without the downsample
+    operand of a stage's first block (video.py:43-60)."""
+    g = torch.Generator().manual_seed(100 + nb + int(ds))
+    planes, hw = 64, 55
+    p4, xc = 4 * planes, (64 if ds else 4 * planes)
+    t1 = torch.rand(nb, hw, hw, planes, generator=g) * 2
+    x = torch.rand(nb, hw, hw, xc, generator=g) * 2
+    w2 = torch.randn(planes, 3, 3, planes, generator=g) / (3 * planes ** 0.5)
+    w3 = torch.randn(p4, planes, generator=g) / planes ** 0.5
+    wd = torch.randn(p4, 64, generator=g) / 8.0
+    w1 = torch.randn(planes, p4, generator=g) / p4 ** 0.5
+    b2, b3, b1 = (torch.randn(n, generator=g) * 0.3 for n in (planes, p4, planes))
+    t2 = F.relu(F.conv2d(t1.permute(0, 3, 1, 2).double(), w2.permute(0, 3, 1, 2).double(), b2.double(), padding=1))
+    o = F.conv2d(t2, w3.double()[:, :, None, None], b3.double())
+    o = o + (F.conv2d(x.permute(0, 3, 1, 2).double(), wd.double()[:, :, None, None]) if ds else x.permute(0, 3, 1, 2).double())
+    out = F.relu(o)
+    t1n = F.relu(F.conv2d(out, w1.double()[:, :, None, None], b1.double()))
+    dev = engine.device
+    w2m = w2.reshape(planes, -1).to(dev)
+    w3m = torch.cat([w3, wd], dim=1) if ds else w3
+    args = (to_sp32(t1).to(dev), to_sp32(x).to(dev))
+    wts = (engine.split_weight_rows(w2m), b2.to(dev), engine.split_weight_rows(w3m), b3.to(dev), engine.split_weight_rows(w1), b1.to(dev))
+    res = []
+    for frags in (None, engine.weight_frags(w2m)):
+        d_out = torch.full((nb, hw, hw, 2 * p4), 0x7fc0, dtype=torch.int16, device=dev)
+        d_t1n = torch.full((nb, hw, hw, 2 * planes), 0x7fc0, dtype=torch.int16, device=dev)
+        engine.bneck_chain(planes, nb, hw, hw, *args, d_out, d_t1n, *wts, ds_cin=64 if ds else 0, w2_frags=frags)
+        torch.cuda.synchronize()
+        res.append((d_out.cpu(), d_t1n.cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    e0 = (from_sp32(res[1][0]).permute(0, 3, 1, 2).double() - out).abs().max().item()
+    e1 = (from_sp32(res[1][1]).permute(0, 3, 1, 2).double() - t1n).abs().max().item()
+    print(f"bneck spatial-tile form nb={nb} ds={ds}: max|out err| {e0:.2e}, max|t1n err| {e1:.2e}")
+    assert e0 < 2e-5 * max(1.0, out.abs().max().item()) and e1 < 2e-5 * max(1.0, t1n.abs().max().item())
+
+
 def test_stem_pool_vs_float64(engine):
     """conv 7x7/2 with TF-"same" padding (2 before, 3 after) + BN + ReLU + max-pool 3x3/2 (video.py:63-90,98-103,116-117) in
     one launch, from the planar fp16 hi/lo image, against float64 torch ops."""

@@ -42,6 +42,8 @@ def show(d, marker="stem_pool"):
     f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     starts = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
+    if not starts:  # no marker kernel: the passes are equally long, show the last quarter (run() makes four)
+        starts = [len(rows) - len(rows) // 4]
     first = starts[-1]
     t0, total = int(rows[first]["Start_Timestamp"]), 0.0
     for r in rows[first:]:
