@@ -73,6 +73,54 @@ def test_asm_loaded_registers_are_untouched_until_their_wait(src, kernel, instan
     assert mod.audit(str(asm), kernel) == []
 
 
+def _store_data_hazards(asm_text):
+    """(kernel, store, next instruction) wherever a 12- / 16-byte buffer store is followed at once by a VALU write of one of its
+    data registers."""
+    bad, kernel, prev = [], "?", None
+    for line in asm_text.splitlines():
+        t = line.strip()
+        if not t or t.startswith((";", ".")):
+            continue
+        if t.endswith(":") and not t.startswith(".L"):
+            kernel, prev = t[:-1], None
+            continue
+        if prev is not None and t.startswith("v_"):
+            m = re.match(r"v_\w+\s+(v\[(\d+):(\d+)\]|v(\d+))", t)
+            if m:
+                lo, hi = (int(m.group(2)), int(m.group(3))) if m.group(2) else (int(m.group(4)), int(m.group(4)))
+                if lo <= prev[1] and hi >= prev[0]:
+                    bad.append((kernel, prev[2], t))
+        prev = None
+        m = re.match(r"buffer_store_dwordx[34]\s+v\[(\d+):(\d+)\]", t)
+        if m:
+            prev = (int(m.group(1)), int(m.group(2)), t)
+    return bad
+
+
+@pytest.mark.parametrize("src", ["fused.hip", "gemm.hip", "kernels.hip"])
+def test_no_valu_write_right_behind_a_wide_buffer_store(src, tmp_path):
+    """gfx950 reads the data registers of a 16-byte buffer store a moment after issue, and hipcc only separates a following VALU
+    write of them by a wait state when the store's scalar offset is a constant ("this hazard only exists if the instruction is
+    not using a register in the soffset field"): with the offset in an SGPR it emitted `v_max3_f32 v0, ..` right behind
+    `buffer_store_dwordx4 v[0:3], ..` in a lab form of the chain kernels, and 4 lanes x 1 dword of the stored rows changed from
+    run to run (profiles/experiments/README.md, round 5).  No shipped kernel may contain that pair."""
+    asm = tmp_path / (src + ".s")
+    flags = [f for f in build.FLAGS if f not in ("-fPIC", "-shared")]
+    r = subprocess.run([_hipcc()] + flags + ["-S", "--cuda-device-only", "-o", str(asm), os.path.join(CSRC, src)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _store_data_hazards(asm.read_text()) == []
+
+
+def test_the_store_data_hazard_scan_sees_the_pair():
+    hazard = "_Z1kv:\nbuffer_store_dwordx4 v[0:3], v80, s[4:7], s16 offen\nv_max3_f32 v0, v89, |v8|, |v9|\ns_endpgm\n"
+    assert len(_store_data_hazards(hazard)) == 1
+    fine = "_Z1kv:\nbuffer_store_dwordx4 v[0:3], v80, s[4:7], s16 offen\ns_nop 0\nv_max3_f32 v0, v89, |v8|, |v9|\ns_endpgm\n"
+    assert _store_data_hazards(fine) == []
+    other = "_Z1kv:\nbuffer_store_dwordx4 v[0:3], v80, s[4:7], s16 offen\nv_max3_f32 v4, v0, |v8|, |v9|\ns_endpgm\n"
+    assert _store_data_hazards(other) == []
+
+
 def test_the_asm_load_audit_catches_a_hazard(tmp_path):
     """The audit on hand-written ISA: a use before the counted wait, a use on a path that skips the wait, an overwrite of
     the destination and a missing drain are reported; the correct sequences are not."""
