@@ -137,6 +137,14 @@ def patch_fused(src: str) -> str:
              "#undef AVCER_T11_LOAD\n#undef AVCER_T11_WAIT\n" +
              STAMP.format(c="lab_c1", r="lab_r1").replace("    __b", "        __b").replace("    const", "        const") +
              f"        if (threadIdx.x == 0 && blockIdx.x < {NSTAMP}) {{ g_lab_stamps[4 * blockIdx.x] = lab_c1 - lab_c0; g_lab_stamps[4 * blockIdx.x + 1] = lab_r1 - lab_r0; }}\n")
+    # the resident-patch form's conv2 loop (planes 128; arm "chain128")
+    s = must(s, "        for (int c = 0; c < NQ; ++c) {\n            // the previous chunk's last barrier freed the patch and both weight tiles",
+             STAMP.format(c="lab_c0", r="lab_r0").replace("    __b", "        __b").replace("    const", "        const") +
+             "        for (int c = 0; c < NQ; ++c) {\n            // the previous chunk's last barrier freed the patch and both weight tiles")
+    s = must(s, "    } else {\n    unsigned a_off[A_ISS];",
+             STAMP.format(c="lab_c1", r="lab_r1").replace("    __b", "        __b").replace("    const", "        const") +
+             f"        if (threadIdx.x == 0 && blockIdx.x < {NSTAMP}) {{ g_lab_stamps[4 * blockIdx.x] = lab_c1 - lab_c0; g_lab_stamps[4 * blockIdx.x + 1] = lab_r1 - lab_r0; }}\n"
+             "    } else {\n    unsigned a_off[A_ISS];")
     # kernel entry / exit, and one common place for the conv2-end stamp of either form (lab_cm: declared at function scope)
     s = must(s, "    float* sbias = reinterpret_cast<float*>(smem + TILES);\n    for (int i = threadIdx.x; i < NBIAS; i += 256)",
              STAMP.format(c="lab_cs", r="lab_rs") + "    unsigned long long lab_a0 = 0, lab_a1 = 0;\n"
@@ -207,7 +215,7 @@ def child(arm: str, seconds: float):
     import torch
     from avcer_amd import _lib
 
-    _lib.LIB = os.path.join(LAB, f"libavcer_clock_{'chain' if arm == 'chain11' else arm}.so")
+    _lib.LIB = os.path.join(LAB, f"libavcer_clock_{'chain' if arm in ('chain11', 'chain128') else arm}.so")
     from avcer_amd.engine import Engine
     from tools.layer_bench import conv2d
 
@@ -217,11 +225,12 @@ def child(arm: str, seconds: float):
     eng.lib.avcer_lab_stamps.argtypes = [C.c_void_p, C.c_int]
     torch.manual_seed(1)
     t11 = arm == "chain11"
-    if t11:
+    p128 = arm == "chain128"
+    if t11 or p128:
         arm = "chain"
         _lib.LIB = os.path.join(LAB, "libavcer_clock_chain.so")
     if arm == "chain":
-        planes, nb, hw = 64, 1024, 55
+        planes, nb, hw = (128, 1024, 28) if p128 else (64, 1024, 55)
         p4, M = 4 * planes, nb * hw * hw
         from avcer_amd import sp32
         t1 = sp32.to_sp32(torch.relu(torch.randn(M, planes, device=dev)))
@@ -330,7 +339,7 @@ def child(arm: str, seconds: float):
               + " / ".join(f"{hist[k] / max(tot_t, 1):.2f}" for k in range(4)) + f" / {sum(v for k, v in hist.items() if k >= 4) / max(tot_t, 1):.2f}", flush=True)
         c1, cy1, n1 = clk(0)
         c2, cy2, n2 = clk(2)
-        print(f"{'chain11 (spatial-tile form)' if t11 else 'chain  '} bneck_kernel<64,128,true,0,false,1> 1024 frames: {us:8.1f} us/launch  conv2 loop {c1:7.1f} MHz ({cy1:.0f} cycles)  "
+        print(f"{'chain11 (spatial-tile form)' if t11 else 'chain128 (patch form, 28 x 28)' if p128 else 'chain  '} bneck_kernel<{planes},128,true,...> 1024 frames: {us:8.1f} us/launch  conv2 loop {c1:7.1f} MHz ({cy1:.0f} cycles)  "
               f"streaming loop {c2:7.1f} MHz ({cy2:.0f} cycles)  [{n1} blocks, {n_l} launches in the settle phase]", flush=True)
     else:
         c, cy, n1 = clk(0)
