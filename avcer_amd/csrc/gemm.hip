@@ -1132,8 +1132,9 @@ void launch_skinny_t(const GemmParams& p, hipStream_t st) {
 template <int OUT>
 void launch_skinny(const GemmParams& p, hipStream_t st) {
     const long simds = (long)p.slots * 2;  // block slots = 2 per CU, 4 SIMDs per CU
-    // 16-position tiles while they leave half the SIMDs free (latency-bound: the smallest tile wins); past that the launch is
-    // bound by L2 -> L1 bytes (~12 TB/s over the chip) and the 32-position tile moves 6 KiB per K-step where two 16s move 8
+    // 16-position tiles while they leave half the SIMDs free (a wave is paced by its round trips -- the weights come from beyond
+    // the L2 once per launch -- so the smallest tile wins); past that the round trips lengthen with the load, and the 32-position
+    // tile moves 6 KiB per K-step where two 16s move 8 (tools/ab_layers.py --skinny, profiles/r05_skinny_ab.txt)
     const long nt = p.N / 16 * (p.groups > 1 ? p.groups : 1);
     if (p.tile_m == 16 || (p.tile_m == 0 && (long)((p.M + 15) / 16) * nt <= simds / 2)) launch_skinny_t<OUT, 1, 12>(p, st);
     else if (p.tile_m == 32 || (p.tile_m == 0 && (long)((p.M + 31) / 32) * nt <= simds)) launch_skinny_t<OUT, 2, 8>(p, st);
