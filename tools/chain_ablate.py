@@ -21,7 +21,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LAB = os.path.join(ROOT, "tools", "lab")
-ARMS = ("product", "noMFMA", "noOUT", "noRes", "noT1N", "noHBM")
+ARMS = ("product", "noMFMA", "noOUT", "noRes", "noT1N", "noHBM", "noW2", "noWS", "noPatch")
 
 
 def must(s, a, b):
@@ -44,6 +44,17 @@ def patch(src, arm):
                     "                l[t] = *reinterpret_cast<const uint4*>(rp + 64);\n",
                  "                const char* rp = p.X + (size_t)x_row[t] + G * 128;\n                h[t] = l[t] = make_uint4(0u, 0u, 0u, 0u);\n"
                  "                if (p.M < 0) { h[t] = *reinterpret_cast<const uint4*>(rp); l[t] = *reinterpret_cast<const uint4*>(rp + 64); }\n")
+    # arms of the spatial-tile form (run with the fragment copy): no conv2 weight loads after the first three K-steps, no
+    # weight DMA in the streaming phase after group 0, no halo-patch DMA
+    if arm == "noW2":
+        s = must(s, "            if (ks + 3 < NKS) { AVCER_T11_LOAD(ks + 3); }", "            if (ks + 3 < NKS && p.M < 0) { AVCER_T11_LOAD(ks + 3); }")
+        s = must(s, "            if (ks + 3 < NKS) AVCER_T11_WAIT(6, ks);\n            else if (ks + 2 < NKS) AVCER_T11_WAIT(4, ks);\n            else if (ks + 1 < NKS) AVCER_T11_WAIT(2, ks);\n            else AVCER_T11_WAIT(0, ks);",
+                 "            AVCER_T11_WAIT(0, ks);")
+    if arm == "noWS":
+        s = must(s, "        if (G + 1 < NG) issue_group(G + 1);", "        if (G + 1 < NG && p.M < 0) issue_group(G + 1);")
+    if arm == "noPatch":
+        s = must(s, "                if (ii < PIECES) dma16(t1rs, smem + q * (T11_SLOTS * ROWB) + ii * 1024, off);",
+                 "                if (ii < PIECES && p.M < 0) dma16(t1rs, smem + q * (T11_SLOTS * ROWB) + ii * 1024, off);")
     return s
 
 
@@ -99,11 +110,13 @@ def child(arm):
         t1 = eng.split_weights(torch.relu(torch.randn(M * planes, device=dev, generator=g))).view(M, -1)
         x = eng.split_weights(torch.relu(torch.randn(M * p4, device=dev, generator=g))).view(M, -1)
         out, t1n = torch.empty_like(x), torch.empty_like(t1)
-        w2 = eng.split_weight_rows(torch.randn(planes, 9 * planes, device=dev) * 0.05)
+        w2f32 = torch.randn(planes, 9 * planes, device=dev) * 0.05
+        w2 = eng.split_weight_rows(w2f32)
         w3 = eng.split_weight_rows(torch.randn(p4, planes, device=dev) * 0.1)
         w1 = eng.split_weight_rows(torch.randn(planes, p4, device=dev) * 0.05)
         b2, b3, b1 = torch.zeros(planes, device=dev), torch.zeros(p4, device=dev), torch.zeros(planes, device=dev)
-        call = lambda: eng.bneck_chain(planes, nb, hw, hw, t1, x, out, t1n, w2, b2, w3, b3, w1, b1)
+        kw = {"w2_frags": eng.weight_frags(w2f32)} if planes == 64 else {}   # planes 64: the shipped spatial-tile form
+        call = lambda: eng.bneck_chain(planes, nb, hw, hw, t1, x, out, t1n, w2, b2, w3, b3, w1, b1, **kw)
         for _ in range(3):
             call()
         torch.cuda.synchronize()
@@ -118,7 +131,7 @@ def child(arm):
             ts.append(e0.elapsed_time(e1) / 10 * 1e3)
         res.append(sorted(ts)[2])
         del t1, x, out, t1n
-    print(f"{arm:8s}  planes 64 (1024 x 55 x 55, middle block): {res[0]:8.1f} us    planes 128 (1024 x 28 x 28): {res[1]:8.1f} us", flush=True)
+    print(f"{arm:8s}  planes 64 (1024 x 55 x 55, middle block, spatial-tile form): {res[0]:8.1f} us    planes 128 (1024 x 28 x 28): {res[1]:8.1f} us", flush=True)
 
 
 if __name__ == "__main__":
