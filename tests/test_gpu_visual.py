@@ -215,3 +215,30 @@ def test_lstm_one_window_matches_its_row_in_a_batch_x3(engine, sd_dynamic):
         part = engine.dynamic_forward(w[lo:hi], MODE_F16X3).cpu()
         assert torch.equal(big[lo:hi], part), (lo, hi)
     assert torch.isfinite(big).all()
+
+
+def test_kernel_families_follow_the_batch(engine_static):
+    """avcer_profile_read_families (the bench line's roofline.per_family): which kernel family serves the static CNN is a function
+    of the batch -- one frame: every contraction with a small grid on the skinny form, the stage-3 tails as two contractions (no
+    fused tail launch); 100 frames: the four fused tails, the chains, the weights-direct form -- and the event times, FLOPs and
+    bytes of every family that launched are positive."""
+    frames = torch.from_numpy(synth.face_frames(3, 100))
+    engine_static.static_forward(frames[:2], MODE_F16X3)   # weights split, workspaces sized
+    torch.cuda.synchronize()
+    got = {}
+    for n in (1, 100):
+        engine_static.profile_enable(True)
+        engine_static.static_forward(frames[:n], MODE_F16X3)
+        got[n] = engine_static.profile_read_families()
+        engine_static.profile_enable(False)
+    one, many = got[1], got[100]
+    assert one["bneck_tail2_kernel"][1] == 0 and many["bneck_tail2_kernel"][1] == 4
+    assert one["conv_gemm_skinny_kernel"][1] >= 25 and many["conv_gemm_skinny_kernel"][1] <= 2
+    assert one["conv_gemm_wd_kernel"][1] == 0 and many["conv_gemm_wd_kernel"][1] >= 8
+    assert one["bneck_kernel"][1] == many["bneck_kernel"][1] == 6 and one["stem_pool_kernel"][1] == 1
+    for fam in (one, many):
+        for name, (ms, launches, flops, nbytes) in fam.items():
+            assert (ms > 0 and flops > 0 and nbytes > 0) if launches else (ms == 0 and flops == 0), name
+    # the same graph either way: FLOPs per frame agree to the padding of the skinny tiles' own accounting (none: algorithmic)
+    f1, f100 = sum(v[2] for v in one.values()), sum(v[2] for v in many.values())
+    assert abs(f100 / 100 - f1) < 1e-6 * f1
