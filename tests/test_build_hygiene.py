@@ -22,16 +22,34 @@ def _hipcc():
     return exe
 
 
+_ASM_CACHE = {}
+
+
+def _device_asm(src):
+    """The device ISA of one source file, compiled once per test session (three tests read fused.hip's, two gemm.hip's)."""
+    if src not in _ASM_CACHE:
+        import tempfile
+
+        out = os.path.join(tempfile.mkdtemp(prefix="avcer_asm_"), src + ".s")
+        flags = [f for f in build.FLAGS if f not in ("-fPIC", "-shared")]
+        r = subprocess.run([_hipcc()] + flags + ["-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, src)],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        _ASM_CACHE[src] = out
+    return _ASM_CACHE[src]
+
+
 @pytest.mark.parametrize("src", ["gemm.hip", "fused.hip"])
-def test_mfma_kernels_do_not_spill(src, tmp_path):
-    r = subprocess.run([_hipcc()] + build.FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o",
-                                                   str(tmp_path / "x.o")], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    names = re.findall(r"Function Name: (\S+)", r.stderr)
-    scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
-    spills = [int(v) for v in re.findall(r"VGPRs Spill: (\d+)", r.stderr)]
-    assert len(names) == len(scratch) == len(spills) and len(names) >= 10
-    bad = [(n, s, v) for n, s, v in zip(names, scratch, spills) if s or v]
+def test_mfma_kernels_do_not_spill(src):
+    """No kernel of the two MFMA sources may use scratch memory or spill a register (the code object's own metadata)."""
+    txt = open(_device_asm(src)).read()
+    kernels = re.findall(r"- \.agpr_count:.*?\.wavefront_size", txt, re.S)
+    assert len(kernels) >= 10
+    bad = []
+    for k in kernels:
+        g = lambda key: re.search(r"\." + key + r":\s+(\S+)", k).group(1)
+        if int(g("private_segment_fixed_size")) or int(g("vgpr_spill_count")) or int(g("sgpr_spill_count")):
+            bad.append((g("name"), g("private_segment_fixed_size"), g("vgpr_spill_count"), g("sgpr_spill_count")))
     assert not bad, bad
 
 
@@ -63,14 +81,10 @@ def test_asm_loaded_registers_are_untouched_until_their_wait(src, kernel, instan
     sixteen conv_gemm_wd_kernel instantiations and of the two spatial-tile (T11) forms of bneck_kernel): only the kernel's counted `s_waitcnt vmcnt(N)` protects those registers, so
     tools/audit_asm_loads.py walks the generated ISA's control-flow graph with the queue of outstanding vector-memory
     operations as its state and checks that no instruction reads or writes a register with an asm load in flight."""
-    asm = tmp_path / (src + ".s")
-    flags = [f for f in build.FLAGS if f not in ("-fPIC", "-shared")]
-    r = subprocess.run([_hipcc()] + flags + ["-S", "--cuda-device-only", "-o", str(asm), os.path.join(CSRC, src)],
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+    asm = _device_asm(src)
     mod = _audit_module()
-    assert len(mod.kernels(str(asm), kernel)) == instances
-    assert mod.audit(str(asm), kernel) == []
+    assert len(mod.kernels(asm, kernel)) == instances
+    assert mod.audit(asm, kernel) == []
 
 
 def _store_data_hazards(asm_text):
@@ -104,12 +118,7 @@ def test_no_valu_write_right_behind_a_wide_buffer_store(src, tmp_path):
     not using a register in the soffset field"): with the offset in an SGPR it emitted `v_max3_f32 v0, ..` right behind
     `buffer_store_dwordx4 v[0:3], ..` in a lab form of the chain kernels, and 4 lanes x 1 dword of the stored rows changed from
     run to run (profiles/experiments/README.md, round 5).  No shipped kernel may contain that pair."""
-    asm = tmp_path / (src + ".s")
-    flags = [f for f in build.FLAGS if f not in ("-fPIC", "-shared")]
-    r = subprocess.run([_hipcc()] + flags + ["-S", "--cuda-device-only", "-o", str(asm), os.path.join(CSRC, src)],
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert _store_data_hazards(asm.read_text()) == []
+    assert _store_data_hazards(open(_device_asm(src)).read()) == []
 
 
 def test_the_store_data_hazard_scan_sees_the_pair():
