@@ -5,7 +5,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from .build import LIB
+from .build import LIB, source_hash
 
 c_ctx = C.c_void_p
 c_stream = C.c_void_p
@@ -32,12 +32,13 @@ class ConvDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 3          # include/avcer_hip.h AVCER_ABI_VERSION: struct layouts, argument lists and buffer sizes below
+ABI_VERSION = 4          # include/avcer_hip.h AVCER_ABI_VERSION: struct layouts, argument lists and buffer sizes below
 SPLIT_TRAILER = 256      # include/avcer_hip.h AVCER_SPLIT_TRAILER: bytes behind a split weight matrix (its scale)
 
 # name -> (restype, argtypes); exactly the symbols include/avcer_hip.h declares
 SIGNATURES = {
     "avcer_abi_version": (C.c_int, []),
+    "avcer_source_hash": (C.c_char_p, []),
     "avcer_ctx_create": (C.c_int, [C.c_int, C.POINTER(c_ctx)]),
     "avcer_ctx_destroy": (None, [c_ctx]),
     "avcer_last_error": (C.c_char_p, [c_ctx]),
@@ -48,6 +49,7 @@ SIGNATURES = {
     "avcer_static_forward": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, c_stream]),
     "avcer_set_static_batch": (C.c_int, [c_ctx, C.c_int]),
+    "avcer_set_static_back_batch": (C.c_int, [c_ctx, C.c_int]),
     "avcer_static_forward_nchw": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             c_stream]),
     "avcer_gather_windows": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, c_stream]),
@@ -96,6 +98,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_PRODUCT_LIB = LIB  # `LIB` may be overridden by lab tools; the stamp check applies to the product path only
 
 
 def load() -> C.CDLL:
@@ -116,8 +119,23 @@ def load() -> C.CDLL:
         if lib.avcer_abi_version() != ABI_VERSION:
             raise RuntimeError(f"{LIB}: ABI version {lib.avcer_abi_version()}, this binding is written for {ABI_VERSION} "
                                "(include/avcer_hip.h AVCER_ABI_VERSION): rebuild with `python -m avcer_amd.build`")
+        check_source_hash(lib, LIB)
         _lib = lib
     return _lib
+
+
+def check_source_hash(lib, path: str, tree_hash: str | None = None) -> str:
+    """The library embeds the hash of the sources it was compiled from (avcer_source_hash(), written by build.py); a binary
+    built from OTHER sources than the tree's -- a stale .so behind an unchanged ABI number -- is refused.  One-off lab builds
+    loaded through an overridden `_lib.LIB` (tools/: patched copies, their hash ends in "+lab...") are exempt."""
+    have = lib.avcer_source_hash().decode()
+    want = tree_hash if tree_hash is not None else source_hash()
+    if "+lab" in have or os.path.abspath(path) != os.path.abspath(_PRODUCT_LIB):
+        return have
+    if have != want:
+        raise RuntimeError(f"{path} was built from sources with hash {have}, the tree's csrc/ + include/ hash is {want}: "
+                           "stale binary -- rebuild with `python -m avcer_amd.build`")
+    return have
 
 
 class AvcerError(RuntimeError):

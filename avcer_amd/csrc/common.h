@@ -43,6 +43,7 @@ struct avcer_ctx {
     Model stat, dyn, aud, face;
     int aud_classes = 0;
     int static_batch = 1024;  // frames per internal pass of the static CNN (4 GiB buffer-descriptor limit at f32)
+    int static_back = 0;      // frames per back pass of the static CNN (0: two front passes; avcer_set_static_back_batch)
     int block_slots = 512;    // 2 x hipDeviceProp_t::multiProcessorCount: what grid_rounds() divides a grid by
     // grow-only workspace arenas (activations), one per pipeline
     DevBuf ws[8];

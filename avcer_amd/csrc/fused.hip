@@ -1254,7 +1254,12 @@ int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t
     if (planes != 64 && planes != 128) return set_err(ctx, AVCER_EINVAL, "bneck: planes %d (64 or 128)", planes);
     if (ds_cin != 0 && !(ds_cin == 64 && planes == 64 && t1n))
         return set_err(ctx, AVCER_EINVAL, "bneck: the downsample form exists for planes 64 with a 64-channel input and a next conv1");
-    if (M_in * planes * 4L >= (long)OOB) return set_err(ctx, AVCER_EINVAL, "bneck: M=%ld too large for one pass", M_in);
+    // The kernel walks every tensor of the pass with 32-bit byte offsets (x_row / o_row) and T1 through a buffer descriptor: the
+    // LARGEST tensor bounds the pass -- X [M_in][4 planes | ds_cin] and OUT [M][4 planes], four times T1 -- not T1 alone
+    const long x_bytes = M_in * (long)(ds_cin ? ds_cin : 4 * planes) * 4L, out_bytes = M * 4L * planes * 4L;
+    if (M_in * planes * 4L >= (long)OOB || x_bytes >= (long)OOB || out_bytes >= (long)OOB)
+        return set_err(ctx, AVCER_EINVAL, "bneck: %ld positions in, %ld out: a tensor of the pass reaches the 4 GiB offset range "
+                                          "(at most %ld positions per call at planes %d)", M_in, M, ((long)OOB - 1) / (16L * planes), planes);
     BneckParams p;
     p.T1 = (const char*)t1; p.X = (const char*)x; p.OUT = (char*)out; p.T1N = (char*)t1n;
     p.W2 = (const char*)w2; p.W2F = (const char*)w2_frags; p.W3 = (const char*)w3; p.W1N = (const char*)w1n;

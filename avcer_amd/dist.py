@@ -31,9 +31,10 @@ def unpack_records(rec: torch.Tensor, t: int, c: int):
     return stat, dyn, aud
 
 
-def all_gather_records(rec: torch.Tensor, n_total: int) -> torch.Tensor:
-    """All-gather of row blocks produced with shard_range (uneven blocks are padded to the largest one)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def all_gather_records(rec: torch.Tensor, n_total: int, force: bool = False) -> torch.Tensor:
+    """All-gather of row blocks produced with shard_range (uneven blocks are padded to the largest one).
+    `force`: run the collective at world size 1 as well (tests/test_gpu_rccl.py: the RCCL path on a one-GPU box)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return rec
     world, rank = dist.get_world_size(), dist.get_rank()
     sizes = [shard_range(n_total, r, world) for r in range(world)]

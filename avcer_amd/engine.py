@@ -78,13 +78,23 @@ class Engine:
         self._check(self.lib.avcer_x3_overflow_count(self.ctx, int(reset), C.byref(n), self._stream()))
         return int(n.value)
 
+    def x3_overflow_clear(self):
+        """Asynchronous reset of the range-contract counter, in stream order on the current stream (no wait)."""
+        self._check(self.lib.avcer_x3_overflow_count(self.ctx, 1, None, self._stream()))
+
     def guarded(self, mode: int, call):
-        """`call(mode)` with the x3 mode's range contract enforced: in MODE_F16X3 the device counter is read ONCE behind the
-        call and, when an activation left fp16's range, the same call is repeated in MODE_FP32 (no range limit; a fresh call on
-        the same context).  What comes back is then what the reference's fp32 path computes -- NaN only where the input was
-        NaN (the empty audio window).  Other modes pass through."""
+        """`call(mode)` with the x3 mode's range contract enforced.  `guarded` OWNS the counter for the duration of the call: in
+        MODE_F16X3 it is cleared in stream order in front of the call (counts left behind by earlier unguarded kernel-level
+        calls, by a call that raised or by abandoned side-stream work are not charged to this one), read ONCE behind it -- the
+        read waits for the current stream, so `call` must have joined any side stream it used -- and, when an activation left
+        fp16's range, the same call is repeated in MODE_FP32 (no range limit; a fresh call on the same context).  What comes
+        back is then what the reference's fp32 path computes -- NaN only where the input was NaN (the empty audio window).
+        Other modes pass through.  Cost: one host synchronisation per guarded call."""
+        if mode != MODE_F16X3:
+            return call(mode)
+        self.x3_overflow_clear()
         out = call(mode)
-        if mode == MODE_F16X3 and self.x3_overflow_count(reset=True):
+        if self.x3_overflow_count(reset=True):
             self.x3_fallbacks += 1
             out = call(MODE_FP32)
         return out
@@ -120,8 +130,11 @@ class Engine:
                                                 _ptr(lm), self._stream()))
         return loc, conf, lm
 
-    def set_static_batch(self, frames: int):
+    def set_static_batch(self, frames: int, back: int | None = None):
+        """Frames per front pass of the static CNN (1..1024) and, optionally, per back pass (1..2048; 0 = two front passes)."""
         self._check(self.lib.avcer_set_static_batch(self.ctx, int(frames)))
+        if back is not None:
+            self._check(self.lib.avcer_set_static_back_batch(self.ctx, int(back)))
 
     # ------------------------------------------------------------------ forward passes
     def static_forward(self, frames_u8, mode: int = MODE_DEFAULT):

@@ -54,24 +54,34 @@ def run_inference(engine, frames_bgr, wav, fps: float, detector=None, detections
         # (1) the audio branch depends on nothing of the visual one: it is queued FIRST, on its own stream, and runs while
         #     the host walks the tracker loop below (750 numpy + linear_sum_assignment iterations for a 30 s video)
         side.wait_stream(main)
-        with torch.cuda.stream(side):
-            win_logits, lo, hi = audio_forward(engine, wav_t, sr, fps, window, step, padding, m)  # get_prob_audio_8_cl.py:68-138
-        # (2) faces -> tracks -> tiles (get_face_images.py:38-63), then the visual models on track 00
-        if "clip" not in host:
-            dets = detections if detections is not None else detector.batch(frames, rgb=False)     # get_face_images.py:49
-            records, tiles = VideoTiler(engine).process(frames, dets)
-            if not (len(records) and (records[:, 1] == 0).any()):
-                raise FileNotFoundError("no face track 00 (os.listdir(<faces>/00) fails in the reference, get_prob_video.py:79)")
-            host["records"] = records
-            host["clip"] = track_clip(records, tiles, 0, total_frames)
-        clip, present = host["clip"]
-        static_probs, dynamic_logits = visual_forward(engine, clip, present, fps, m)                # get_prob_video.py:67-204
-        # (3) fusion last, behind both branches; nothing has been copied to the host yet
-        main.wait_stream(side)
-        win_logits.record_stream(main)
-        prob, am = fuse(engine, static_probs, dynamic_logits, win_logits, lo, hi, weights_prob_model, weights_model,
-                        ce_weights_type, ce_mask)                                                   # run.py:25-189
-        return static_probs, dynamic_logits, win_logits, lo, hi, prob, am
+        wav_t.record_stream(side)  # allocated on `main`: the allocator must not hand it out while `side` still reads it
+        joined = False
+        try:
+            with torch.cuda.stream(side):
+                win_logits, lo, hi = audio_forward(engine, wav_t, sr, fps, window, step, padding, m)  # get_prob_audio_8_cl.py:68-138
+            # (2) faces -> tracks -> tiles (get_face_images.py:38-63), then the visual models on track 00
+            if "clip" not in host:
+                dets = detections if detections is not None else detector.batch(frames, rgb=False)  # get_face_images.py:49
+                records, tiles = VideoTiler(engine).process(frames, dets)
+                if not (len(records) and (records[:, 1] == 0).any()):
+                    raise FileNotFoundError("no face track 00 (os.listdir(<faces>/00) fails in the reference, get_prob_video.py:79)")
+                host["records"] = records
+                host["clip"] = track_clip(records, tiles, 0, total_frames)
+            clip, present = host["clip"]
+            static_probs, dynamic_logits = visual_forward(engine, clip, present, fps, m)             # get_prob_video.py:67-204
+            # (3) fusion last, behind both branches; nothing has been copied to the host yet
+            main.wait_stream(side)
+            joined = True
+            win_logits.record_stream(main)
+            prob, am = fuse(engine, static_probs, dynamic_logits, win_logits, lo, hi, weights_prob_model, weights_model,
+                            ce_weights_type, ce_mask)                                                # run.py:25-189
+            return static_probs, dynamic_logits, win_logits, lo, hi, prob, am
+        finally:
+            # the reference's failure paths (no face track, a detector error) unwind from here: the audio branch already queued
+            # on `side` is joined all the same, so that no launch of this video outlives the call (its workspace and the
+            # range-contract counter belong to the next one)
+            if not joined:
+                main.wait_stream(side)
 
     # MODE_F16X3: one read of the range-contract counter behind the last launch; a video during which an activation left fp16's
     # range is run again in MODE_FP32 (engine.guarded)

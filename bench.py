@@ -107,12 +107,10 @@ def peaks():
 
 
 def kernel_source_hash():
-    """Hash of the HIP sources: a committed PMC traffic figure is only valid for the kernels it was measured on."""
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "avcer_amd", "csrc", "*.hip")) +
-                    glob.glob(os.path.join(ROOT, "avcer_amd", "csrc", "*.h"))):
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    """Hash of the HIP sources and headers in the tree (avcer_amd/build.py source_hash): a committed PMC traffic figure is only
+    valid for the kernels it was measured on, and the loaded binary must carry the same hash (binary_source_hash)."""
+    from avcer_amd.build import source_hash
+    return source_hash()
 
 
 def pmc_traffic(mode, clips):
@@ -598,7 +596,8 @@ def main():
     torch.set_num_threads(min(usable_cores(), 16))
     log(f"rank {rank}/{world}: building pipeline (synthetic weights, seed 42)")
     pipe = AVPipeline(device=local_rank, seed=42, mode=modes[args.mode])
-    pipe.overlap_branches = not args.no_overlap
+    if args.no_overlap:
+        pipe.overlap_branches = False  # the library default (two streams) is what the headline times
     log("generating inputs")
     frames, wav = make_inputs(args.clips, rank, device)
     n_total = args.clips * world
@@ -704,6 +703,7 @@ def main():
                                         "(avcer_measure_ceilings); roofline.peak stays the datasheet figure.  The MFMA kernels "
                                         "run at the socket power cap (tools/clock_probe.py): the loop's rate is what 1.4 kW buys"},
             "kernel_source_hash": kernel_source_hash(),
+            "binary_source_hash": pipe.engine.lib.avcer_source_hash().decode(),
             "max_dprob_vs_cpu_oracle": dprob, "argmax_identical": same, "parity_gate": 1e-4,
             "gflop_per_clip": GFLOP_CLIP,
             "gflop_per_clip_reference_graph": GFLOP_CLIP + T_FRAMES * GFLOP_STATIC_UNREAD,

@@ -65,9 +65,14 @@ enum {
  * refuses a library whose avcer_abi_version() differs (avcer_amd/_lib.py).
  *   2: avcer_conv_desc grew r_sub / r_h / r_w / tile_m, avcer_bneck_chain gained out_step, avcer_set_option left (round 3);
  *      split weight buffers carry a trailer and AVCER_MODE_BF16X3 became AVCER_MODE_F16X3 (round 4).
- *   3: avcer_x3_overflow_count, avcer_profile_read_families; avcer_bneck_chain gained w2_frags (round 5). */
-#define AVCER_ABI_VERSION 3
+ *   3: avcer_x3_overflow_count, avcer_profile_read_families; avcer_bneck_chain gained w2_frags (round 5).
+ *   4: avcer_source_hash, avcer_set_static_back_batch (round 6). */
+#define AVCER_ABI_VERSION 4
 int avcer_abi_version(void);
+/* Hash (16 hex digits) of the sources and headers this binary was compiled from, embedded at build time by
+ * avcer_amd/build.py (source_hash()).  The Python binding refuses a library whose hash differs from the tree's, and bench.py
+ * prints it beside the tree's hash: a stale binary with the right ABI number cannot be measured under a fresh label. */
+const char* avcer_source_hash(void);
 
 int avcer_ctx_create(int device, avcer_ctx** out);
 void avcer_ctx_destroy(avcer_ctx* ctx);
@@ -79,7 +84,10 @@ const char* avcer_last_error(const avcer_ctx* ctx);
  * 0: any NaN in an output came in through the input -- the reference's own result for an empty audio window.  > 0: outputs
  * produced since the last reset may hold NaN where the reference (fp32, no range limit) holds numbers
  *   ref: get_prob_video.py:107-112, get_prob_audio_8_cl.py:87-92 (fp32 forward passes)
- * -- repeat the call with AVCER_MODE_FP32.  Waits for `stream`; reset != 0 zeroes the counter behind the read. */
+ * -- repeat the call with AVCER_MODE_FP32.  Waits for `stream`; reset != 0 zeroes the counter behind the read.
+ * count == NULL with reset != 0: an asynchronous reset queued on `stream`, nothing read, nothing waited for -- what a guarded call
+ * puts in front of its launches so that counts left by earlier work on the context are not charged to it.  The counter sees the
+ * launches of every stream; the read orders only behind `stream`, so join side streams into it first. */
 int avcer_x3_overflow_count(avcer_ctx* ctx, int reset, int64_t* count, avcer_stream_t stream);
 
 /* Packed weights (host pointers; the library copies them to the device and owns the copy).
@@ -99,8 +107,13 @@ int avcer_load_audio(avcer_ctx* ctx, const void* blob_host, size_t nbytes);
 int avcer_static_forward(avcer_ctx* ctx, const uint8_t* frames_hwc, int n, int in_h, int in_w, int mode,
                          float* logits, float* probs, float* feats, avcer_stream_t stream);
 
-/* Frames per internal pass of the static CNN, 1..1024 (default 1024). Larger passes fill the chip on layers 3/4. */
+/* Frames per FRONT pass of the static CNN (stem, stage 1, first block of stage 2: the 55 x 55 tensors), 1..1024 (default 1024).
+ * Results do not depend on it (every kernel's arithmetic per frame is independent of the batch around it). */
 int avcer_set_static_batch(avcer_ctx* ctx, int frames);
+/* Frames per BACK pass (rest of stage 2, stages 3-4, tail), 1..2048, or 0 = two front passes (the default: 2048 at the default
+ * front pass).  The late layers' grids are small, so the back wants as many frames per launch as the 4 GiB descriptors allow
+ * whatever the front pass is.  A scheduling knob like the one above: results do not depend on it. */
+int avcer_set_static_back_batch(avcer_ctx* ctx, int frames);
 
 /* The same model on an already preprocessed tensor, i.e. the exact argument of the reference's
  * `pth_model_static(x)`:  x f32 [n,3,224,224] (BGR, mean-subtracted).   ref: get_prob_video.py:103-109 */
@@ -206,9 +219,13 @@ int avcer_fuse(avcer_ctx* ctx, const float* stat, const float* dyn_logits, const
  * 4 = f32 in / sp32 out, 5 = sp32 in / sp32 out (+ sp32 residual), 6 = sp32 in / f32 out (+ f32 residual);
  * 7 / 8 = 5 / 6 with w in fragment order (avcer_weight_frags): the weights-direct form of the kernel, bit-identical results,
  * for n % 256 == 0, an even number of 32-element K-steps and groups <= 1 (anything else is AVCER_EINVAL: use 5 / 6);
- * 9 / 10 = 5 / 6 with w in fragment order once more, the "skinny" form for a handful of positions (one frame or one window per
- * call: one wave per 64 positions x 32 channels, registers only, no LDS), bit-identical results as well, for
- * k % 128 == 0, groups <= 1, M <= 4096 (anything else is AVCER_EINVAL).  The networks use it for launches of M <= 256.
+ * 9 / 10 = 5 / 6 with w in fragment order once more, the "skinny" form for launches of few positions (one frame or one window
+ * per call, the deep layers of a small batch): one WAVE per (16 | 32 | 64 positions) x 16 channels, registers only, no LDS, no
+ * barrier; bit-identical results as well.  Requires cin % 32 == 0 and n % 32 == 0 (per group), no second source (x2_cin == 0);
+ * grouped convolutions are supported (one launch, as for 5 / 6); M is not limited by the kernel.  tile_m = 16, 32 or 64 picks
+ * the positions per wave tile (0: the smallest tile that leaves half of the chip's SIMDs free); tile_n does not apply.  Anything
+ * else is AVCER_EINVAL: use 5 / 6.  The networks choose it while (M / 32) * (n / 16) wave tiles fit the chip's SIMDs in one
+ * round and M <= 4096 (api.hip prefer_skinny).
  * "sp32" storage = per aligned group of 32 channels, 32 fp16 hi values then 32 fp16 lo values (x = hi + lo), i.e. the
  * layout avcer_split_weights produces; 4 bytes per element. */
 typedef struct avcer_conv_desc {
@@ -240,7 +257,8 @@ typedef struct avcer_conv_desc {
      * only at the positions the next stage's stride-2 1x1 convolutions read.  0 / 1: one residual row per output row. */
     int32_t r_sub, r_h, r_w;
     int32_t tile_m;                  /* dtypes 7 / 8: positions per block tile, 0 = chosen by the library (whichever of 112 / 128
-                                        leaves the cheaper last round on the 512 block slots), 112 or 128.  A tuning knob like
+                                        leaves the cheaper last round on the 512 block slots), 112 or 128.  Dtypes 9 / 10:
+                                        positions per WAVE tile, 0 = chosen by the library, 16, 32 or 64.  A tuning knob like
                                         tile_n: an element's accumulation order, hence the result, does not depend on it. */
 } avcer_conv_desc;
 

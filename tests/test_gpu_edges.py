@@ -144,3 +144,49 @@ def test_nan_audio_window_is_not_an_overflow(engine_audio):
     out = eng.audio_forward(big, normalize=False, mode=MODE_F16X3)
     n = eng.x3_overflow_count(reset=True)
     assert n > 0 or torch.isfinite(out).all()  # LayerNorm may pull the values back into range: then nothing broke
+
+
+def test_guarded_call_is_not_charged_with_counts_left_by_earlier_work(engine_static, sd_static):
+    """`Engine.guarded` owns the range-contract counter for its call: an overflow left behind by an earlier UNGUARDED raw call
+    (or by a call that raised, or by abandoned side-stream work) must not force a needless fp32 repeat of an in-range call."""
+    from avcer_amd.models import StaticModel
+
+    eng = engine_static
+    x = torch.from_numpy(synth.face_frames(7, 2)).float().permute(0, 3, 1, 2).contiguous() - 100.0
+    eng.static_forward_nchw(x * 1.0e4, MODE_F16X3)                     # raw entry: leaves a count behind, nobody read it
+    model = StaticModel(eng, sd_static)
+    before = eng.x3_fallbacks
+    lg = model(x)                                                      # in range
+    assert eng.x3_fallbacks == before and torch.isfinite(lg).all()
+    assert torch.equal(lg, eng.static_forward_nchw(x, MODE_F16X3)[0])
+    assert eng.x3_overflow_count(reset=True) == 0
+
+
+def test_bneck_chain_refuses_a_pass_whose_trunk_leaves_the_32_bit_offset_range(engine):
+    """avcer_bneck_chain walks X / OUT [M][4 planes] with 32-bit byte offsets: 1400 frames of 55 x 55 at planes 64 is 4.3 GB of
+    trunk (T1 alone, 1.08 GB, would pass).  AVCER_EINVAL before anything is launched -- the pointers are never dereferenced."""
+    dev = engine.device
+    dummy = torch.zeros(64, dtype=torch.int16, device=dev)
+    b = torch.zeros(256, device=dev)
+    for planes, nb, hw in ((64, 1400, 55), (128, 2750, 28)):
+        with pytest.raises(AvcerError) as e:
+            engine.bneck_chain(planes, nb, hw, hw, dummy, dummy, dummy, dummy, dummy, b, dummy, b, dummy, b)
+        assert e.value.code == -1 and "4 GiB" in str(e.value)
+
+
+def test_front_and_back_pass_sizes_do_not_show_in_any_result(engine_static):
+    """avcer_set_static_batch / avcer_set_static_back_batch are scheduling knobs: 70 frames as front passes of 16 (the size the
+    library defaults to for residency in the memory-side cache) feeding ONE back pass, as 7 + 70, and as the single-pass schedule."""
+    eng = engine_static
+    frames = torch.from_numpy(synth.face_frames(99, 70))
+    try:
+        eng.set_static_batch(1024, back=0)
+        one = [t.cpu() for t in eng.static_forward(frames, MODE_F16X3)]
+        for front, back in ((16, 2048), (7, 70), (32, 33), (1024, 2048)):
+            eng.set_static_batch(front, back=back)
+            got = [t.cpu() for t in eng.static_forward(frames, MODE_F16X3)]
+            assert all(torch.equal(a, b) for a, b in zip(one, got)), (front, back)
+        with pytest.raises(AvcerError):
+            eng.set_static_batch(16, back=4096)
+    finally:
+        eng.set_static_batch(1024, back=0)

@@ -565,6 +565,49 @@ def test_x3_keeps_f32_grade_accuracy_with_activations_near_1e4(engine, dtype):
     assert err < 2e-6 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("mag", [1e-2, 1e-3])
+@pytest.mark.parametrize("dtype", [5, 7, 9])
+def test_x3_small_magnitude_activations_keep_the_absolute_bound(engine, dtype, mag):
+    """The OTHER end of the range contract (include/avcer_hip.h): a whole activation tensor of magnitude 1e-2 / 1e-3.  Below
+    2^-3 the lo half of a pair is an fp16 subnormal (quantum 2^-24), so an element carries an ABSOLUTE error of at most 2^-25
+    instead of the 2^-22 relative one -- 3e-6 relative at 1e-2, 3e-5 at 1e-3.  Asserted: (a) the stored pair is within 2^-25
+    of the f32 value (host split and the device's own epilogue split alike: dtype 4 writes what dtype 5 reads), (b) a
+    contraction over such a tensor is within sum_k |w_k| * 2^-25 of the exact result plus the f32 accumulation's own error --
+    the subnormal halves are neither flushed by the conversion nor by the MFMA."""
+    g = torch.Generator().manual_seed(int(1 / mag) + dtype)
+    m, k, n = 256, 512, 256
+    x = (torch.rand(m, k, generator=g) + 0.5) * mag * torch.where(torch.rand(m, k, generator=g) < 0.5, -1.0, 1.0)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    bound = 2.0 ** -25
+    assert (from_sp32(to_sp32(x)).double() - x.double()).abs().max().item() <= bound       # (a) host split
+    dev = engine.device
+    # (a) device split: an identity contraction in dtype 4 (f32 in -> sp32 out) stores x through the kernels' own sp_value path
+    eye = torch.eye(k)
+    d_id = _desc(batch=m, cin=k, x_stride_b=k, x_stride_h=k, x_stride_w=k, n=k, y_ld=k, r_ld=k)
+    xs = torch.zeros(m, 2 * k, dtype=torch.int16, device=dev)
+    engine.conv_gemm(d_id, 4, x.to(dev), engine.split_weight_rows(eye.to(dev)), None, None, None, xs)
+    torch.cuda.synchronize()
+    dev_split_err = (from_sp32(xs.cpu()).double() - x.double()).abs().max().item()
+    # the identity contraction itself re-adds hi + lo of x on the f32 accumulator: exact for one non-zero product per output
+    assert dev_split_err <= 2 * bound, dev_split_err
+    # (b) the contraction over the small tensor
+    d = _desc(batch=m, cin=k, x_stride_b=k, x_stride_h=k, x_stride_w=k, n=n, y_ld=n, r_ld=n, tile_m=0)
+    yd = torch.zeros(m, 2 * n, dtype=torch.int16, device=dev)
+    w_arg = engine.weight_frags(w.to(dev)) if dtype in (7, 9) else engine.split_weight_rows(w.to(dev))
+    engine.conv_gemm(d, dtype, to_sp32(x).to(dev), w_arg, None, None, None, yd)
+    torch.cuda.synchronize()
+    ref = x.double() @ w.double().t()
+    got = from_sp32(yd.cpu()).double()
+    err = (got - ref).abs().max().item()
+    budget = w.abs().sum(1).max().item() * bound + 2e-6 * ref.abs().max().item() + bound
+    rel = ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    print(f"dtype {dtype}, |x| ~ {mag:g}: pair error {dev_split_err:.2e} (2^-25 = {bound:.2e}); contraction max|err| {err:.2e} "
+          f"(budget {budget:.2e}), rms relative {rel:.2e}")
+    assert err <= budget
+    # and in practice far inside it: the element errors are independent, the sum grows with sqrt(K)
+    assert rel < (2e-6 if mag >= 1e-2 else 2e-5)
+
+
 def test_x3_overflow_is_nan_not_a_wrong_number(engine):
     """An sp32 OUTPUT beyond fp16's range: hi = +-inf, lo = x - inf = -+inf, hi + lo = NaN for every consumer."""
     m, k, n = 128, 64, 64

@@ -202,3 +202,34 @@ def test_sp32_host_view_roundtrip_and_layout():
     assert torch.isnan(from_sp32(to_sp32(torch.full((1, 32), 7.0e4)))).all()          # beyond fp16: inf + (-inf)
     tiny = torch.full((1, 32), 3.0e-5)                                                  # lo half is an fp16 subnormal
     assert float((from_sp32(to_sp32(tiny)) - tiny).abs().max()) <= 2.0 ** -25
+
+
+def test_library_carries_the_hash_of_its_sources_and_a_stale_binary_is_refused(tmp_path):
+    """avcer_amd/build.py embeds source_hash() into the .so (avcer_source_hash()); _lib.load() compares it with the tree's.
+    A source touched WITHOUT a rebuild -- simulated on a copy of the sources, the tree itself stays untouched -- no longer
+    matches the binary and the load is refused; the binary built from the tree loads."""
+    import shutil
+
+    from avcer_amd import _lib, build
+
+    build.build()
+    lib = ctypes.CDLL(build.LIB)
+    lib.avcer_source_hash.restype = ctypes.c_char_p
+    assert lib.avcer_source_hash().decode() == build.source_hash()
+    assert _lib.check_source_hash(lib, build.LIB) == build.source_hash()
+    # the same sources with one byte appended to one kernel file: what the tree would hash to after an edit
+    paths = []
+    for f in build.SOURCES + build.HEADERS:
+        dst = tmp_path / os.path.basename(f)
+        shutil.copy(os.path.join(build.CSRC, f), dst)
+        paths.append(str(dst))
+    with open(paths[0], "ab") as fh:
+        fh.write(b"\n// touched\n")
+    touched = build._digest(paths)
+    assert touched != build.source_hash()
+    with pytest.raises(RuntimeError, match="stale binary"):
+        _lib.check_source_hash(lib, build.LIB, tree_hash=touched)
+    # ... and build() would rebuild: its object stamps are content hashes, not mtimes
+    key_now = build._digest([os.path.join(build.CSRC, build.SOURCES[0])] + [os.path.join(build.CSRC, h) for h in build.HEADERS],
+                            build.FLAGS)
+    assert open(os.path.join(build.CSRC, build.SOURCES[0].replace(".hip", ".o")) + ".stamp").read() == key_now

@@ -25,11 +25,10 @@ MFMA_FAMILY = ("conv_gemm", "bneck_kernel", "bneck_tail2_kernel", "stem_pool")
 
 
 def kernel_source_hash():
-    """Same hash as bench.py: the figure is only valid for the kernels it was measured on."""
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "avcer_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "avcer_amd", "csrc", "*.h"))):
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    """Same hash as bench.py and the library itself (avcer_amd/build.py): the figure is only valid for the kernels it was measured on."""
+    sys.path.insert(0, ROOT)
+    from avcer_amd.build import source_hash
+    return source_hash()
 
 
 def per_kernel(dirname, counter):
