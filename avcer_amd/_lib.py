@@ -67,6 +67,8 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p, c_stream]),
     "avcer_face_decode": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_float, C.c_float, C.c_void_p, c_stream]),
+    "avcer_face_decode_batch": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_float, C.c_float, C.c_void_p, c_stream]),
     "avcer_crop_tiles": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                    C.c_void_p, c_stream]),
     "avcer_fuse": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,

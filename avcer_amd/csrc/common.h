@@ -162,7 +162,7 @@ int k_audio_chunks(avcer_ctx*, const float* wav, const int32_t* starts, const in
 int k_split_weights(avcer_ctx*, const float* w, bf16_t* out, size_t n, hipStream_t);
 int k_split_weight_rows(avcer_ctx*, const float* w, bf16_t* out, int n, int k, hipStream_t);
 int k_weight_frags(avcer_ctx*, const bf16_t* rows, bf16_t* out, int n, int k, hipStream_t);
-int k_face_decode(avcer_ctx*, const float* loc, const float* conf, const float* landms, const float* priors, int P, int im_h,
+int k_face_decode(avcer_ctx*, const float* loc, const float* conf, const float* landms, const float* priors, int T, int P, int im_h,
                   int im_w, float var0, float var1, float* dets, hipStream_t);
 int k_face_nms(avcer_ctx*, const float* dets, int T, int P, float conf_thresh, float nms_thresh, int nms_top_k, int top_k,
                float threshold, int32_t* order, int32_t* count, float* out, int32_t* out_n, hipStream_t);

@@ -272,6 +272,10 @@ __global__ void face_decode_kernel(const float* __restrict__ loc, const float* _
 #pragma clang fp contract(off)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
+    {   // grid.y = frame of a batch: every frame has its own P rows of loc / conf / landms / dets, the priors are shared
+        const long f = blockIdx.y;
+        loc += f * P * 4; conf += f * P * 2; landms += f * P * 10; dets += f * P * 15;
+    }
     const float4 pr = *reinterpret_cast<const float4*>(priors + 4L * i);
     const float4 l = *reinterpret_cast<const float4*>(loc + 4L * i);
     const float cx = pr.x + (l.x * var0) * pr.z;
@@ -330,6 +334,55 @@ __global__ void face_rank_kernel(const float* __restrict__ dets, int P, float co
     }
 }
 
+// The same order by SORTING (round 6): one workgroup per frame, the (score, prior index) keys of all P priors in LDS, a bitonic
+// sort of the next power of two.  The counting kernel above does P comparisons per candidate -- 90 M per 640 x 360 frame when
+// every prior is a candidate (synthetic detector weights; 14.7 ms per 750 frames, profiles/r06_face_kernel_stats_before.csv) --
+// the sort 105 compare-exchange passes over 16 K keys.  Key = the score's bits made monotone (sign flip), prior index + 1 in the
+// low word: a descending sort visits equal scores HIGHER index first, the rule above; non-candidates are key 0 and sink.
+constexpr int SORT_THREADS = 1024;
+constexpr int SORT_MAX = 16384;  // keys held in LDS (128 KiB); frames with more priors keep the counting kernel
+
+__global__ void __launch_bounds__(SORT_THREADS) face_sort_kernel(const float* __restrict__ dets, int P, int N, float conf_thresh,
+                                                                  int nms_top_k, int32_t* __restrict__ order, int32_t* __restrict__ count) {
+    extern __shared__ char sort_smem[];
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(sort_smem);
+    __shared__ int cnt;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const float* d = dets + (long)f * P * 15;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < N; i += SORT_THREADS) {
+        unsigned long long k = 0;
+        if (i < P) {
+            const float sc = d[15L * i + 4];
+            if (sc > conf_thresh) {
+                unsigned u = __float_as_uint(sc);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                k = ((unsigned long long)u << 32) | (unsigned)(i + 1);
+                ++mine;
+            }
+        }
+        key[i] = k;
+    }
+    if (mine) atomicAdd(&cnt, mine);
+    __syncthreads();
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < N / 2; t += SORT_THREADS) {
+                const int a = 2 * t - (t & (j - 1)), b = a + j;
+                const unsigned long long ka = key[a], kb = key[b];
+                const bool desc = (a & k) == 0;  // descending runs where bit k of the position is clear: the whole array at k = N
+                if (desc ? ka < kb : ka > kb) { key[a] = kb; key[b] = ka; }
+            }
+            __syncthreads();
+        }
+    }
+    const int n = min(cnt, nms_top_k);
+    for (int r = tid; r < n; r += SORT_THREADS) order[(long)f * nms_top_k + r] = (int)(unsigned)(key[r] & 0xffffffffu) - 1;
+    if (tid == 0) count[f] = cnt;
+}
+
 constexpr int NMS_THREADS = 1024;
 constexpr int NMS_MAX = 6144;  // boxes held in LDS: 5 floats + 1 flag byte each (126 KiB)
 
@@ -354,11 +407,16 @@ __global__ void __launch_bounds__(NMS_THREADS) face_nms_kernel(const float* __re
         bx[4 * n + a] = (x2 - x1 + 1.0f) * (y2 - y1 + 1.0f);
         dead[a] = 0;
     }
-    if (tid == 0) kept_n = 0;
     __syncthreads();
+    // The reference keeps every survivor and then takes keep[:top_k] (retina_face_predictor.py:96-100).  Boxes are visited in
+    // descending score order, so the first top_k kept ones ARE that prefix: the walk stops there (with every prior a
+    // candidate -- synthetic weights -- that is 750 of ~5000 kept boxes: a fifth of the barriers, a quarter of the IoUs).
+    const int cap = min(top_k, 1024);
+    int nkept = 0;  // uniform across the block
     for (int a = 0; a < n; ++a) {
         if (dead[a]) continue;  // uniform: every thread reads the same flag after the previous barrier
-        if (tid == 0 && kept_n < 1024) kept[kept_n++] = a;
+        if (tid == 0) kept[nkept] = a;
+        if (++nkept >= cap) break;
         const float x1 = bx[a], y1 = bx[n + a], x2 = bx[2 * n + a], y2 = bx[3 * n + a], ar = bx[4 * n + a];
         for (int b = a + 1 + tid; b < n; b += NMS_THREADS) {
             if (dead[b]) continue;
@@ -370,6 +428,8 @@ __global__ void __launch_bounds__(NMS_THREADS) face_nms_kernel(const float* __re
         }
         __syncthreads();
     }
+    if (tid == 0) kept_n = nkept;
+    __syncthreads();
     // dets[keep][:top_k], then the rows with score >= threshold (retina_face_predictor.py:96-108)
     const int nk = min(kept_n, min(top_k, 1024));
     __shared__ int out_rows;
@@ -1641,9 +1701,9 @@ int k_fuse(avcer_ctx* ctx, const float* stat, const float* dyn, const float* aud
     return AVCER_OK;
 }
 
-int k_face_decode(avcer_ctx* ctx, const float* loc, const float* conf, const float* landms, const float* priors, int P,
+int k_face_decode(avcer_ctx* ctx, const float* loc, const float* conf, const float* landms, const float* priors, int T, int P,
                   int im_h, int im_w, float var0, float var1, float* dets, hipStream_t st) {
-    face_decode_kernel<<<cdiv(P, 256), 256, 0, st>>>(loc, conf, landms, priors, P, (float)im_w, (float)im_h, var0, var1, dets);
+    face_decode_kernel<<<dim3(cdiv(P, 256), T), 256, 0, st>>>(loc, conf, landms, priors, P, (float)im_w, (float)im_h, var0, var1, dets);
     CHECK_LAUNCH(ctx, "face_decode");
     return AVCER_OK;
 }
@@ -1658,13 +1718,21 @@ int k_crop_tiles(avcer_ctx* ctx, const uint8_t* frames, int T, int H, int W, con
 int k_face_nms(avcer_ctx* ctx, const float* dets, int T, int P, float conf_thresh, float nms_thresh, int nms_top_k, int top_k,
                float threshold, int32_t* order, int32_t* count, float* out, int32_t* out_n, hipStream_t st) {
     if (nms_top_k > NMS_MAX) return set_err(ctx, AVCER_EINVAL, "face_nms: nms_top_k %d exceeds %d", nms_top_k, NMS_MAX);
-    if (hipMemsetAsync(count, 0, (size_t)T * 4, st) != hipSuccess) return set_err(ctx, AVCER_EHIP, "face_nms: memset failed");
-    face_rank_kernel<<<dim3(cdiv(P, 256), T), 256, 0, st>>>(dets, P, conf_thresh, nms_top_k, order, count);
-    CHECK_LAUNCH(ctx, "face_rank");
     static uint64_t attr_dev = 0;
     if (!((attr_dev >> (ctx->device & 63)) & 1)) {
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)face_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)face_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_MAX * 8));
         attr_dev |= 1ull << (ctx->device & 63);
+    }
+    if (P <= SORT_MAX) {
+        int N = 2;
+        while (N < P) N <<= 1;
+        face_sort_kernel<<<T, SORT_THREADS, (size_t)N * 8, st>>>(dets, P, N, conf_thresh, nms_top_k, order, count);
+        CHECK_LAUNCH(ctx, "face_sort");
+    } else {
+        if (hipMemsetAsync(count, 0, (size_t)T * 4, st) != hipSuccess) return set_err(ctx, AVCER_EHIP, "face_nms: memset failed");
+        face_rank_kernel<<<dim3(cdiv(P, 256), T), 256, 0, st>>>(dets, P, conf_thresh, nms_top_k, order, count);
+        CHECK_LAUNCH(ctx, "face_rank");
     }
     const size_t lds = (size_t)std::min(nms_top_k, P) * 21 + 16;
     face_nms_kernel<<<T, NMS_THREADS, lds, st>>>(dets, P, order, count, nms_top_k, nms_thresh, top_k, threshold, out, out_n);

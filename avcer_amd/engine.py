@@ -248,6 +248,19 @@ class Engine:
                                                float(variance[1]), _ptr(dets), self._stream()))
         return dets
 
+    def face_decode_batch(self, loc, conf, landms, priors, image_size, variance=(0.1, 0.2)):
+        """The same for T frames in one launch: loc [T,P,4], conf [T,P,2], landms [T,P,10] + priors [P,4] -> dets [T,P,15]."""
+        loc, conf = self._dev(loc, torch.float32), self._dev(conf, torch.float32)
+        landms, priors = self._dev(landms, torch.float32), self._dev(priors, torch.float32)
+        t, p = int(loc.shape[0]), int(priors.shape[0])
+        if tuple(loc.shape) != (t, p, 4) or tuple(conf.shape) != (t, p, 2) or tuple(landms.shape) != (t, p, 10) or priors.shape[1] != 4:
+            raise ValueError("face_decode_batch: loc [T,P,4], conf [T,P,2], landms [T,P,10], priors [P,4]")
+        dets = self._new(t, p, 15)
+        self._check(self.lib.avcer_face_decode_batch(self.ctx, _ptr(loc), _ptr(conf), _ptr(landms), _ptr(priors), t, p,
+                                                     int(image_size[0]), int(image_size[1]), float(variance[0]),
+                                                     float(variance[1]), _ptr(dets), self._stream()))
+        return dets
+
     def face_nms(self, dets, conf_thresh: float = 0.02, nms_thresh: float = 0.4, nms_top_k: int = 5000, top_k: int = 750,
                  threshold: float = 0.8):
         """dets [T,P,15] (face_decode output per frame) -> (rows [T,top_k,15], counts [T]) after the reference's confidence

@@ -78,15 +78,16 @@ class FaceDetections:
 
 
     def batch(self, loc, conf, landms, image_size) -> List[np.ndarray]:
-        """[T,P,*] network outputs of T frames -> one [k,15] array per frame: decode per frame, ONE NMS launch pair and
+        """[T,P,*] network outputs of T frames -> one [k,15] array per frame: ONE decode launch, ONE order + NMS launch pair and
         ONE device-to-host copy for the whole batch."""
         key = (int(image_size[0]), int(image_size[1]))
         if key not in self._priors_dev:
             self._priors_dev[key] = torch.from_numpy(np.array(prior_boxes(key))).to(self.engine.device)
-        dets = torch.stack([self.engine.face_decode(loc[t], conf[t], landms[t], self._priors_dev[key], key, CFG_RE50["variance"])
-                            for t in range(int(loc.shape[0]))])
+        dets = self.engine.face_decode_batch(loc, conf, landms, self._priors_dev[key], key, CFG_RE50["variance"])
         rows, cnt = self.engine.face_nms(dets, self.conf_thresh, self.nms_thresh, self.nms_top_k, self.top_k, self.threshold)
-        rows, cnt = rows.cpu().numpy(), cnt.cpu().numpy()
+        cnt = cnt.cpu().numpy()
+        most = int(cnt.max()) if len(cnt) else 0
+        rows = rows[:, :most].cpu().numpy() if most else None  # only the rows some frame kept cross to the host
         return [rows[t, :int(cnt[t])] if cnt[t] else np.empty((0, 15), dtype=np.float32) for t in range(len(cnt))]
 
 

@@ -87,6 +87,25 @@ def stem_border_shifts(w, scale, shift) -> np.ndarray:
     return out.astype(np.float32)
 
 
+def _fold_fused_weights(out, li: int, blocks: int) -> None:
+    """`*.wf` = weight rows times the BN scale, for the layers the x3 mode runs inside fused kernels (csrc/fused.hip), whose
+    epilogues only add the BN shift.  Shared by the static CNN and the detector body: a bottleneck WITHOUT spatial stride has the
+    same shape in both (video.py:43-60 puts a stage's stride on conv1 of its first block, torchvision on conv2 of the same block)."""
+    if li <= 2:  # stages that run as fused chains conv2 -> conv3 (+x) -> next conv1:
+        # stage 1 from its first block (stride 1; conv3 + downsample = c3d), stage 2 from its second block.
+        for b in range(0 if li == 1 else 1, blocks):
+            head = b == (0 if li == 1 else 1)  # conv1 of the chain's first block runs on its own (plain conv_gemm)
+            for i in (1, 2, 3):
+                if (i == 1 and head) or (i == 3 and b == 0):
+                    continue
+                k = f"l{li}.{b}.c{i}"
+                out[k + ".wf"] = np.ascontiguousarray(out[k + ".w"] * out[k + ".s"][:, None])
+    if li == 3:  # stage 3: conv3 (+x) of block b and conv1 of block b+1 share a launch (bneck_tail2_kernel), b = 1..blocks-2
+        for b in range(1, blocks - 1):
+            for k in (f"l{li}.{b}.c3", f"l{li}.{b + 1}.c1"):
+                out[k + ".wf"] = np.ascontiguousarray(out[k + ".w"] * out[k + ".s"][:, None])
+
+
 def pack_static(sd) -> "OrderedDict[str, np.ndarray]":
     """ResNet50(7) state_dict (architectures/video.py:93-166)."""
     sd = _unwrap(sd)
@@ -112,20 +131,7 @@ def pack_static(sd) -> "OrderedDict[str, np.ndarray]":
                 w3, s3, b3 = out.pop(f"{dst}.c3.w"), out.pop(f"{dst}.c3.s"), out.pop(f"{dst}.c3.b")
                 out[f"{dst}.c3d.w"] = np.ascontiguousarray(np.concatenate([w3 * s3[:, None], wd * s_d[:, None]], axis=1))
                 out[f"{dst}.c3d.b"] = (b3 + b_d).astype(np.float32)
-        if li <= 2:  # stages that run as fused chains conv2 -> conv3 (+x) -> next conv1 in the x3 mode (csrc/fused.hip):
-            # stage 1 from its first block (stride 1; conv3 + downsample = c3d), stage 2 from its second block.
-            # BN scale folded into the rows: the chain's epilogues only add the shift.
-            for b in range(0 if li == 1 else 1, blocks):
-                head = b == (0 if li == 1 else 1)  # conv1 of the chain's first block runs on its own (plain conv_gemm)
-                for i in (1, 2, 3):
-                    if (i == 1 and head) or (i == 3 and b == 0):
-                        continue
-                    k = f"l{li}.{b}.c{i}"
-                    out[k + ".wf"] = np.ascontiguousarray(out[k + ".w"] * out[k + ".s"][:, None])
-        if li == 3:  # stage 3: conv3 (+x) of block b and conv1 of block b+1 share a launch (bneck_tail2_kernel), b = 1..blocks-2
-            for b in range(1, blocks - 1):
-                for k in (f"l{li}.{b}.c3", f"l{li}.{b + 1}.c1"):
-                    out[k + ".wf"] = np.ascontiguousarray(out[k + ".w"] * out[k + ".s"][:, None])
+        _fold_fused_weights(out, li, blocks)
     out["fc1.w"], out["fc1.b"] = _f32(sd["fc1.weight"]), _f32(sd["fc1.bias"])
     out["fc2.w"], out["fc2.b"] = _f32(sd["fc2.weight"]), _f32(sd["fc2.bias"])
     return out
@@ -168,6 +174,7 @@ def pack_face(sd) -> "OrderedDict[str, np.ndarray]":
                 w3, s3, b3 = out.pop(f"{dst}.c3.w"), out.pop(f"{dst}.c3.s"), out.pop(f"{dst}.c3.b")
                 out[f"{dst}.c3d.w"] = np.ascontiguousarray(np.concatenate([w3 * s3[:, None], wd * s_d[:, None]], axis=1))
                 out[f"{dst}.c3d.b"] = (b3 + b_d).astype(np.float32)
+        _fold_fused_weights(out, li, blocks)  # the body's stride-1 bottlenecks run on the same fused kernels in the x3 mode
     for i in (1, 2, 3):
         out[f"fpn.o{i}.w"] = _conv_w(sd[f"fpn.output{i}.0.weight"])
         out[f"fpn.o{i}.s"], out[f"fpn.o{i}.b"] = _bn_fold(sd, f"fpn.output{i}.1", eps)

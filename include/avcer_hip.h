@@ -66,7 +66,7 @@ enum {
  *   2: avcer_conv_desc grew r_sub / r_h / r_w / tile_m, avcer_bneck_chain gained out_step, avcer_set_option left (round 3);
  *      split weight buffers carry a trailer and AVCER_MODE_BF16X3 became AVCER_MODE_F16X3 (round 4).
  *   3: avcer_x3_overflow_count, avcer_profile_read_families; avcer_bneck_chain gained w2_frags (round 5).
- *   4: avcer_source_hash, avcer_set_static_back_batch (round 6). */
+ *   4: avcer_source_hash, avcer_set_static_back_batch, avcer_face_decode_batch (round 6). */
 #define AVCER_ABI_VERSION 4
 int avcer_abi_version(void);
 /* Hash (16 hex digits) of the sources and headers this binary was compiled from, embedded at build time by
@@ -199,6 +199,11 @@ int avcer_face_nms(avcer_ctx* ctx, const float* dets, int n_frames, int n_priors
  *     avcer_static_forward.  A rect that is empty or leaves the frame yields an all-zero tile. */
 int avcer_face_decode(avcer_ctx* ctx, const float* loc, const float* conf, const float* landms, const float* priors,
                       int n_priors, int im_h, int im_w, float var0, float var1, float* dets, avcer_stream_t stream);
+/* avcer_face_decode for a batch of frames in one launch: loc [T,P,4], conf [T,P,2], landms [T,P,10] (what avcer_face_forward
+ * writes for T frames) -> dets [T,P,15]; the priors [P,4] are shared.  T <= 65535. */
+int avcer_face_decode_batch(avcer_ctx* ctx, const float* loc, const float* conf, const float* landms, const float* priors,
+                            int n_frames, int n_priors, int im_h, int im_w, float var0, float var1, float* dets,
+                            avcer_stream_t stream);
 int avcer_crop_tiles(avcer_ctx* ctx, const uint8_t* frames, int n_frames, int h, int w, const int32_t* rects, int n,
                      int swap_rb, uint8_t* tiles, avcer_stream_t stream);
 

@@ -97,6 +97,42 @@ def test_nms_kernel_matches_reference_keep_lists(engine):
         assert out[f, :int(cnt[f]), 5].cpu().numpy().astype(int).tolist() == keep.tolist()
 
 
+def test_nms_order_sort_and_counting_forms_agree(engine):
+    """The descending-score order comes from an LDS bitonic sort for frames of at most 16384 priors and from the counting kernel
+    beyond (1280 x 720: 37840 priors).  Same rule (ties: higher prior index first) -- checked on one score table with heavy ties,
+    negative scores and non-candidates, once as 16000 priors (sort) and once padded to 20000 (counting) with non-candidates."""
+    rng = np.random.default_rng(11)
+    n = 16000
+    xy = rng.uniform(0, 3000, (n, 2)).astype(np.float32)
+    wh = rng.uniform(5, 60, (n, 2)).astype(np.float32)
+    score = np.round(rng.uniform(-1.0, 0.2, n), 3).astype(np.float32)          # ~1300 candidates on ~100 distinct scores: ties everywhere
+    d = np.zeros((1, n, 15), np.float32)
+    d[0, :, :4], d[0, :, 4], d[0, :, 5] = np.concatenate([xy, xy + wh], 1), score, np.arange(n)
+    pad = np.zeros((1, 20000, 15), np.float32)
+    pad[0, :n] = d[0]
+    pad[0, n:, 4] = -5.0                                                       # below the floor
+    res = []
+    for rows in (d, pad):
+        out, cnt = engine.face_nms(rows, conf_thresh=0.1, nms_thresh=0.4, nms_top_k=5000, top_k=750, threshold=0.15)
+        res.append(out[0, :int(cnt[0]), 5].cpu().numpy().astype(int).tolist())
+    inds = np.where(score > 0.1)[0]
+    keep = inds[of.nms(d[0, inds, :5], 0.4, 5000, stable=True)][:750]
+    keep = keep[score[keep] >= 0.15]
+    assert res[0] == res[1] == keep.tolist() and len(keep) > 100
+
+
+def test_decode_batch_equals_per_frame_decode(engine):
+    size = tuple(int(v) for v in G["size_a"])
+    pri = of.prior_boxes(size)
+    rng = np.random.default_rng(2)
+    loc = np.stack([G["loc_a"], G["loc_a"][::-1].copy(), rng.normal(0, 1, G["loc_a"].shape).astype(np.float32)])
+    conf = np.stack([G["conf_a"], G["conf_a"][::-1].copy(), G["conf_a"]])
+    lm = np.stack([G["landms_a"], G["landms_a"][::-1].copy(), rng.normal(0, 1, G["landms_a"].shape).astype(np.float32)])
+    got = engine.face_decode_batch(loc, conf, lm, pri, size).cpu()
+    for t in range(3):
+        assert torch.equal(got[t], engine.face_decode(loc[t], conf[t], lm[t], pri, size).cpu())
+
+
 def test_detections_empty(engine):
     p = len(G["priors_a"])
     conf = np.tile(np.array([[1.0, 0.0]], dtype=np.float32), (p, 1))

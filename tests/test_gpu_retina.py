@@ -61,6 +61,29 @@ def test_batch_and_rgb_against_oracle(engine_face, sd_retina):
     assert engine_face.lib.avcer_face_num_priors(150, 214) == len(of.prior_boxes((150, 214))) == loc.shape[1]
 
 
+@pytest.mark.parametrize("h,w,n", [(150, 214, 3), (70, 33, 2), (360, 640, 2)])
+def test_x3_fused_body_against_oracle_and_fp32_mode(engine_face, sd_retina, h, w, n):
+    """The x3 mode runs the body's stride-1 bottlenecks on the fused chain / tail kernels of the recognition CNN (api.hip
+    face_forward_impl): odd extents (38 x 54 and 19 x 27 positions per frame in stages 1-2), a frame narrower than one tile row, and
+    the bench's 640 x 360 -- against the oracle where it finishes in seconds, against the exact-f32 mode of the library otherwise."""
+    frames = synth.video_frames(41, n, h, w)
+    loc, conf, lm = (t.cpu().numpy() for t in engine_face.face_forward(frames, MODE_F16X3))
+    l32, c32, m32 = (t.cpu().numpy() for t in engine_face.face_forward(frames, MODE_FP32))
+    assert np.isfinite(conf).all()
+    print(h, w, "x3 vs fp32 mode: max|dconf|", np.abs(conf - c32).max(), "max|dloc|", np.abs(loc - l32).max())
+    assert np.abs(conf - c32).max() < 1e-4 and np.abs(loc - l32).max() < 1e-3 and np.abs(lm - m32).max() < 1e-3
+    if h * w <= 150 * 214:
+        for i in range(n):
+            rl, rc, rm = orf.retina_forward(sd_retina, orf.preprocess(frames[i]))
+            assert np.abs(conf[i] - rc[0].numpy()).max() < 1e-4
+            assert np.abs(loc[i] - rl[0].numpy()).max() < 1e-3
+            assert np.abs(lm[i] - rm[0].numpy()).max() < 1e-3
+    # batch invariance of the fused forms: frame 1 alone
+    l1, c1, m1 = (t.cpu().numpy() for t in engine_face.face_forward(frames[1:2], MODE_F16X3))
+    np.testing.assert_array_equal(c1[0], conf[1])
+    np.testing.assert_array_equal(l1[0], loc[1])
+
+
 def test_predictor_chain_matches_oracle_chain(engine_face, sd_retina):
     frame = synth.video_frames(5, 1, 120, 160)[0]
     pred = ft.RetinaFacePredictor(engine_face, sd_retina, threshold=0.5, mode=MODE_FP32)
