@@ -44,6 +44,9 @@ struct avcer_ctx {
     int aud_classes = 0;
     int static_batch = 1024;  // frames per internal pass of the static CNN (4 GiB buffer-descriptor limit at f32)
     int static_back = 0;      // frames per back pass of the static CNN (0: two front passes; avcer_set_static_back_batch)
+    int static_lanes = 2;     // calls of 128-512 frames as two half-batches on two streams (avcer_set_static_lanes)
+    hipStream_t lane_stream = nullptr;  // the second lane's stream, created on first use, and its fork / join events
+    hipEvent_t lane_ev[2] = {nullptr, nullptr};
     int block_slots = 512;    // 2 x hipDeviceProp_t::multiProcessorCount: what grid_rounds() divides a grid by
     // grow-only workspace arenas (activations), one per pipeline
     DevBuf ws[8];

@@ -342,45 +342,77 @@ __global__ void face_rank_kernel(const float* __restrict__ dets, int P, float co
 constexpr int SORT_THREADS = 1024;
 constexpr int SORT_MAX = 16384;  // keys held in LDS (128 KiB); frames with more priors keep the counting kernel
 
-__global__ void __launch_bounds__(SORT_THREADS) face_sort_kernel(const float* __restrict__ dets, int P, int N, float conf_thresh,
+// NPT compare-exchanges per thread and pass (N = 2048 NPT keys): fully unrolled, branch-free, so that a pass is NPT pairs of
+// LDS reads in flight at once instead of a chain of dependent round trips
+template <int NPT>
+__device__ __forceinline__ void bitonic_desc(unsigned long long* key, int tid) {
+    constexpr int N = 2 * SORT_THREADS * NPT;
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            unsigned long long ka[NPT], kb[NPT];
+            int ia[NPT];
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const int t = tid + u * SORT_THREADS;
+                ia[u] = 2 * t - (t & (j - 1));
+                ka[u] = key[ia[u]];
+                kb[u] = key[ia[u] + j];
+            }
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                // descending runs where bit k of the position is clear: the whole array at k = N
+                const bool sw = ((ia[u] & k) == 0) ? ka[u] < kb[u] : ka[u] > kb[u];
+                key[ia[u]] = sw ? kb[u] : ka[u];
+                key[ia[u] + j] = sw ? ka[u] : kb[u];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(SORT_THREADS) face_sort_kernel(const float* __restrict__ dets, int P, float conf_thresh,
                                                                   int nms_top_k, int32_t* __restrict__ order, int32_t* __restrict__ count) {
-    extern __shared__ char sort_smem[];
-    unsigned long long* key = reinterpret_cast<unsigned long long*>(sort_smem);
+    extern __shared__ __align__(16) unsigned long long sort_keys[];
+    unsigned long long* key = sort_keys;
     __shared__ int cnt;
     const int f = blockIdx.x, tid = threadIdx.x;
     const float* d = dets + (long)f * P * 15;
     if (tid == 0) cnt = 0;
     __syncthreads();
-    int mine = 0;
-    for (int i = tid; i < N; i += SORT_THREADS) {
-        unsigned long long k = 0;
-        if (i < P) {
-            const float sc = d[15L * i + 4];
-            if (sc > conf_thresh) {
-                unsigned u = __float_as_uint(sc);
-                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-                k = ((unsigned long long)u << 32) | (unsigned)(i + 1);
-                ++mine;
+    // candidates only, compacted in arrival order (the sort fixes the order): a real detector leaves a few dozen of 9520 priors
+    // above the confidence floor, and the sort below then runs on 2048 keys instead of 16384
+    for (int i0 = 0; i0 < P; i0 += 4 * SORT_THREADS) {
+        float sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * SORT_THREADS + tid;
+            sc[u] = i < P ? d[15L * i + 4] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * SORT_THREADS + tid;
+            if (i < P && sc[u] > conf_thresh) {
+                unsigned v = __float_as_uint(sc[u]);
+                v = (v & 0x80000000u) ? ~v : (v | 0x80000000u);
+                key[atomicAdd(&cnt, 1)] = ((unsigned long long)v << 32) | (unsigned)(i + 1);
             }
         }
-        key[i] = k;
     }
-    if (mine) atomicAdd(&cnt, mine);
     __syncthreads();
-    for (int k = 2; k <= N; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < N / 2; t += SORT_THREADS) {
-                const int a = 2 * t - (t & (j - 1)), b = a + j;
-                const unsigned long long ka = key[a], kb = key[b];
-                const bool desc = (a & k) == 0;  // descending runs where bit k of the position is clear: the whole array at k = N
-                if (desc ? ka < kb : ka > kb) { key[a] = kb; key[b] = ka; }
-            }
-            __syncthreads();
-        }
+    const int c = cnt;
+    int N = 2 * SORT_THREADS;
+    while (N < c) N <<= 1;
+    for (int i = c + tid; i < N; i += SORT_THREADS) key[i] = 0ull;  // padding sinks to the end of a descending sort
+    __syncthreads();
+    switch (N / (2 * SORT_THREADS)) {
+        case 1: bitonic_desc<1>(key, tid); break;
+        case 2: bitonic_desc<2>(key, tid); break;
+        case 4: bitonic_desc<4>(key, tid); break;
+        default: bitonic_desc<8>(key, tid); break;
     }
-    const int n = min(cnt, nms_top_k);
+    const int n = min(c, nms_top_k);
     for (int r = tid; r < n; r += SORT_THREADS) order[(long)f * nms_top_k + r] = (int)(unsigned)(key[r] & 0xffffffffu) - 1;
-    if (tid == 0) count[f] = cnt;
+    if (tid == 0) count[f] = c;
 }
 
 constexpr int NMS_THREADS = 1024;
@@ -423,7 +455,11 @@ __global__ void __launch_bounds__(NMS_THREADS) face_nms_kernel(const float* __re
             const float w = fmaxf(0.0f, fminf(x2, bx[2 * n + b]) - fmaxf(x1, bx[b]) + 1.0f);
             const float h = fmaxf(0.0f, fminf(y2, bx[3 * n + b]) - fmaxf(y1, bx[n + b]) + 1.0f);
             const float inter = w * h;
-            const float ovr = inter / (ar + bx[4 * n + b] - inter);
+            const float uni = ar + bx[4 * n + b] - inter;
+            // disjoint boxes (almost every pair): 0 / union is +-0 <= threshold for every non-zero union -- no division needed
+            // to know it; a zero union (0 / 0 = NaN, dropped by numpy's `ovr <= thresh`) takes the division like the rest
+            if (inter == 0.0f && uni != 0.0f && uni == uni && nms_thresh >= 0.0f) continue;
+            const float ovr = inter / uni;
             if (!(ovr <= nms_thresh)) dead[b] = 1;
         }
         __syncthreads();
@@ -1725,9 +1761,9 @@ int k_face_nms(avcer_ctx* ctx, const float* dets, int T, int P, float conf_thres
         attr_dev |= 1ull << (ctx->device & 63);
     }
     if (P <= SORT_MAX) {
-        int N = 2;
+        int N = 2 * SORT_THREADS;  // LDS for the worst case (every prior a candidate); the kernel sorts the next power of two of ITS count
         while (N < P) N <<= 1;
-        face_sort_kernel<<<T, SORT_THREADS, (size_t)N * 8, st>>>(dets, P, N, conf_thresh, nms_top_k, order, count);
+        face_sort_kernel<<<T, SORT_THREADS, (size_t)N * 8, st>>>(dets, P, conf_thresh, nms_top_k, order, count);
         CHECK_LAUNCH(ctx, "face_sort");
     } else {
         if (hipMemsetAsync(count, 0, (size_t)T * 4, st) != hipSuccess) return set_err(ctx, AVCER_EHIP, "face_nms: memset failed");

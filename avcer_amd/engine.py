@@ -136,6 +136,10 @@ class Engine:
         if back is not None:
             self._check(self.lib.avcer_set_static_back_batch(self.ctx, int(back)))
 
+    def set_static_lanes(self, lanes: int):
+        """2 (default): static-CNN calls of 128-512 frames run as two half-batches on two streams; 1: always serial."""
+        self._check(self.lib.avcer_set_static_lanes(self.ctx, int(lanes)))
+
     # ------------------------------------------------------------------ forward passes
     def static_forward(self, frames_u8, mode: int = MODE_DEFAULT):
         """frames u8 [N,H,W,3] RGB -> (logits [N,7], probs [N,7], feats [N,512] pre-ReLU)."""
