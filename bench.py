@@ -392,6 +392,23 @@ def config_benches(pipe, modes, pk, device, iters=5):
     frames = torch.from_numpy(synth.face_frames(1, 256)).to(device)
     run("static_b256", lambda m: eng.static_forward(frames, m), 256, GFLOP_STATIC_FRAME, GFLOP_STATIC_FRAME - 2 * 512 * 7e-9,
         "frames", ("x3", "bf16", "fp32"))
+    # the same call on one stream alone (avcer_set_static_lanes(1)): what the two-lane split of 128-512-frame calls buys
+    eng.set_static_lanes(1)
+    try:
+        for name in ("x3", "fp32"):
+            for _ in range(2):
+                eng.static_forward(frames, modes[name])
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                eng.static_forward(frames, modes[name])
+            torch.cuda.synchronize(device)
+            out["static_b256"][name]["ms_one_lane"] = (time.perf_counter() - t0) / iters * 1e3
+    finally:
+        eng.set_static_lanes(2)
+    out["static_b256"]["lanes_note"] = ("`ms` = the library default: the 256 frames as two half-batches on two HIP streams (bit-identical "
+                                        "results); `ms_one_lane` = avcer_set_static_lanes(1); the roofline sub-object comes from a "
+                                        "serial evented pass either way")
     del frames
     wav = torch.from_numpy(synth.waveforms(2, 128, T_AUDIO)).to(device)
     run("audio_b128", lambda m: eng.audio_forward(wav, True, m), 128, GFLOP_AUDIO_CHUNK,
@@ -473,10 +490,47 @@ def run_inference_bench(pipe, modes, device, do_cpu, seconds=30, fps=25, h=360, 
                 torch.cuda.synchronize(device)
                 dts.append(time.perf_counter() - t0)
             dtd = sorted(dts)[1]
+            # stage 0 on its own, with per-family events (serial: nothing else is queued beside it)
+            det = detector.det
+            det.batch(frames, rgb=False)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            det.batch(frames, rgb=False)
+            torch.cuda.synchronize(device)
+            det_ms = (time.perf_counter() - t0) * 1e3
+            eng.gemm_stats(reset=True)
+            eng.profile_enable(True)
+            det.batch(frames, rgb=False)
+            torch.cuda.synchronize(device)
+            fams = eng.profile_read_families()
+            eng.profile_enable(False)
+            _, det_flops = eng.gemm_stats(reset=True)
+            fam_rows, mfma_ms = [], 0.0
+            for fam, (ms, n_l, fl, by) in fams.items():
+                if not n_l:
+                    continue
+                mfma_ms += ms
+                bound = FAMILY_BOUND.get(fam, "mfma")
+                tf, gbs = fl / ms / 1e9, by / ms / 1e6
+                ent = {"kernel": fam, "ms": ms, "launches": n_l, "bound": bound, "algorithmic_tflops": tf, "compulsory_gb_per_s": gbs}
+                if bound == "hbm":
+                    ent.update(achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
+                else:
+                    ent.update(achieved=tf, peak=PEAK_FALLBACK["x3"], unit="TFLOP/s", frac=tf / PEAK_FALLBACK["x3"],
+                               frac_executed=3 * tf / PEAK_FALLBACK["x3"])
+                fam_rows.append(ent)
             out["with_detector"] = {"mode": name, "s": dtd, "frames_per_s": n / dtd, "real_time_factor": dtd / seconds,
                                     "detector": "RetinaFace-R50 network + decode + device NMS over all frames (synthetic weights: "
-                                                f"{detector.found} boxes kept; the scripted track is used behind it)",
-                                    "detector_gflop_per_frame": 51.5}
+                                                f"{detector.found} boxes kept -- EVERY prior is a candidate, the worst case of the "
+                                                "order + NMS kernels; the scripted track is used behind it)",
+                                    "detector_gflop_per_frame": det_flops / n / 1e9,
+                                    "detector_alone": {"ms": det_ms, "mfma_kernel_ms": mfma_ms,
+                                                       "other_ms": det_ms - mfma_ms,
+                                                       "other": "face_pre, max-pool, upsample-add, heads, decode, order, NMS, device-to-host rows",
+                                                       "roofline": {"bound": "mfma", "achieved": det_flops / mfma_ms / 1e9, "peak": PEAK_FALLBACK["x3"],
+                                                                    "unit": "TFLOP/s", "frac": det_flops / mfma_ms / 1e9 / PEAK_FALLBACK["x3"],
+                                                                    "frac_of_peak_executed": 3 * det_flops / mfma_ms / 1e9 / PEAK_FALLBACK["x3"]},
+                                                       "per_family": fam_rows}}
     if do_cpu:
         from oracle import audio as oa
         from oracle import face as oface
