@@ -70,6 +70,9 @@ SIGNATURES = {
                                     C.c_float, C.c_float, C.c_void_p, c_stream]),
     "avcer_face_decode_batch": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_float, C.c_float, C.c_void_p, c_stream]),
+    "avcer_track_faces": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                    C.c_void_p, C.POINTER(C.c_int64)]),
+    "avcer_lsap": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "avcer_crop_tiles": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                    C.c_void_p, c_stream]),
     "avcer_fuse": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,

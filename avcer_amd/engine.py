@@ -281,6 +281,25 @@ class Engine:
                                             int(top_k), float(threshold), _ptr(out), _ptr(cnt), self._stream()))
         return out, cnt
 
+    def track_faces(self, dets_per_frame, frame_w: int, frame_h: int, iou_threshold: float = 0.4, minimum_face_size: float = 0.0):
+        """The tracker + crop-rectangle loop of `VideoPredictor.process` for a whole video in one native HOST call
+        (csrc/track.hip): per-frame detection arrays [k, >= 4] -> records int64 [n, 6] = frame, track directory, x0, y0, x1, y1.
+        Raises ValueError where the reference raises (zero-area detection, empty crop)."""
+        counts = np.fromiter((len(d) for d in dets_per_frame), dtype=np.int32, count=len(dets_per_frame))
+        total = int(counts.sum())
+        boxes = np.zeros((max(total, 1), 4), dtype=np.float32)
+        if total:
+            np.concatenate([np.asarray(d, dtype=np.float32).reshape(len(d), -1)[:, :4] for d in dets_per_frame if len(d)], out=boxes[:total])
+        rec = np.empty((max(total, 1), 6), dtype=np.int64)
+        n = C.c_int64(0)
+        rc = self.lib.avcer_track_faces(self.ctx, boxes.ctypes.data_as(C.c_void_p), 4, counts.ctypes.data_as(C.c_void_p), len(counts),
+                                        int(frame_w), int(frame_h), float(iou_threshold), float(minimum_face_size),
+                                        rec.ctypes.data_as(C.c_void_p), C.byref(n))
+        if rc == -1:
+            raise ValueError(self.lib.avcer_last_error(self.ctx).decode("utf-8", "replace"))
+        self._check(rc)
+        return rec[:int(n.value)]
+
     def crop_tiles(self, frames_u8, rects, bgr: bool = True):
         """frames u8 [T,H,W,3] + rects i32 [n,5] (frame, x0, y0, x1, y1; validated by the caller) -> RGB tiles [n,224,224,3]."""
         x = self._dev(frames_u8, torch.uint8)

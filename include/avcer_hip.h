@@ -66,7 +66,8 @@ enum {
  *   2: avcer_conv_desc grew r_sub / r_h / r_w / tile_m, avcer_bneck_chain gained out_step, avcer_set_option left (round 3);
  *      split weight buffers carry a trailer and AVCER_MODE_BF16X3 became AVCER_MODE_F16X3 (round 4).
  *   3: avcer_x3_overflow_count, avcer_profile_read_families; avcer_bneck_chain gained w2_frags (round 5).
- *   4: avcer_source_hash, avcer_set_static_back_batch, avcer_set_static_lanes, avcer_face_decode_batch (round 6). */
+ *   4: avcer_source_hash, avcer_set_static_back_batch, avcer_set_static_lanes, avcer_face_decode_batch, avcer_track_faces,
+ *      avcer_lsap (round 6). */
 #define AVCER_ABI_VERSION 4
 int avcer_abi_version(void);
 /* Hash (16 hex digits) of the sources and headers this binary was compiled from, embedded at build time by
@@ -212,6 +213,20 @@ int avcer_face_decode_batch(avcer_ctx* ctx, const float* loc, const float* conf,
                             avcer_stream_t stream);
 int avcer_crop_tiles(avcer_ctx* ctx, const uint8_t* frames, int n_frames, int h, int w, const int32_t* rects, int n,
                      int swap_rb, uint8_t* tiles, avcer_stream_t stream);
+
+/* The face tracker between detector and tiles, for a whole video in ONE call -- HOST code and HOST pointers (the tracker is
+ * sequential in time and sees a handful of boxes per frame; the reference runs it on the host too):
+ *   ref: data/face_detection/ibug/face_detection/utils/simple_face_tracker.py:10-90 (IoU distance, Hungarian assignment by
+ *        scipy.optimize.linear_sum_assignment, tracklets dropped on an empty frame), data/get_face_images.py:38-63
+ *        (VideoPredictor.process: tracker per frame, crop rectangle fr[y0:y1, x0:x1] of every detection).
+ * dets host f32 [sum(counts), ld] (x0, y0, x1, y1 first; ld >= 4), counts host i32 [n_frames] detections per frame ->
+ * records host i64 [sum(counts), 6] = frame, track directory (track id - 1), x0, y0, x1, y1 (the clamped half-open crop) in the
+ * reference's write order, *n_records rows.  AVCER_EINVAL where the reference raises: a zero-area detection (no track id) or an
+ * empty crop; avcer_last_error names the frame (ctx may be NULL: no device is touched, errors are then the code alone).  avcer_lsap is the assignment step on its own (scipy's algorithm and
+ * tie-breaking; cost host f64 [nr, nc] -> min(nr, nc) pairs sorted by row), exported for the host-logic tests. */
+int avcer_track_faces(avcer_ctx* ctx, const float* dets_host, int ld, const int32_t* counts_host, int n_frames, int frame_w,
+                      int frame_h, double iou_threshold, double minimum_face_size, int64_t* records_host, int64_t* n_records);
+int avcer_lsap(int nr, int nc, const double* cost_host, int32_t* rows_host, int32_t* cols_host);
 
 /* Probability fusion and compound-expression rule.
  *   ref: run.py:25-165 (get_c_expr_db_pred), data/utils.py:125-127 (softmax), :222-241 (get_compound_expression)

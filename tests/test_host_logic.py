@@ -233,3 +233,126 @@ def test_library_carries_the_hash_of_its_sources_and_a_stale_binary_is_refused(t
     key_now = build._digest([os.path.join(build.CSRC, build.SOURCES[0])] + [os.path.join(build.CSRC, h) for h in build.HEADERS],
                             build.FLAGS)
     assert open(os.path.join(build.CSRC, build.SOURCES[0].replace(".hip", ".o")) + ".stamp").read() == key_now
+
+
+def _host_lib():
+    from avcer_amd import _lib, build
+
+    build.build()
+    lib = ctypes.CDLL(build.LIB)
+    for name in ("avcer_lsap", "avcer_track_faces"):
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = _lib.SIGNATURES[name]
+    return lib
+
+
+def test_native_assignment_equals_scipy_including_ties():
+    """csrc/track.hip lsap = scipy.optimize.linear_sum_assignment (the tracker's Hungarian step,
+    simple_face_tracker.py:60): same pairs in the same order on random rectangular matrices AND on small-integer matrices,
+    where many assignments share the optimal cost and only the algorithm's own tie-breaking decides."""
+    from scipy.optimize import linear_sum_assignment
+
+    lib = _host_lib()
+    rng = np.random.default_rng(0)
+    cases = 0
+    for trial in range(600):
+        nr, nc = int(rng.integers(0, 8)), int(rng.integers(0, 8))
+        kind = trial % 3
+        if kind == 0:
+            cost = rng.uniform(0, 1, (nr, nc))
+        elif kind == 1:
+            cost = rng.integers(0, 3, (nr, nc)).astype(np.float64)          # ties everywhere
+        else:
+            cost = np.where(rng.uniform(size=(nr, nc)) < 0.5, 2.0 * min(nr, nc), rng.uniform(0, 0.6, (nr, nc)))  # the tracker's shape
+        cost = np.ascontiguousarray(cost, dtype=np.float64)
+        k = min(nr, nc)
+        rows, cols = np.full(max(k, 1), -1, np.int32), np.full(max(k, 1), -1, np.int32)
+        assert lib.avcer_lsap(nr, nc, cost.ctypes.data_as(ctypes.c_void_p), rows.ctypes.data_as(ctypes.c_void_p),
+                              cols.ctypes.data_as(ctypes.c_void_p)) == 0
+        r_ref, c_ref = linear_sum_assignment(cost)
+        assert rows[:k].tolist() == r_ref.tolist() and cols[:k].tolist() == c_ref.tolist(), (trial, cost)
+        cases += 1
+    assert cases == 600
+
+
+def _track_native(lib, dets, w, h, iou=0.4, min_size=0.0):
+    counts = np.array([len(d) for d in dets], np.int32)
+    total = int(counts.sum())
+    boxes = np.zeros((max(total, 1), 4), np.float32)
+    if total:
+        boxes[:total] = np.concatenate([np.asarray(d, np.float32).reshape(len(d), -1)[:, :4] for d in dets if len(d)])
+    rec = np.empty((max(total, 1), 6), np.int64)
+    n = ctypes.c_int64(0)
+    rc = lib.avcer_track_faces(None, boxes.ctypes.data_as(ctypes.c_void_p), 4, counts.ctypes.data_as(ctypes.c_void_p), len(counts), w, h,
+                               iou, min_size, rec.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n))
+    return rc, rec[:n.value]
+
+
+def _track_python(dets, w, h, iou=0.4, min_size=0.0):
+    """The per-frame loop the native call replaces: SimpleFaceTracker + crop_rects of avcer_amd/face_tiles.py, which are
+    themselves pinned to the reference's SimpleFaceTracker / VideoPredictor.process by tests/test_face_cpu.py."""
+    from avcer_amd.face_tiles import SimpleFaceTracker, crop_rects
+
+    tr = SimpleFaceTracker(iou, min_size)
+    recs = []
+    for t, d in enumerate(dets):
+        d = np.asarray(d, np.float32).reshape(-1, 15)
+        tids = tr(d)
+        for (x0, y0, x1, y1), tid in zip(crop_rects(d, w, h), tids):
+            if tid is None or x1 <= x0 or y1 <= y0:
+                return -1, None
+            recs.append((t, tid - 1, x0, y0, x1, y1))
+    return 0, np.array(recs, np.int64).reshape(-1, 6)
+
+
+def test_native_tracker_equals_the_python_tracker_frame_by_frame():
+    """avcer_track_faces (one native host call per video) against the Python mirror of the reference's tracker driven frame by
+    frame: several faces drifting, crossing, leaving and re-entering, empty frames (every tracklet dropped), boxes hanging over
+    the frame edges (negative and beyond-size corners: Python's slice rules), a minimum face size -- and the two failure cases."""
+    lib = _host_lib()
+    rng = np.random.default_rng(1)
+    w, h = 640, 360
+    for trial in range(40):
+        nf = int(rng.integers(3, 7))
+        centres = rng.uniform([0, 0], [w, h], (nf, 2))
+        vel = rng.normal(0, 6, (nf, 2))
+        size = rng.uniform(20, 120, nf)
+        dets = []
+        for t in range(60):
+            centres += vel + rng.normal(0, 2, centres.shape)
+            rows = []
+            for f in range(nf):
+                if rng.uniform() < 0.15:
+                    continue                                                   # missed detection
+                cx, cy = centres[f]
+                s = size[f] * rng.uniform(0.9, 1.1)
+                rows.append([cx - s / 2, cy - s / 2, cx + s / 2, cy + s / 2, 0.9] + [0.0] * 10)
+            if rng.uniform() < 0.08:
+                rows = []                                                      # a frame without faces
+            order = rng.permutation(len(rows))
+            dets.append(np.array([rows[i] for i in order], np.float32).reshape(-1, 15))
+        min_size = 0.0 if trial % 2 == 0 else 40.0
+        rc_p, rec_p = _track_python(dets, w, h, 0.4, min_size)
+        rc_n, rec_n = _track_native(lib, dets, w, h, 0.4, min_size)
+        assert rc_n == rc_p, (trial, rc_n, rc_p)
+        if rc_p == 0:
+            np.testing.assert_array_equal(rec_n, rec_p)
+    # the reference's two failure cases come back as AVCER_EINVAL (ValueError through Engine.track_faces)
+    zero_area = [np.array([[10, 10, 10, 50, 0.9] + [0] * 10], np.float32)]
+    assert _track_native(lib, zero_area, w, h)[0] == -1 and _track_python(zero_area, w, h)[0] == -1
+    outside = [np.array([[700, 10, 760, 50, 0.9] + [0] * 10], np.float32)]
+    assert _track_native(lib, outside, w, h)[0] == -1 and _track_python(outside, w, h)[0] == -1
+
+
+def test_native_tracker_reproduces_the_reference_generated_records():
+    from test_face_cpu import G, golden_script
+
+    lib = _host_lib()
+    frames_h, frames_w = (int(v) for v in G["track_hw"]) if "track_hw" in G else (None, None)
+    script = golden_script()
+    if frames_h is None:
+        from test_face_cpu import golden_frames
+        frames_h, frames_w = golden_frames().shape[1:3]
+    rc, rec = _track_native(lib, script, frames_w, frames_h)
+    assert rc == 0
+    np.testing.assert_array_equal(rec, G["track_records"])
