@@ -12,6 +12,13 @@ Arms (patched copies of csrc/fused.hip; results of the patched kernels are wrong
     noRes     the residual rows of X are not loaded               (1 KiB)
     noT1N     the next block's conv1 output is not stored         (256 B)
     noHBM     noOUT + noRes + noT1N: only T1 is read              (256 B) -- the kernel's compute side alone
+    trunk3    round 6: the CEILING of a 3-byte trunk (fp16 hi + 8-bit lo; the round-5 review's byte cut).  The residual rows are read and
+              the OUT rows written at 3 bytes per element in a compact layout (row pitch 3 x 4P bytes: the hi halves of a row
+              first, 16 bytes per lane, then its 8-bit lo halves, 8 bytes per lane; whole 64- / 32-byte pieces per lane group) with
+              NO pack / unpack arithmetic: the byte traffic of the format at zero VALU cost.  A real pack costs ~ +4.5 VALU per
+              stored value, an unpack ~ +2.5 per loaded one (exponent extraction, scale, convert, byte pack).
+
+    python tools/chain_ablate.py build [arm ...]; python tools/chain_ablate.py run [arm ...]
 """
 import os
 import shutil
@@ -21,7 +28,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LAB = os.path.join(ROOT, "tools", "lab")
-ARMS = ("product", "noMFMA", "noOUT", "noRes", "noT1N", "noHBM", "noW2", "noWS", "noPatch")
+ARMS = ("product", "noMFMA", "noOUT", "noRes", "noT1N", "noHBM", "noW2", "noWS", "noPatch", "trunk3")
+ONLY = tuple(a for a in sys.argv[2:] if a in ARMS) if len(sys.argv) > 2 and sys.argv[1] in ("build", "run") else ()
+if ONLY:
+    ARMS = ONLY
 
 
 def must(s, a, b):
@@ -44,6 +54,16 @@ def patch(src, arm):
                     "                l[t] = *reinterpret_cast<const uint4*>(rp + 64);\n",
                  "                const char* rp = p.X + (size_t)x_row[t] + G * 128;\n                h[t] = l[t] = make_uint4(0u, 0u, 0u, 0u);\n"
                  "                if (p.M < 0) { h[t] = *reinterpret_cast<const uint4*>(rp); l[t] = *reinterpret_cast<const uint4*>(rp + 64); }\n")
+    if arm == "trunk3":
+        s = must(s, "                char* yp = p.OUT + (size_t)(SUB == 1 ? x_row[t] : o_row[SUB > 1 ? t : 0]) + G * 128;\n"
+                    "                *reinterpret_cast<spx8_t*>(yp) = oh[t];\n                *reinterpret_cast<spx8_t*>(yp + 64) = ol[t];\n",
+                 "                char* yp = p.OUT + (size_t)m_row[t] * (4 * P * 3);\n"
+                 "                *reinterpret_cast<spx8_t*>(yp + G * 64 + 16 * g) = oh[t];\n"
+                 "                { const uint4 l4_ = __builtin_bit_cast(uint4, ol[t]); *reinterpret_cast<uint2*>(yp + 8 * P + G * 32 + 8 * g) = make_uint2(l4_.x, l4_.y); }\n")
+        s = must(s, "                const char* rp = p.X + (size_t)x_row[t] + G * 128;\n                h[t] = *reinterpret_cast<const uint4*>(rp);\n"
+                    "                l[t] = *reinterpret_cast<const uint4*>(rp + 64);\n",
+                 "                const char* rp = p.X + (size_t)m_row[t] * (4 * P * 3);\n                h[t] = *reinterpret_cast<const uint4*>(rp + G * 64 + 16 * g);\n"
+                 "                { const uint2 l2_ = *reinterpret_cast<const uint2*>(rp + 8 * P + G * 32 + 8 * g); l[t] = make_uint4(l2_.x, l2_.y, 0u, 0u); }\n")
     # arms of the spatial-tile form (run with the fragment copy): no conv2 weight loads after the first three K-steps, no
     # weight DMA in the streaming phase after group 0, no halo-patch DMA
     if arm == "noW2":
