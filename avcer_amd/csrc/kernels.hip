@@ -416,59 +416,74 @@ __global__ void __launch_bounds__(SORT_THREADS) face_sort_kernel(const float* __
 }
 
 constexpr int NMS_THREADS = 1024;
-constexpr int NMS_MAX = 6144;  // boxes held in LDS: 5 floats + 1 flag byte each (126 KiB)
+constexpr int NMS_MAX = 6144;  // API bound on nms_top_k (the kernel itself no longer holds all boxes at once)
 
+// Greedy NMS of one frame per workgroup, in CHUNKS of 1024 boxes of the descending-score order (round 6).  The reference keeps
+// every survivor and then takes keep[:top_k] (retina_face_predictor.py:96-100); boxes are visited in score order, so the first top_k
+// kept ones ARE that prefix and nothing behind the chunk that completes them is ever looked at.  Per chunk: every thread owns one
+// box; it is first tested against the boxes kept from earlier chunks (their corners sit in LDS), then the chunk is walked in
+// order with one barrier per kept box and at most ONE IoU per thread and kept box.  The first form of this kernel held all
+// nms_top_k boxes in 126 KiB of LDS (one block per CU) and tested every later box against every kept one: with every prior a
+// candidate (synthetic detector weights) 4.4-6.7 ms per 750 frames, here the walk ends inside the first chunk and three blocks
+// share a CU.  f32 arithmetic in numpy's evaluation order, contraction off: the keep decisions are the reference's.
 __global__ void __launch_bounds__(NMS_THREADS) face_nms_kernel(const float* __restrict__ dets, int P, const int32_t* __restrict__ order,
                                                                 const int32_t* __restrict__ count, int nms_top_k, float nms_thresh,
                                                                 int top_k, float threshold, float* __restrict__ out,
                                                                 int32_t* __restrict__ out_n) {
 #pragma clang fp contract(off)
-    extern __shared__ char nms_smem[];
+    __shared__ float cx1[NMS_THREADS], cy1[NMS_THREADS], cx2[NMS_THREADS], cy2[NMS_THREADS], car[NMS_THREADS];  // the chunk
+    __shared__ float kx1[1024], ky1[1024], kx2[1024], ky2[1024], kar[1024];                                       // kept so far
+    __shared__ unsigned char cdead[NMS_THREADS];
+    __shared__ int kept[1024];  // position in the score order of every kept box (beyond top_k they are never reported)
+    __shared__ int out_rows;
     const int f = blockIdx.x, tid = threadIdx.x;
     const int n = min(count[f], nms_top_k);
-    float* bx = reinterpret_cast<float*>(nms_smem);       // [5][n]: x1, y1, x2, y2, area
-    unsigned char* dead = reinterpret_cast<unsigned char*>(bx + 5 * (long)n);
-    __shared__ int kept_n;
-    __shared__ int kept[1024];                            // kept boxes beyond top_k are never reported
     const float* d = dets + (long)f * P * 15;
     const int32_t* ord = order + (long)f * nms_top_k;
-    for (int a = tid; a < n; a += NMS_THREADS) {
-        const float* r = d + 15L * ord[a];
-        const float x1 = r[0], y1 = r[1], x2 = r[2], y2 = r[3];
-        bx[a] = x1; bx[n + a] = y1; bx[2 * n + a] = x2; bx[3 * n + a] = y2;
-        bx[4 * n + a] = (x2 - x1 + 1.0f) * (y2 - y1 + 1.0f);
-        dead[a] = 0;
-    }
-    __syncthreads();
-    // The reference keeps every survivor and then takes keep[:top_k] (retina_face_predictor.py:96-100).  Boxes are visited in
-    // descending score order, so the first top_k kept ones ARE that prefix: the walk stops there (with every prior a
-    // candidate -- synthetic weights -- that is 750 of ~5000 kept boxes: a fifth of the barriers, a quarter of the IoUs).
     const int cap = min(top_k, 1024);
     int nkept = 0;  // uniform across the block
-    for (int a = 0; a < n; ++a) {
-        if (dead[a]) continue;  // uniform: every thread reads the same flag after the previous barrier
-        if (tid == 0) kept[nkept] = a;
-        if (++nkept >= cap) break;
-        const float x1 = bx[a], y1 = bx[n + a], x2 = bx[2 * n + a], y2 = bx[3 * n + a], ar = bx[4 * n + a];
-        for (int b = a + 1 + tid; b < n; b += NMS_THREADS) {
-            if (dead[b]) continue;
-            const float w = fmaxf(0.0f, fminf(x2, bx[2 * n + b]) - fmaxf(x1, bx[b]) + 1.0f);
-            const float h = fmaxf(0.0f, fminf(y2, bx[3 * n + b]) - fmaxf(y1, bx[n + b]) + 1.0f);
-            const float inter = w * h;
-            const float uni = ar + bx[4 * n + b] - inter;
-            // disjoint boxes (almost every pair): 0 / union is +-0 <= threshold for every non-zero union -- no division needed
-            // to know it; a zero union (0 / 0 = NaN, dropped by numpy's `ovr <= thresh`) takes the division like the rest
-            if (inter == 0.0f && uni != 0.0f && uni == uni && nms_thresh >= 0.0f) continue;
-            const float ovr = inter / uni;
-            if (!(ovr <= nms_thresh)) dead[b] = 1;
+    for (int c0 = 0; c0 < n && nkept < cap; c0 += NMS_THREADS) {
+        const int cn = min(NMS_THREADS, n - c0);
+        float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, ar = 0.f;
+        bool dead = tid >= cn;
+        if (!dead) {
+            const float* r = d + 15L * ord[c0 + tid];
+            x1 = r[0]; y1 = r[1]; x2 = r[2]; y2 = r[3];
+            ar = (x2 - x1 + 1.0f) * (y2 - y1 + 1.0f);
+            for (int k = 0; k < nkept; ++k) {  // boxes kept from earlier chunks all precede this one in the order
+                const float w = fmaxf(0.0f, fminf(kx2[k], x2) - fmaxf(kx1[k], x1) + 1.0f);
+                const float h = fmaxf(0.0f, fminf(ky2[k], y2) - fmaxf(ky1[k], y1) + 1.0f);
+                const float inter = w * h;
+                const float ovr = inter / (kar[k] + ar - inter);
+                if (!(ovr <= nms_thresh)) { dead = true; break; }
+            }
         }
+        __syncthreads();  // the previous chunk's arrays are free (every thread has left its walk)
+        cx1[tid] = x1; cy1[tid] = y1; cx2[tid] = x2; cy2[tid] = y2; car[tid] = ar;
+        cdead[tid] = dead ? 1 : 0;
         __syncthreads();
+        for (int a = 0; a < cn; ++a) {
+            if (cdead[a]) continue;  // uniform: every thread reads the same flag behind the previous barrier
+            const float ax1 = cx1[a], ay1 = cy1[a], ax2 = cx2[a], ay2 = cy2[a], aar = car[a];
+            if (tid == 0) {
+                kept[nkept] = c0 + a;
+                kx1[nkept] = ax1; ky1[nkept] = ay1; kx2[nkept] = ax2; ky2[nkept] = ay2; kar[nkept] = aar;
+            }
+            if (++nkept >= cap) break;
+            if (tid > a && !dead) {
+                const float w = fmaxf(0.0f, fminf(ax2, x2) - fmaxf(ax1, x1) + 1.0f);
+                const float h = fmaxf(0.0f, fminf(ay2, y2) - fmaxf(ay1, y1) + 1.0f);
+                const float inter = w * h;
+                const float ovr = inter / (aar + ar - inter);
+                if (!(ovr <= nms_thresh)) { dead = true; cdead[tid] = 1; }
+            }
+            __syncthreads();
+        }
+        __syncthreads();  // tid 0's last kept entry is visible before the next chunk tests against it
     }
-    if (tid == 0) kept_n = nkept;
-    __syncthreads();
     // dets[keep][:top_k], then the rows with score >= threshold (retina_face_predictor.py:96-108)
-    const int nk = min(kept_n, min(top_k, 1024));
-    __shared__ int out_rows;
+    __syncthreads();
+    const int nk = min(nkept, cap);
     if (tid == 0) {
         int m = 0;
         for (int k = 0; k < nk; ++k) {
@@ -1756,7 +1771,6 @@ int k_face_nms(avcer_ctx* ctx, const float* dets, int T, int P, float conf_thres
     if (nms_top_k > NMS_MAX) return set_err(ctx, AVCER_EINVAL, "face_nms: nms_top_k %d exceeds %d", nms_top_k, NMS_MAX);
     static uint64_t attr_dev = 0;
     if (!((attr_dev >> (ctx->device & 63)) & 1)) {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)face_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)face_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SORT_MAX * 8));
         attr_dev |= 1ull << (ctx->device & 63);
     }
@@ -1770,8 +1784,7 @@ int k_face_nms(avcer_ctx* ctx, const float* dets, int T, int P, float conf_thres
         face_rank_kernel<<<dim3(cdiv(P, 256), T), 256, 0, st>>>(dets, P, conf_thresh, nms_top_k, order, count);
         CHECK_LAUNCH(ctx, "face_rank");
     }
-    const size_t lds = (size_t)std::min(nms_top_k, P) * 21 + 16;
-    face_nms_kernel<<<T, NMS_THREADS, lds, st>>>(dets, P, order, count, nms_top_k, nms_thresh, top_k, threshold, out, out_n);
+    face_nms_kernel<<<T, NMS_THREADS, 0, st>>>(dets, P, order, count, nms_top_k, nms_thresh, top_k, threshold, out, out_n);
     CHECK_LAUNCH(ctx, "face_nms");
     return AVCER_OK;
 }
