@@ -562,7 +562,8 @@ __global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const Bneck
                 const int py = sl / T11_PW, px = sl - py * T11_PW;
                 const int y = t11_y0 - 1 + py, x = t11_x0 - 1 + px;
                 const bool ok = sl < T11_PW * T11_PW && (unsigned)y < 55u && (unsigned)x < 55u;
-                const unsigned off = ok ? (unsigned)(((t11_b * 55 + y) * 55 + x) * (P * 4) + q * ROWB + ((slot ^ swz_key(sl)) << 4)) : OOB;
+                // chunk swizzle keyed by py * 11 + px, not by the slot py * 13 + px: see the fragment reads below
+                const unsigned off = ok ? (unsigned)(((t11_b * 55 + y) * 55 + x) * (P * 4) + q * ROWB + ((slot ^ swz_key(py * T11_E + px)) << 4)) : OOB;
                 if (ii < PIECES) dma16(t1rs, smem + q * (T11_SLOTS * ROWB) + ii * 1024, off);
             }
         // ---- conv2, CHANNEL-split across the waves: wave w owns output-channel tile w (16 stored rows of W2) for ALL 128 rows of
@@ -587,11 +588,18 @@ __global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const Bneck
 #define AVCER_T11_WAIT(N, KS) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(wq[(KS) % RING][0]), "+v"(wq[(KS) % RING][1]) :: "memory")
         static_assert(P == 64, "four waves, four channel tiles");
         int sb8[NPT];  // patch slot of this lane's position in each of the block's eight position tiles, at tap (0, 0)
+        // Swizzle index of the same position (round 6).  The 16 lanes of a fragment read hold 16 consecutive tile positions r; their
+        // SLOTS py * 13 + px jump by 2 at the end of a tile row, so they span 18 slot numbers and, keyed by the slot, two lane
+        // pairs landed on the same banks: 39 % of this form's LDS cycles were conflicts (profiles/experiments/README.md, "SQ
+        // counters of the chains").  Keyed by py * 11 + px = r + (a constant per tap) the 16 lanes are 16 CONSECUTIVE indices for
+        // every tap, the case the searched key serves without conflicts; the slot's own parity still alternates lane by lane.
+        int sq8[NPT];
 #pragma unroll
         for (int t = 0; t < NPT; ++t) {
             const int r = min(t * 16 + l15, T11_E * T11_E - 1);
             const int ry = r / T11_E, rx = r - ry * T11_E;
             sb8[t] = (ry + 1) * T11_PW + rx + 1;
+            sq8[t] = (ry + 1) * T11_E + rx + 1;
         }
         f32x4_t acc2c[NPT];
 #pragma unroll
@@ -605,7 +613,7 @@ __global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const Bneck
             __builtin_amdgcn_sched_barrier(0);
             if (ks + 3 < NKS) { AVCER_T11_LOAD(ks + 3); }
             const int tap = ks / NQ, q = ks % NQ;
-            const int toff = (tap / 3 - 1) * T11_PW + (tap % 3 - 1);
+            const int toff = (tap / 3 - 1) * T11_PW + (tap % 3 - 1), toffq = (tap / 3 - 1) * T11_E + (tap % 3 - 1);
             const char* plane = smem + q * (T11_SLOTS * ROWB);
             // the fragments of step ks are in their registers; the loads of up to three later steps may fly
             if (ks + 3 < NKS) AVCER_T11_WAIT(6, ks);
@@ -616,7 +624,10 @@ __global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const Bneck
             const spx8_t wh = __builtin_bit_cast(spx8_t, wq[ks % RING][0]), wl = __builtin_bit_cast(spx8_t, wq[ks % RING][1]);
 #pragma unroll
             for (int t = 0; t < NPT; ++t) {
-                const spx8_t ah = ldfrag(plane, sb8[t] + toff, g), al = ldfrag(plane, sb8[t] + toff, 4 + g);
+                const char* row_ = plane + (sb8[t] + toff) * ROWB;
+                const int key_ = swz_key(sq8[t] + toffq);
+                const spx8_t ah = *reinterpret_cast<const spx8_t*>(row_ + ((g ^ key_) << 4));
+                const spx8_t al = *reinterpret_cast<const spx8_t*>(row_ + (((4 + g) ^ key_) << 4));
                 mfma3(acc2c[t], wh, wl, ah, al);
             }
         }
