@@ -99,6 +99,8 @@ SIGNATURES = {
     "avcer_profile_read": (C.c_int, [c_ctx, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "avcer_profile_read_families": (C.c_int, [c_ctx, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                               C.POINTER(C.c_double)]),
+    "avcer_profile_read_launches": (C.c_int, [c_ctx, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.POINTER(C.c_int64)]),
     "avcer_debug_tap": (C.c_int, [c_ctx, C.c_char_p, C.c_void_p, C.c_size_t]),
     "avcer_debug_tap_copied": (C.c_int64, [c_ctx]),
 }

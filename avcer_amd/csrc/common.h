@@ -59,6 +59,8 @@ struct avcer_ctx {
     bool prof = false;
     std::vector<hipEvent_t> prof_ev;
     std::vector<int> prof_fam;  // kernel family of every event pair (AVCER_FAM_*)
+    struct ProfLaunch { double flops, bytes; long m, n, k; };
+    std::vector<ProfLaunch> prof_log;  // per event pair: algorithmic FLOPs, compulsory bytes and the contraction's M, N, K
     size_t prof_used = 0;
     // per kernel family since the last avcer_profile_read*: launches, algorithmic FLOPs and compulsory HBM bytes
     int64_t fam_launches[8] = {0};
@@ -97,7 +99,8 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
 // kernel families of the MFMA launches (avcer_profile_read_families; include/avcer_hip.h AVCER_FAM_*)
 enum { FAM_GEMM = 0, FAM_GEMM_WD = 1, FAM_CHAIN = 2, FAM_TAIL = 3, FAM_STEM = 4, FAM_SKINNY = 5, FAM_COUNT = 6 };
 // `flops` / `bytes`: algorithmic work and compulsory HBM traffic of the launch (operands read once + outputs written once)
-int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1, int family, double flops, double bytes);
+int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1, int family, double flops, double bytes, long M = 0,
+               long N = 0, long K = 0);
 
 // ---- fused.hip (split-fp16 mode only)
 // planes: fp16 hi plane [n][230][230][4] followed plane_bytes later by the lo plane; y: sp32 [n][55][55][64]

@@ -1288,7 +1288,8 @@ int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t
         // per position: T1 in (P), residual or downsample operand in (4P | ds_cin), OUT (4P) and T1' (P) out, 4 bytes per element
         const double bytes = 4.0 * ((double)M_in * planes + (double)M * (ds_cin ? ds_cin : 4 * planes) + (double)M * 4 * planes +
                                     (t1n ? (double)M * planes : 0.0));
-        TRY(prof_begin(ctx, st, &ev0, &ev1, FAM_CHAIN, 2.0 * (double)M * planes * (planes * (9.0 + 4.0 + (t1n ? 4.0 : 0.0)) + 4.0 * ds_cin), bytes));
+        TRY(prof_begin(ctx, st, &ev0, &ev1, FAM_CHAIN, 2.0 * (double)M * planes * (planes * (9.0 + 4.0 + (t1n ? 4.0 : 0.0)) + 4.0 * ds_cin), bytes, M,
+                       4 * planes, planes));
     }
     // Resident halo patch for the conv2 phase: planes 128 only (28x28: -5..7 % per launch).  At planes 64 (55x55) the patch
     // costs the third resident block (76 KiB of LDS) and measured +2..4 %, so that form keeps the per-tap gather.
@@ -1337,7 +1338,7 @@ int launch_bneck_tail(avcer_ctx* ctx, int planes, long M, const void* t2, const 
     p.M = (int)M; p.ovf = ctx->ovf;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // per position: T2 in (P), residual in (4P), OUT (4P) and T1' (P) out
-    TRY(prof_begin(ctx, st, &ev0, &ev1, FAM_TAIL, 2.0 * (double)M * planes * planes * 8.0, 4.0 * (double)M * planes * 10.0));
+    TRY(prof_begin(ctx, st, &ev0, &ev1, FAM_TAIL, 2.0 * (double)M * planes * planes * 8.0, 4.0 * (double)M * planes * 10.0, M, 4 * planes, planes));
     p.t1_bytes = (unsigned)(M * 4096L);
     bneck_tail2_kernel<256><<<dim3((int)((M + 127) / 128)), dim3(512), 0, st>>>(p);
     if (ev1) (void)hipEventRecord(ev1, st);

@@ -1187,7 +1187,8 @@ void launch_t(const GemmParams& p0, hipStream_t st) {
 
 // Live timing of the MFMA kernels (avcer_profile_enable): a pair of events around each launch, on the launch stream.
 // Records *ev0 now; the caller records *ev1 behind its launch.  Both stay null while profiling is off.
-int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1, int family, double flops, double bytes) {
+int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1, int family, double flops, double bytes, long M, long N,
+               long K) {
     *ev0 = *ev1 = nullptr;
     ctx->fam_launches[family] += 1;
     ctx->fam_flops[family] += flops;
@@ -1200,8 +1201,12 @@ int prof_begin(avcer_ctx* ctx, hipStream_t st, hipEvent_t* ev0, hipEvent_t* ev1,
             ctx->prof_ev.push_back(e);
         }
     }
-    if (ctx->prof_fam.size() < ctx->prof_ev.size() / 2) ctx->prof_fam.resize(ctx->prof_ev.size() / 2, 0);
+    if (ctx->prof_fam.size() < ctx->prof_ev.size() / 2) {
+        ctx->prof_fam.resize(ctx->prof_ev.size() / 2, 0);
+        ctx->prof_log.resize(ctx->prof_ev.size() / 2);
+    }
     ctx->prof_fam[ctx->prof_used / 2] = family;
+    ctx->prof_log[ctx->prof_used / 2] = {flops, bytes, M, N, K};
     *ev0 = ctx->prof_ev[ctx->prof_used++];
     *ev1 = ctx->prof_ev[ctx->prof_used++];
     (void)hipEventRecord(*ev0, st);
@@ -1302,7 +1307,8 @@ int launch_conv_gemm(avcer_ctx* ctx, const avcer_conv_desc& d, int dtype, const 
         // compulsory traffic: the input once (each position's taps overlap), the weights once, the output (+ residual) once
         const double in_el = (double)d.batch * d.in_h * d.in_w * d.cin * groups + (x2 ? (double)M * d.x2_cin : 0.0);
         const double bytes = in_el * es + (double)w_extent + (double)M * d.n * groups * (dtype == 1 ? 2 : 4) * (residual ? 2 : 1);
-        TRY(prof_begin(ctx, st, &ev0, &ev1, skinny ? FAM_SKINNY : wdirect ? FAM_GEMM_WD : FAM_GEMM, 2.0 * (double)M * (double)d.n * (double)K * groups, bytes));
+        TRY(prof_begin(ctx, st, &ev0, &ev1, skinny ? FAM_SKINNY : wdirect ? FAM_GEMM_WD : FAM_GEMM, 2.0 * (double)M * (double)d.n * (double)K * groups, bytes,
+                       M, (long)d.n * groups, K));
     }
     switch (dtype) {
         case 0: launch_t<0, 0>(p, st); break;  // f32

@@ -356,6 +356,19 @@ class Engine:
         self._check(self.lib.avcer_profile_read_families(self.ctx, n, ms, la, fl, by))
         return {name: (ms[i], int(la[i]), fl[i], by[i]) for i, name in enumerate(self.FAMILIES)}
 
+    def profile_read_launches(self, max_n: int = 8192):
+        """Launch by launch since profile_enable / the last read: list of dicts {family, ms, flops, bytes, m, n, k} in launch
+        order; synchronises.  Use instead of profile_read / profile_read_families."""
+        fam = np.zeros(max_n, np.int32)
+        ms, fl, by = np.zeros(max_n), np.zeros(max_n), np.zeros(max_n)
+        mnk = np.zeros((max_n, 3), np.int64)
+        n = C.c_int64(0)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        self._check(self.lib.avcer_profile_read_launches(self.ctx, max_n, vp(fam), vp(ms), vp(fl), vp(by), vp(mnk), C.byref(n)))
+        k = min(int(n.value), max_n)
+        return [dict(family=self.FAMILIES[fam[i]], ms=float(ms[i]), flops=float(fl[i]), bytes=float(by[i]), m=int(mnk[i, 0]),
+                     n=int(mnk[i, 1]), k=int(mnk[i, 2])) for i in range(k)]
+
     def debug_tap(self, name: str, numel: int, dtype=torch.float32):
         """Arm a one-shot tap; returns the destination tensor (filled by the next forward pass)."""
         dst = torch.zeros(numel, dtype=dtype, device=self.device)

@@ -67,7 +67,7 @@ enum {
  *      split weight buffers carry a trailer and AVCER_MODE_BF16X3 became AVCER_MODE_F16X3 (round 4).
  *   3: avcer_x3_overflow_count, avcer_profile_read_families; avcer_bneck_chain gained w2_frags (round 5).
  *   4: avcer_source_hash, avcer_set_static_back_batch, avcer_set_static_lanes, avcer_face_decode_batch, avcer_track_faces,
- *      avcer_lsap (round 6). */
+ *      avcer_lsap, avcer_profile_read_launches (round 6). */
 #define AVCER_ABI_VERSION 4
 int avcer_abi_version(void);
 /* Hash (16 hex digits) of the sources and headers this binary was compiled from, embedded at build time by
@@ -398,6 +398,12 @@ enum {
     AVCER_FAM_COUNT = 6
 };
 int avcer_profile_read_families(avcer_ctx* ctx, int n_fam, double* ms, int64_t* launches, double* flops, double* bytes);
+/* ... and launch by launch, in launch order (tools/wd_traffic.py matches this list with the dispatches of a rocprofv3 --pmc pass of
+ * the same step): family (AVCER_FAM_*), event milliseconds, algorithmic FLOPs, compulsory HBM bytes and the contraction's
+ * M, N, K (mnk [3 * max_n]) of up to max_n launches; *n = launches recorded since avcer_profile_enable / the last read.  Use
+ * INSTEAD of the two reads above (all three rewind the event pool). */
+int avcer_profile_read_launches(avcer_ctx* ctx, int64_t max_n, int32_t* fam, double* ms, double* flops, double* bytes, int64_t* mnk,
+                                int64_t* n);
 
 /* Debug aid for parity tests: arm a one-shot tap; the next forward pass copies up to `bytes` raw bytes of the
  * named intermediate activation (first sub-batch) into dst_dev.  Names: static "pre", "stem_conv", "stem",
