@@ -108,6 +108,8 @@ int launch_stem_pool(avcer_ctx* ctx, const void* planes, size_t plane_bytes, con
                      const float* bias, void* y, int n, hipStream_t st);
 int launch_stem_pool_u8(avcer_ctx* ctx, const uint8_t* frames, int in_h, int in_w, const void* w_x3, const float* scale,
                         const float* bias9, void* y, int n, hipStream_t st);
+int launch_stem_pool_face(avcer_ctx* ctx, const uint8_t* frames, int h, int w, int rgb, const void* w_x3, const float* scale,
+                          const float* bias, void* y, int n, hipStream_t st);
 // conv2 + conv3 (+ residual) of one bottleneck and conv1 of the next block (t1n / w1n null when there is none);
 // ds_cin = 0: x [M][4 planes] is the residual; ds_cin = 64: x [M][64] is the downsample operand and w3 is [4 planes][planes + 64];
 // all activations sp32, weights split-fp16 (scaled, row-permuted) with the BN scale folded in (packing.py: *.wf, c3d.w)

@@ -102,6 +102,10 @@ struct StemParams {
     char* Y;               // sp32 [n][55][55][64]
     int n;
     unsigned* ovf;         // the context's range-contract counter (split_dev.h sp_commit)
+    // FACE form (stem_pool_u8_kernel<true>: the detector's stem, any frame size): stem map oh x ow, pooled map mh x mw, tiles of
+    // 8 x 7 pooled outputs per frame, channel order of the frames, the integer channel means of the net's (B, G, R) inputs
+    int oh, ow, mh, mw, tiles_y, tiles_x, swap_rb;
+    int mean[3];
 };
 
 constexpr int ST_TH = 8, ST_TW = 7;                       // pooled tile
@@ -259,6 +263,16 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(const StemParams p) {
 //    one tap row per step (counted wait: the tile requested at the top of a step may still be in flight at its barrier), and
 //    the BN + ReLU image is parked and pooled in two halves of 32 channels (32 KiB instead of 64).  The block is a serial
 //    chain -- patch, MFMAs, image, pool, store -- so what hides one block's latencies is the other blocks of its CU.
+//
+// FACE = true (round 6): the stem of the RetinaFace body (torchvision ResNet-50: conv 7x7/2 pad 3, BN, ReLU, max-pool 3x3/2 pad 1;
+// retina_face.py:46-76, retina_face_predictor.py:59-66) on frames of ANY size.  Same tiling -- a block = 8 x 7 pooled outputs, the
+// 17 x 15 stem positions under them, a 39 x 36-pixel patch -- with the window origins of symmetric padding (patch origin
+// (4 py0 - 5, 4 px0 - 5); stem row -1 / column -1 and those past the map are the pool's padding and are skipped).  The net's
+// input is pixel - (104, 117, 123): INTEGER means, so the mean-subtracted value itself is exact in fp16 -- no lo half, two
+// MFMAs per product, zero padding is exactly zero and no border classes are needed (the BN shift is the plain one).
+// Replaces face_pre_kernel + the f32-input stem contraction + maxpool3s2p1_kernel: 0.9 + 7.9 + 3.2 ms per 750 frames of
+// 640 x 360 (profiles/r06_face_trace_before_stem.txt), the stem map [n,180,320,64] written and read once each for nothing.
+template <bool FACE>
 __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p) {
     constexpr int NK = 7, WRING = 3;
     constexpr int PROWS = 2 * (ST_RH - 1) + NK, PCH = (2 * (ST_RW - 1) + 8) / 2;  // 39 patch rows of 18 16-byte chunks (36 pixels)
@@ -271,8 +285,9 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = blk / (ST_TY * ST_TX), t = blk % (ST_TY * ST_TX);
-    const int ty = t / ST_TX, tx = t % ST_TX;
+    const int tiles_x = FACE ? p.tiles_x : ST_TX, tiles = FACE ? p.tiles_y * p.tiles_x : ST_TY * ST_TX;
+    const int b = blk / tiles, t = blk % tiles;
+    const int ty = t / tiles_x, tx = t % tiles_x;
     const int lrow8 = lane >> 3, slot = lane & 7;
     const float wmul = split_wmul(p.W, 64 * NK * ROWB);
     const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W), (short)0, 64 * NK * ROWB, 0x00020000);
@@ -297,7 +312,8 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
         // (pixels outside the image and chunks past the patch load a valid byte and are zeroed afterwards), so nothing here
         // branches around a load and the three passes cost one memory round trip, not six
         const uint8_t* fr = p.F + (long)b * p.in_h * p.in_w * 3;
-        const bool resize = p.in_h != 224 || p.in_w != 224;
+        const bool resize = !FACE && (p.in_h != 224 || p.in_w != 224);
+        const int ih = FACE ? p.in_h : 224, iw = FACE ? p.in_w : 224, org = FACE ? 5 : 2;  // extent of the (resized) image, padding offset
         constexpr int PASSES = (NCH + 255) / 256;
         uint8_t raw[PASSES][2][3];
         bool ok[PASSES][2];
@@ -305,15 +321,15 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
         for (int j = 0; j < PASSES; ++j) {
             const int ci = min(j * 256 + tid, NCH - 1);
             const int prow = ci / PCH, pc = ci - prow * PCH;
-            const int iy = 4 * ST_TH * ty + prow - 2;
-            int sy = min(max(iy, 0), 223);
+            const int iy = 4 * ST_TH * ty + prow - org;
+            int sy = min(max(iy, 0), ih - 1);
             if (resize) sy = min((int)(((double)sy + 0.5) * ((double)p.in_h / 224.0)), p.in_h - 1);  // PIL NEAREST
 #pragma unroll
             for (int px = 0; px < 2; ++px) {
-                const int ix = 4 * ST_TW * tx + 2 * pc + px - 2;
-                int sx = min(max(ix, 0), 223);
+                const int ix = 4 * ST_TW * tx + 2 * pc + px - org;
+                int sx = min(max(ix, 0), iw - 1);
                 if (resize) sx = min((int)(((double)sx + 0.5) * ((double)p.in_w / 224.0)), p.in_w - 1);
-                ok[j][px] = (unsigned)iy < 224u && (unsigned)ix < 224u;
+                ok[j][px] = (unsigned)iy < (unsigned)ih && (unsigned)ix < (unsigned)iw;
                 const uint8_t* q = fr + ((long)sy * p.in_w + sx) * 3;
                 raw[j][px][0] = q[0]; raw[j][px][1] = q[1]; raw[j][px][2] = q[2];
             }
@@ -325,8 +341,16 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
 #pragma unroll
             for (int px = 0; px < 2; ++px) {
                 // [B G R 0]; integers up to 255 need 8 significant bits: the fp16 is exact
-                const uint32_t lo2 = (uint32_t)f2sp((float)raw[j][px][2]) | ((uint32_t)f2sp((float)raw[j][px][1]) << 16);
-                const uint32_t hi2 = (uint32_t)f2sp((float)raw[j][px][0]);
+                uint32_t lo2, hi2;
+                if constexpr (FACE) {  // pixel - integer mean, |.| <= 151: exact as well; frames are BGR unless swap_rb
+                    const int c0 = (int)raw[j][px][p.swap_rb ? 2 : 0] - p.mean[0], c1 = (int)raw[j][px][1] - p.mean[1];
+                    const int c2 = (int)raw[j][px][p.swap_rb ? 0 : 2] - p.mean[2];
+                    lo2 = (uint32_t)f2sp((float)c0) | ((uint32_t)f2sp((float)c1) << 16);
+                    hi2 = (uint32_t)f2sp((float)c2);
+                } else {
+                    lo2 = (uint32_t)f2sp((float)raw[j][px][2]) | ((uint32_t)f2sp((float)raw[j][px][1]) << 16);
+                    hi2 = (uint32_t)f2sp((float)raw[j][px][0]);
+                }
                 wds[2 * px] = ok[j][px] ? lo2 : 0u;
                 wds[2 * px + 1] = ok[j][px] ? hi2 : 0u;
             }
@@ -393,7 +417,7 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
                 const int ry = row / ST_RW, rx = row - ry * ST_RW;
                 const int cy = 2 * ST_TH * ty + ry, cx = 2 * ST_TW * tx + rx;
                 const int cls = 3 * (cy == 0 ? 0 : (cy >= 110 ? 2 : 1)) + (cx == 0 ? 0 : (cx >= 110 ? 2 : 1));
-                const float4 bi = *reinterpret_cast<const float4*>(p.bias9 + cls * 64 + ch);
+                const float4 bi = *reinterpret_cast<const float4*>(FACE ? p.bias + ch : p.bias9 + cls * 64 + ch);
                 const int chunk = 2 * g + fh;  // 16-byte chunk of the 32-channel row
                 *reinterpret_cast<float4*>(smem + row * 128 + ((chunk ^ (row & 7)) << 4)) =
                     make_float4(relu_nan(acc[fn][fm][0] * sc.x + bi.x), relu_nan(acc[fn][fm][1] * sc.y + bi.y),
@@ -405,7 +429,7 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
             const int pp = tid >> 2, c8 = tid & 3;  // pooled position of the tile, group of 8 channels of this half
             const int ppy = pp / ST_TW, ppx = pp - ppy * ST_TW;
             const int py = ST_TH * ty + ppy, px = ST_TW * tx + ppx;
-            if (pp < ST_TH * ST_TW && py < 55 && px < 55) {
+            if (pp < ST_TH * ST_TW && py < (FACE ? p.mh : 55) && px < (FACE ? p.mw : 55)) {
                 float m[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) m[j] = 0.f;  // post-ReLU values are >= 0
@@ -415,6 +439,10 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) {
                         const int row = (2 * ppy + dy) * ST_RW + 2 * ppx + dx;
+                        if constexpr (FACE) {  // region row r <-> stem row 2 py0 - 1 + r: the pool's padding and the map's end are skipped
+                            const int cy = 2 * py - 1 + dy, cx = 2 * px - 1 + dx;
+                            if ((unsigned)cy >= (unsigned)p.oh || (unsigned)cx >= (unsigned)p.ow) continue;
+                        }
                         const float4 u = *reinterpret_cast<const float4*>(smem + row * 128 + (((2 * c8) ^ (row & 7)) << 4));
                         const float4 v = *reinterpret_cast<const float4*>(smem + row * 128 + (((2 * c8 + 1) ^ (row & 7)) << 4));
                         const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
@@ -425,7 +453,7 @@ __global__ void __launch_bounds__(256, 3) stem_pool_u8_kernel(const StemParams p
                 for (int j = 0; j < 8; ++j) if (anynan[j]) m[j] = NAN;  // like torch's max-pool
                 spx8_t hi, lo;
                 split8v(m, hi, lo, ovm);
-                const long e = (((long)b * 55 + py) * 55 + px) * 64 + 32 * half + c8 * 8;
+                const long e = (((long)b * (FACE ? p.mh : 55) + py) * (FACE ? p.mw : 55) + px) * 64 + 32 * half + c8 * 8;
                 char* yp = p.Y + sp32_byte(e);
                 *reinterpret_cast<spx8_t*>(yp) = hi;
                 *reinterpret_cast<spx8_t*>(yp + 64) = lo;
@@ -1242,12 +1270,39 @@ int launch_stem_pool_u8(avcer_ctx* ctx, const uint8_t* frames, int in_h, int in_
     p.W = (const char*)w_x3; p.scale = scale; p.Y = (char*)y; p.n = n; p.ovf = ctx->ovf;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     TRY(prof_begin(ctx, st, &ev0, &ev1, FAM_STEM, 2.0 * n * 112.0 * 112.0 * 64 * 147, (double)n * ((double)in_h * in_w * 3 + 55.0 * 55 * 64 * 4)));
-    stem_pool_u8_kernel<<<dim3(n * ST_TY * ST_TX), dim3(256), 0, st>>>(p);
+    stem_pool_u8_kernel<false><<<dim3(n * ST_TY * ST_TX), dim3(256), 0, st>>>(p);
     if (ev1) (void)hipEventRecord(ev1, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "stem_pool_u8 launch: %s", hipGetErrorString(e));
     ctx->gemm_launches += 1;
     ctx->gemm_flops += 2.0 * n * 112.0 * 112.0 * 64 * 147;
+    return AVCER_OK;
+}
+
+// The detector's stem (stem_pool_u8_kernel<true>): frames u8 [n][h][w][3] (BGR unless rgb) -> sp32 [n][mh][mw][64], mh = ceil(ceil(h/2)/2).
+int launch_stem_pool_face(avcer_ctx* ctx, const uint8_t* frames, int h, int w, int rgb, const void* w_x3, const float* scale,
+                          const float* bias, void* y, int n, hipStream_t st) {
+    if (!frames || !w_x3 || !scale || !bias || !y || n <= 0 || h <= 0 || w <= 0) return set_err(ctx, AVCER_EINVAL, "stem_pool_face: bad arguments");
+    StemParams p;
+    memset(&p, 0, sizeof(p));
+    p.F = frames; p.in_h = h; p.in_w = w; p.bias = bias;
+    p.W = (const char*)w_x3; p.scale = scale; p.Y = (char*)y; p.n = n; p.ovf = ctx->ovf;
+    p.oh = (h - 1) / 2 + 1; p.ow = (w - 1) / 2 + 1;
+    p.mh = (p.oh - 1) / 2 + 1; p.mw = (p.ow - 1) / 2 + 1;
+    p.tiles_y = (p.mh + ST_TH - 1) / ST_TH; p.tiles_x = (p.mw + ST_TW - 1) / ST_TW;
+    p.swap_rb = rgb ? 1 : 0;
+    p.mean[0] = 104; p.mean[1] = 117; p.mean[2] = 123;  // retina_face_predictor.py:59-65, in the net's (B, G, R) order
+    const long grid = (long)n * p.tiles_y * p.tiles_x;
+    if (grid >= (1L << 31)) return set_err(ctx, AVCER_EINVAL, "stem_pool_face: %d frames of %d x %d are too many tiles for one launch", n, h, w);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const double flops = 2.0 * n * (double)p.oh * p.ow * 64 * 147;
+    TRY(prof_begin(ctx, st, &ev0, &ev1, FAM_STEM, flops, (double)n * ((double)h * w * 3 + (double)p.mh * p.mw * 64 * 4), (long)n * p.oh * p.ow, 64, 147));
+    stem_pool_u8_kernel<true><<<dim3((unsigned)grid), dim3(256), 0, st>>>(p);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "stem_pool_face launch: %s", hipGetErrorString(e));
+    ctx->gemm_launches += 1;
+    ctx->gemm_flops += flops;
     return AVCER_OK;
 }
 

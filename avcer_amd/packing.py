@@ -161,6 +161,7 @@ def pack_face(sd) -> "OrderedDict[str, np.ndarray]":
     stem = np.zeros((64, 8, 8, 4), np.float32)
     stem[:, :7, :7, :3] = w.transpose(0, 2, 3, 1)
     out["stem.w"] = stem.reshape(64, 256)
+    out["stem7.w"] = np.ascontiguousarray(stem[:, :7].reshape(64, 224))  # 7 tap rows only: the fused stem of the x3 mode
     out["stem.s"], out["stem.b"] = _bn_fold(sd, "body.bn1", eps)
     for li, (planes, blocks, _) in enumerate(RESNET_STAGES, start=1):
         for b in range(blocks):
