@@ -12,8 +12,9 @@ import sys
 d = sys.argv[1]
 f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "face_pre_kernel" in r["Kernel_Name"]]
-# a 750-frame pass is three sub-passes (273 + 273 + 204 frames): the last pass begins at the third face_pre launch from the end
+# every sub-pass of the detector begins with its stem: the fused stem_pool_u8_kernel<true> in the x3 mode, face_pre_kernel otherwise
+starts = [i for i, r in enumerate(rows) if "stem_pool_u8_kernel" in r["Kernel_Name"] or "face_pre_kernel" in r["Kernel_Name"]]
+# a 750-frame pass is three sub-passes (273 + 273 + 204 frames): the last pass begins at the third such launch from the end
 first = starts[-3] if len(starts) >= 3 else starts[0]
 t0 = int(rows[first]["Start_Timestamp"])
 total, by = 0.0, {}
