@@ -182,7 +182,9 @@ def test_seven_class_variant(engine, golden):
     assert eng.audio_classes == 7
     wav = torch.from_numpy(synth.waveforms(777, 2, 32000))
     ref = golden("audio_model7")["logits"]
-    for mode, tol in ((MODE_FP32, 1e-4), (MODE_F16X3, 8e-4)):  # measured 9e-6 / 7.7e-5
+    # measured (round 6): f32 mode max|dlogit| 1.2e-5 / max|dprob| 1.3e-6, x3 6.7e-6 / 2.4e-7 -- one tolerance for both (the 8e-4 the
+    # x3 mode had here dated from the bf16 operand pairs of rounds 1-3: 7.7e-5)
+    for mode, tol in ((MODE_FP32, 1e-4), (MODE_F16X3, 1e-4)):
         out = eng.audio_forward(wav, normalize=True, mode=mode).cpu().numpy()
         assert out.shape == (2, 7)
         p_got = torch.softmax(torch.from_numpy(out), 1).numpy()
