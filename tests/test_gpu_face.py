@@ -121,6 +121,27 @@ def test_nms_order_sort_and_counting_forms_agree(engine):
     assert res[0] == res[1] == keep.tolist() and len(keep) > 100
 
 
+@pytest.mark.parametrize("n", [6000, 12000])
+def test_nms_order_with_thousands_of_candidates(engine, n):
+    """The candidate order sorts the next power of two of the candidate COUNT (2048 ... 16384 keys: four instantiations of the
+    unrolled bitonic passes); here 6000 and 12000 candidates -- the 8192- and 16384-key sorts, the bench's synthetic detector is the
+    latter -- on clustered boxes with tied scores, so that the walk keeps few boxes and the plain-loop oracle finishes in seconds.
+    The kept list is a function of the whole order: a single misplaced key shows."""
+    rng = np.random.default_rng(n)
+    centres = rng.uniform(50, 1500, (60, 2)).astype(np.float32)
+    c = centres[rng.integers(0, 60, n)] + rng.normal(0, 3, (n, 2)).astype(np.float32)
+    wh = rng.uniform(60, 90, (n, 2)).astype(np.float32)
+    score = np.round(rng.uniform(0.03, 1.0, n), 3).astype(np.float32)           # ~970 distinct values: ties everywhere
+    d = np.zeros((1, n, 15), np.float32)
+    d[0, :, :4], d[0, :, 4], d[0, :, 5] = np.concatenate([c - wh / 2, c + wh / 2], 1), score, np.arange(n)
+    out, cnt = engine.face_nms(d, conf_thresh=0.02, nms_thresh=0.4, nms_top_k=5000, top_k=750, threshold=0.05)
+    got = out[0, :int(cnt[0]), 5].cpu().numpy().astype(int).tolist()
+    inds = np.where(score > 0.02)[0]
+    keep = inds[of.nms(d[0, inds, :5], 0.4, 5000, stable=True)][:750]          # the 5000 best of them, ties higher index first
+    keep = keep[score[keep] >= 0.05]
+    assert len(inds) == n and 30 < len(keep) < 750 and got == keep.tolist()
+
+
 def test_decode_batch_equals_per_frame_decode(engine):
     size = tuple(int(v) for v in G["size_a"])
     pri = of.prior_boxes(size)

@@ -242,3 +242,27 @@ def test_kernel_families_follow_the_batch(engine_static):
     # the same graph either way: FLOPs per frame agree to the padding of the skinny tiles' own accounting (none: algorithmic)
     f1, f100 = sum(v[2] for v in one.values()), sum(v[2] for v in many.values())
     assert abs(f100 / 100 - f1) < 1e-6 * f1
+
+
+def test_profile_launch_log_matches_the_family_sums(engine_static):
+    """avcer_profile_read_launches (tools/wd_traffic.py matches it with a rocprofv3 counter pass): one entry per MFMA launch in
+    launch order with its family, event time, algorithmic FLOPs, compulsory bytes and the contraction's M, N, K -- the same
+    launches and the same sums the per-family read reports for the same call."""
+    frames = torch.from_numpy(synth.face_frames(3, 100))
+    engine_static.static_forward(frames, MODE_F16X3)
+    torch.cuda.synchronize()
+    engine_static.profile_enable(True)
+    engine_static.static_forward(frames, MODE_F16X3)
+    fams = engine_static.profile_read_families()
+    engine_static.static_forward(frames, MODE_F16X3)
+    log = engine_static.profile_read_launches()
+    engine_static.profile_enable(False)
+    assert len(log) == sum(v[1] for v in fams.values()) and log[0]["family"] == "stem_pool_kernel"
+    for name, (ms, launches, flops, nbytes) in fams.items():
+        mine = [l for l in log if l["family"] == name]
+        assert len(mine) == launches
+        assert abs(sum(l["flops"] for l in mine) - flops) <= 1e-9 * max(flops, 1) and abs(sum(l["bytes"] for l in mine) - nbytes) <= 1e-9 * max(nbytes, 1)
+    gemms = [l for l in log if l["family"].startswith("conv_gemm")]
+    assert all(l["ms"] > 0 for l in log) and all(abs(2.0 * l["m"] * l["n"] * l["k"] - l["flops"]) <= 1e-9 * l["flops"] for l in gemms)
+    # layer3's first 3 x 3 convolution of the 100 frames: 19600 positions, 256 channels out, K = 9 x 256
+    assert any((l["m"], l["n"], l["k"]) == (100 * 14 * 14, 256, 2304) for l in gemms)
