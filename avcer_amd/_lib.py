@@ -51,6 +51,7 @@ SIGNATURES = {
     "avcer_set_static_batch": (C.c_int, [c_ctx, C.c_int]),
     "avcer_set_static_back_batch": (C.c_int, [c_ctx, C.c_int]),
     "avcer_set_static_lanes": (C.c_int, [c_ctx, C.c_int]),
+    "avcer_set_static_lane_range": (C.c_int, [c_ctx, C.c_int, C.c_int]),
     "avcer_static_forward_nchw": (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             c_stream]),
     "avcer_gather_windows": (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, c_stream]),

@@ -44,7 +44,8 @@ struct avcer_ctx {
     int aud_classes = 0;
     int static_batch = 1024;  // frames per internal pass of the static CNN (4 GiB buffer-descriptor limit at f32)
     int static_back = 0;      // frames per back pass of the static CNN (0: two front passes; avcer_set_static_back_batch)
-    int static_lanes = 2;     // calls of 128-512 frames as two half-batches on two streams (avcer_set_static_lanes)
+    int static_lanes = 2;     // calls of lane_min .. lane_max frames as two half-batches on two streams (avcer_set_static_lanes)
+    int lane_min = 32, lane_max = 2048;  // avcer_set_static_lane_range (tools/two_lane_sweep.py: two lanes win from 16 to 2048 frames)
     hipStream_t lane_stream = nullptr;  // the second lane's stream, created on first use, and its fork / join events
     hipEvent_t lane_ev[2] = {nullptr, nullptr};
     int block_slots = 512;    // 2 x hipDeviceProp_t::multiProcessorCount: what grid_rounds() divides a grid by

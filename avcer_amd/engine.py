@@ -136,9 +136,12 @@ class Engine:
         if back is not None:
             self._check(self.lib.avcer_set_static_back_batch(self.ctx, int(back)))
 
-    def set_static_lanes(self, lanes: int):
-        """2 (default): static-CNN calls of 128-512 frames run as two half-batches on two streams; 1: always serial."""
+    def set_static_lanes(self, lanes: int, min_frames: int | None = None, max_frames: int | None = None):
+        """2 (default): mid-sized static-CNN calls run as two half-batches on two streams; 1: always serial.  min / max frames:
+        the call sizes that take the two-lane schedule."""
         self._check(self.lib.avcer_set_static_lanes(self.ctx, int(lanes)))
+        if min_frames is not None or max_frames is not None:
+            self._check(self.lib.avcer_set_static_lane_range(self.ctx, int(min_frames or 128), int(max_frames or 512)))
 
     # ------------------------------------------------------------------ forward passes
     def static_forward(self, frames_u8, mode: int = MODE_DEFAULT):

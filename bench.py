@@ -143,6 +143,7 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="skip the per-model BASELINE configs 2 and 3")
     ap.add_argument("--no-overlap", action="store_true", help="timed steps on ONE stream (default: the audio branch runs on "
                                                              "its own HIP stream beside the visual branch)")
+    ap.add_argument("--one-lane", action="store_true", help="A/B: avcer_set_static_lanes(1) -- every static-CNN call on one stream")
     ap.add_argument("--no-events", action="store_true", help="skip the separate evented pass (the roofline object is then empty)")
     ap.add_argument("--no-run-inference", action="store_true", help="skip configs.run_inference (one 30 s video through run.py)")
     return ap.parse_args()
@@ -652,6 +653,8 @@ def main():
     pipe = AVPipeline(device=local_rank, seed=42, mode=modes[args.mode])
     if args.no_overlap:
         pipe.overlap_branches = False  # the library default (two streams) is what the headline times
+    if args.one_lane:
+        pipe.engine.set_static_lanes(1)
     log("generating inputs")
     frames, wav = make_inputs(args.clips, rank, device)
     n_total = args.clips * world

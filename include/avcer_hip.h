@@ -66,7 +66,7 @@ enum {
  *   2: avcer_conv_desc grew r_sub / r_h / r_w / tile_m, avcer_bneck_chain gained out_step, avcer_set_option left (round 3);
  *      split weight buffers carry a trailer and AVCER_MODE_BF16X3 became AVCER_MODE_F16X3 (round 4).
  *   3: avcer_x3_overflow_count, avcer_profile_read_families; avcer_bneck_chain gained w2_frags (round 5).
- *   4: avcer_source_hash, avcer_set_static_back_batch, avcer_set_static_lanes, avcer_face_decode_batch, avcer_track_faces,
+ *   4: avcer_source_hash, avcer_set_static_back_batch, avcer_set_static_lanes, avcer_set_static_lane_range, avcer_face_decode_batch, avcer_track_faces,
  *      avcer_lsap, avcer_profile_read_launches (round 6). */
 #define AVCER_ABI_VERSION 4
 int avcer_abi_version(void);
@@ -115,12 +115,17 @@ int avcer_set_static_batch(avcer_ctx* ctx, int frames);
  * front pass).  The late layers' grids are small, so the back wants as many frames per launch as the 4 GiB descriptors allow
  * whatever the front pass is.  A scheduling knob like the one above: results do not depend on it. */
 int avcer_set_static_back_batch(avcer_ctx* ctx, int frames);
-/* Lanes of a static-CNN call: 2 (default) = a call of 128-512 frames runs as two half-batches on two HIP streams (the context's
- * own second stream, forked from and joined into `stream` by events; a second workspace): the grids of stages 3-4 are under one
- * round of block slots at those sizes and the two halves fill each other's tails (-4 % at 256 frames, -6 % at 512).  1 = always
- * on `stream` alone.  Results are bit-identical either way (a frame's result does not depend on the batch around it); calls made
- * while avcer_profile_enable is on or a debug tap is armed are serial regardless, so that per-launch events stay meaningful. */
+/* Lanes of a static-CNN call: 2 (default) = a call of 32-2048 frames (avcer_set_static_lane_range) runs as two half-batches on two
+ * HIP streams (the context's own second stream, forked from and joined into `stream` by events; a second workspace): below a few
+ * thousand frames the grids of stages 3-4 are a fraction of a round of block slots, and the two halves fill each other's tails:
+ * -4 % at 32 frames, -8 ... -12 % at 48-192, -5 % at 256-512, -2 ... -3 % at 640-1536, -1.7 % at 2048 (tools/two_lane_sweep.py,
+ * profiles/r06_two_lane_sweep.txt; at 8 frames +4 %: latency chains).  1 = always on `stream` alone.  Results are bit-identical
+ * either way (a frame's result does not depend on the batch around it); calls made while avcer_profile_enable is on or a debug tap
+ * is armed are serial regardless, so that per-launch events stay meaningful. */
 int avcer_set_static_lanes(avcer_ctx* ctx, int lanes);
+/* The call sizes that take the two-lane schedule: min_frames <= n <= max_frames, 2 <= min <= max <= 4096 (default 32 .. 2048).
+ * A scheduling knob: results do not depend on it. */
+int avcer_set_static_lane_range(avcer_ctx* ctx, int min_frames, int max_frames);
 
 /* The same model on an already preprocessed tensor, i.e. the exact argument of the reference's
  * `pth_model_static(x)`:  x f32 [n,3,224,224] (BGR, mean-subtracted).   ref: get_prob_video.py:103-109 */

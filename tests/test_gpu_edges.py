@@ -192,10 +192,10 @@ def test_front_and_back_pass_sizes_do_not_show_in_any_result(engine_static):
         eng.set_static_batch(1024, back=0)
 
 
-@pytest.mark.parametrize("n", [256, 301])
+@pytest.mark.parametrize("n", [33, 256, 301, 1100])
 def test_two_lane_split_of_mid_sized_calls_is_bit_identical(engine_static, n):
-    """avcer_static_forward runs calls of 128-512 frames as two half-batches on two HIP streams (api.hip static_forward_impl;
-    BASELINE config 2 is 256 frames).  The split must not show: serial (avcer_set_static_lanes(1)) and two-lane results are
+    """avcer_static_forward runs calls of 32-2048 frames as two half-batches on two HIP streams (api.hip static_forward_impl;
+    BASELINE config 2 is 256 frames; 1100 frames: each lane runs its own front / back passes).  The split must not show: serial (avcer_set_static_lanes(1)) and two-lane results are
     equal bit for bit, an odd count splits 151 + 150, and the caller's stream sees the second lane's outputs (the join)."""
     eng = engine_static
     frames = torch.from_numpy(synth.face_frames(31, n)).to(eng.device)
@@ -208,10 +208,16 @@ def test_two_lane_split_of_mid_sized_calls_is_bit_identical(engine_static, n):
             # consumed on the caller's stream right away, without a device synchronisation in between
             same = [torch.equal(a, b) for a, b in zip(one, two)]
             assert all(same), same
-        x32 = [t.clone() for t in eng.static_forward(frames[:130], MODE_FP32)]
+        m = min(n, 130)
+        x32 = [t.clone() for t in eng.static_forward(frames[:m], MODE_FP32)]
         eng.set_static_lanes(1)
-        assert all(torch.equal(a, b) for a, b in zip(x32, eng.static_forward(frames[:130], MODE_FP32)))
+        assert all(torch.equal(a, b) for a, b in zip(x32, eng.static_forward(frames[:m], MODE_FP32)))
+        # the range knob: a call outside it is serial (same bits, of course), bad ranges are refused
+        eng.set_static_lanes(2, 2, 16)
+        assert all(torch.equal(a, b) for a, b in zip(one, eng.static_forward(frames, MODE_F16X3)))
+        with pytest.raises(AvcerError):
+            eng.set_static_lanes(2, 64, 32)
         with pytest.raises(AvcerError):
             eng.set_static_lanes(3)
     finally:
-        eng.set_static_lanes(2)
+        eng.set_static_lanes(2, 32, 2048)

@@ -21,6 +21,7 @@ def run(batch, what="static"):
     from avcer_amd.engine import MODE_F16X3, Engine
 
     eng = Engine(0)
+    eng.set_static_lanes(1)  # one stream: the trace lists the launches of a call in order
     if what == "audio":   # `batch` windows of 4 s
         eng.load_audio(synth.audio_state_dict(42))
         wav = torch.from_numpy(synth.waveforms(5678, batch, 64000)).cuda()
