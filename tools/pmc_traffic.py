@@ -71,7 +71,7 @@ def main():
         commit = None
     res = {"kernel": "MFMA kernels: conv_gemm*, bneck_kernel, bneck_tail2_kernel, stem_pool_kernel / stem_pool_u8_kernel (all instantiations)",
            "clips_per_gpu": clips, "commit": commit or None, "kernel_source_hash": kernel_source_hash(),
-           "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-secondary --no-cpu --no-configs --no-events --no-overlap",
+           "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-secondary --no-cpu --no-configs --no-events --no-overlap --one-lane",
            "profiled_steps": steps, "hbm_gb_per_step_mfma_kernels": tot / steps / 1e9, "hbm_gb_per_step_all_kernels": everything / steps / 1e9,
            "per_kernel": {r[1][-60:]: {"launches": r[2], "read_gb": r[3] / 1e9, "write_gb": r[4] / 1e9} for r in rows[:12]},
            "launches": n, "hbm_bytes_per_launch": tot / n,

@@ -8,11 +8,11 @@ O=gpurun_out/refresh
 PART=${1:-all}   # main | face | all (two gpurun calls of <= 20 minutes: `bash tools/refresh_profiles.sh main`, then `... face`)
 mkdir -p "$O"
 if [ "$PART" != face ]; then
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o x3 -- python3 bench.py --steps 5 --warmup 2 --no-secondary --no-cpu --no-configs --no-overlap > "$O/stats.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o x3 -- python3 bench.py --steps 5 --warmup 2 --no-secondary --no-cpu --no-configs --no-overlap --one-lane > "$O/stats.log" 2>&1
 echo "stats done"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_FETCH_SIZE" -- python3 bench.py --steps 1 --warmup 1 --no-secondary --no-cpu --no-configs --no-events --no-overlap > "$O/pmc_f.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_FETCH_SIZE" -- python3 bench.py --steps 1 --warmup 1 --no-secondary --no-cpu --no-configs --no-events --no-overlap --one-lane > "$O/pmc_f.log" 2>&1
 echo "fetch done"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_WRITE_SIZE" -- python3 bench.py --steps 1 --warmup 1 --no-secondary --no-cpu --no-configs --no-events --no-overlap > "$O/pmc_w.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_WRITE_SIZE" -- python3 bench.py --steps 1 --warmup 1 --no-secondary --no-cpu --no-configs --no-events --no-overlap --one-lane > "$O/pmc_w.log" 2>&1
 echo "write done"
 python3 tools/pmc_traffic.py "$O/pmc_FETCH_SIZE" "$O/pmc_WRITE_SIZE" --out "$O/traffic_x3.json" > "$O/traffic_x3.txt"
 find "$O/stats" -name "*kernel_stats.csv" -exec cp {} "$O/kernel_stats.csv" \;
