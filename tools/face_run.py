@@ -2,9 +2,10 @@
 """Stage 0 of the reference's real run (get_face_images.py:38-63): RetinaFace-R50 over the 750 frames of a 30 s 640 x 360
 video -- network, box decoding, device NMS, rows back on the host -- as `avcer_amd.face_tiles.RetinaFacePredictor.batch` runs it.
 
-    python3 tools/face_run.py [passes=3] [fam]         wall time per pass; `fam`: per kernel family from HIP events
-    rocprofv3 --kernel-trace --stats --output-format csv -d out -o face -- python3 tools/face_run.py 3
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d out -- python3 tools/face_run.py 1     (then WRITE_SIZE; tools/pmc_table.py)
+    python3 tools/face_run.py [passes=3] [fam] [serial]   wall time per pass; `fam`: per kernel family from HIP events (serial by
+                                                            itself); `serial`: avcer_set_static_lanes(1) -- one stream, for traces
+    rocprofv3 --kernel-trace --stats --output-format csv -d out -o face -- python3 tools/face_run.py 3 serial
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d out -- python3 tools/face_run.py 1 serial   (then WRITE_SIZE; tools/pmc_table.py)
 """
 import os
 import sys
@@ -23,6 +24,8 @@ if __name__ == "__main__":
     fam = "fam" in sys.argv
     n, h, w = 750, 360, 640
     eng = Engine(0)
+    if "serial" in sys.argv:
+        eng.set_static_lanes(1)  # the detector's batches on one stream: per-kernel durations of a trace mean something
     det = RetinaFacePredictor(eng, synth.to_torch(synth.retina_state_dict(42)), mode=MODE_F16X3)
     frames = torch.from_numpy(synth.video_frames(77, n, h, w)).cuda()
     det.batch(frames)  # warm-up: weight split, workspace
@@ -36,7 +39,8 @@ if __name__ == "__main__":
         found = det.batch(frames)
         torch.cuda.synchronize()
         dts.append((time.perf_counter() - t0) * 1e3)
-    print(f"detector over {n} frames of {w}x{h}: " + ", ".join(f"{d:.1f}" for d in dts) + f" ms per pass ({sum(len(d) for d in found)} boxes kept)")
+    how = "one lane" if ("serial" in sys.argv or fam) else "two lanes (the default)"
+    print(f"detector over {n} frames of {w}x{h}, {how}: " + ", ".join(f"{d:.1f}" for d in dts) + f" ms per pass ({sum(len(d) for d in found)} boxes kept)")
     if fam:
         fams = eng.profile_read_families()
         eng.profile_enable(False)

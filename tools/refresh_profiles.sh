@@ -43,15 +43,15 @@ timeout -k 10 300 python3 tools/ab_layers.py --frames 2048 --only "l4." > "$O/ab
 fi
 if [ "$PART" = main ]; then ls -la "$O"; exit 0; fi
 # stage 0 (detector) evidence: kernel stats, HBM traffic, launch-by-launch trace, families
-timeout -k 10 200 python3 tools/face_run.py 3 fam 2>&1 | grep -v amdgpu.ids > "$O/face_families.txt" || true
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/face_stats" -o face -- python3 tools/face_run.py 3 > "$O/face_stats.log" 2>&1
+{ timeout -k 10 200 python3 tools/face_run.py 3 2>&1; timeout -k 10 200 python3 tools/face_run.py 3 fam 2>&1; } | grep -v amdgpu.ids > "$O/face_families.txt" || true
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/face_stats" -o face -- python3 tools/face_run.py 3 serial > "$O/face_stats.log" 2>&1
 find "$O/face_stats" -name "*kernel_stats.csv" -exec cp {} "$O/face_kernel_stats.csv" \;
 rm -rf "$O/face_stats"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_ff" -- python3 tools/face_run.py 1 > "$O/pmc_ff.log" 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_fw" -- python3 tools/face_run.py 1 > "$O/pmc_fw.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_ff" -- python3 tools/face_run.py 1 serial > "$O/pmc_ff.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_fw" -- python3 tools/face_run.py 1 serial > "$O/pmc_fw.log" 2>&1
 (cd tools && python3 pmc_table.py "../$O/pmc_ff" "../$O/pmc_fw" 40) > "$O/face_traffic.txt" 2>&1 || true
 rm -rf "$O/pmc_ff" "$O/pmc_fw"
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/ftr" -o t -- python3 tools/face_run.py 1 > "$O/ftr.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/ftr" -o t -- python3 tools/face_run.py 1 serial > "$O/ftr.log" 2>&1
 python3 tools/face_trace.py "$O/ftr" > "$O/face_trace.txt" 2>&1 || true
 rm -rf "$O/ftr"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/ri" -o t -- python3 tools/trace_run_inference.py run > "$O/ri.log" 2>&1
