@@ -21,6 +21,7 @@ def run():
 
     pipe = AVPipeline(device=0, seed=42, mode=MODE_F16X3)
     pipe.overlap_branches = False  # one stream: the trace lists the launches of a step in order
+    pipe.engine.set_static_lanes(1)  # ... and the static CNN's 2048 frames on one lane
     frames = torch.from_numpy(synth.face_frames(1234, 128 * 16)).reshape(128, 16, 224, 224, 3).cuda()
     wav = torch.from_numpy(synth.waveforms(5678, 128, 32000)).cuda()
     for _ in range(3):
