@@ -102,6 +102,22 @@ def test_batch_equals_frame_by_frame(engine_face, sd_retina):
         np.testing.assert_array_equal(together[t], pred(frames[t], rgb=False))
 
 
+@pytest.mark.parametrize("mode", [MODE_F16X3, MODE_FP32])
+def test_two_lane_detector_batches_are_bit_identical(engine_face, mode):
+    """Batches of at least 16 frames run as two lanes (api.hip face_forward_impl: the halves on two streams, equal passes inside a
+    lane); 21 frames of 96 x 128 split 11 + 10.  Same bits as on one lane, and the outputs are complete on the caller's stream."""
+    frames = synth.video_frames(21, 21, 96, 128)
+    try:
+        engine_face.set_static_lanes(1)
+        one = [t.clone() for t in engine_face.face_forward(frames, mode)]
+        engine_face.set_static_lanes(2)
+        for _ in range(2):
+            two = engine_face.face_forward(frames, mode)
+            assert all(torch.equal(a, b) for a, b in zip(one, two))
+    finally:
+        engine_face.set_static_lanes(2)
+
+
 def test_rejects_bad_arguments(engine_face):
     with pytest.raises(Exception):
         engine_face.face_forward(np.zeros((1, 16, 16, 3), np.uint8), MODE_FP32)

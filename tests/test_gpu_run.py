@@ -60,3 +60,26 @@ def test_run_inference_needs_a_first_track(engine_all):
     with pytest.raises(FileNotFoundError):
         arun.run_inference(engine_all, frames, np.zeros(1600, np.float32), 25,
                            detections=[np.zeros((0, 15), np.float32)] * 2)
+
+
+def test_failed_call_leaves_nothing_behind_for_the_next_one(engine_all):
+    """The reference's failure path (no face track 00: os.listdir fails, get_prob_video.py:79) unwinds `run_inference` while its
+    audio branch is already queued on the side stream.  The call joins that stream on the way out (avcer_amd/run.py), so the next
+    video on the same engine starts clean: same results as on a fresh call, range-contract counter at 0, and a tracker error
+    (zero-area detection: TypeError in the reference) surfaces as ValueError naming the frame, from the native tracker."""
+    frames, script = golden_frames(), golden_script()
+    total, fps, sr = len(frames), 25, 16000
+    wav = synth.waveforms(99, 1, int(total / fps * sr))[0]
+    ref = arun.run_inference(engine_all, frames, wav, fps, detections=script, mode=MODE_F16X3)
+    for _ in range(2):
+        with pytest.raises(FileNotFoundError):
+            arun.run_inference(engine_all, frames, wav, fps, detections=[np.zeros((0, 15), np.float32)] * total, mode=MODE_F16X3)
+    bad = [np.asarray(d).copy() for d in script]
+    k = next(i for i, d in enumerate(bad) if len(d))
+    bad[k][0, 2] = bad[k][0, 0]                                    # zero width: no track id in the reference
+    with pytest.raises(ValueError, match=f"frame {k}"):
+        arun.run_inference(engine_all, frames, wav, fps, detections=bad, mode=MODE_F16X3)
+    assert engine_all.x3_overflow_count(reset=False) == 0
+    again = arun.run_inference(engine_all, frames, wav, fps, detections=script, mode=MODE_F16X3)
+    for key in ("static_probs", "dynamic_logits", "audio_rows", "compound_prob", "av", "records"):
+        np.testing.assert_array_equal(again[key], ref[key])
