@@ -128,11 +128,10 @@ inline double grid_rounds(long tiles, long slots) {
 }
 
 // w2_frags: the conv2 weights once more in MFMA fragment order (k_weight_frags), or null: selects the spatial-tile form
-// where it applies (planes 64, 55 x 55 images, a next conv1).  next_planes: output channels of the next conv1 where they differ
-// from planes (128 behind the LAST planes-64 block: conv1 of the next stage's first block; w1n [128][256], t1n [M][128])
+// where it applies (planes 64, 55 x 55 images, a next conv1)
 int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, int out_step,
                  void* out, void* t1n, const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n,
-                 const float* b1n, hipStream_t st, const void* w2_frags = nullptr, int next_planes = 0);
+                 const float* b1n, hipStream_t st, const void* w2_frags = nullptr);
 
 // conv3 + residual + ReLU of a planes-256 bottleneck and conv1 of the next block in one launch (t2 = conv2 output [M][256])
 int launch_bneck_tail(avcer_ctx* ctx, int planes, long M, const void* t2, const void* x, void* out, void* t1n, const void* w3,

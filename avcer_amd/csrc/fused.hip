@@ -512,16 +512,9 @@ struct BneckParams {
 // offset on the fragment reads, and the conv2 weights never touch LDS: every wave loads its W2 fragments (fragment-order
 // copy, 1 KiB per load, L2-resident) straight into registers two K-steps ahead.  After the patch barrier the conv2 phase has
 // no barrier, no DMA and no wait on HBM.  Same K order (tap, channel chunk) as the gather form: bit-identical results.
-//
-// NP (round 6): output channels of the NEXT conv1 when they differ from P -- the LAST block of stage 1 computes conv1 of stage 2's
-// first block (256 -> 128) behind its own output, which that 1x1 convolution would otherwise re-read from HBM as a launch of its
-// own (0.30 ms per 1024 frames in the recognition CNN, 1.35 ms per 273 detector frames: a pure HBM stream).  The weight tile of a
-// K-step has NP rows, the accumulators NP / 16 tiles; everything else is the NEXT path.  With SUB = 2 the next conv1 runs on the
-// compact grid, which is where video.py's stride-2 conv1 evaluates it.
-template <int P, int BM, bool NEXT, int NQX, bool PATCH, int SUB = 1, bool T11 = false, int NP = P>
-__global__ void __launch_bounds__(256, (P == 64 && NP == P) ? 3 : 2) bneck_kernel(const BneckParams p) {  // NP = 128: 64 more accumulators, two blocks per CU
-    static_assert(SUB == 1 || (SUB == 2 && NQX == 0 && !PATCH && (!NEXT || NP != P)), "the strided form is the last block of a stage");
-    static_assert(NP == P || (NEXT && NP == 2 * P && !T11 && !PATCH && NQX == 0), "a wider next conv1 exists for the stage's last block");
+template <int P, int BM, bool NEXT, int NQX, bool PATCH, int SUB = 1, bool T11 = false>
+__global__ void __launch_bounds__(256, P == 64 ? 3 : 2) bneck_kernel(const BneckParams p) {
+    static_assert(SUB == 1 || (SUB == 2 && !NEXT && NQX == 0 && !PATCH), "the strided form is the plain last block of a stage");
     static_assert(!T11 || (P == 64 && BM == 128 && !PATCH && SUB == 1), "the spatial-tile form serves planes 64 at full resolution");
     constexpr int NQ = P / 32;            // K-steps of a P-channel contraction
     constexpr int NQT = NQ + NQX;         // K-steps of conv3 (+ downsample)
@@ -530,14 +523,14 @@ __global__ void __launch_bounds__(256, (P == 64 && NP == P) ? 3 : 2) bneck_kerne
     constexpr int NT = BM / 64;           // 16-position tiles per wave
     constexpr int NG = 4 * P / 32;        // 32-channel groups of the block output
     constexpr int TILE_A = (BM + P) * ROWB;
-    constexpr int TILE_B = (32 * NQT + NP) * ROWB;
+    constexpr int TILE_B = (32 * NQT + P) * ROWB;
     constexpr int PHASE_A = T11 ? NQ * T11_SLOTS * ROWB : (PATCH ? PSLOTS * ROWB + 2 * P * ROWB : 2 * TILE_A);  // patch (+ two weight tiles), or two full stages
     constexpr int TILES = PHASE_A > 2 * TILE_B ? PHASE_A : 2 * TILE_B;
-    constexpr int NBIAS = 5 * P + NP;  // b2 [P], b1n [NP], b3 [4P]: read back as broadcast float4 pairs in the epilogues
+    constexpr int NBIAS = 6 * P;  // b2 [P], b1n [P], b3 [4P]: read back as broadcast float4 pairs in the epilogues
     __shared__ __attribute__((aligned(16))) char smem[TILES + NBIAS * 4];
     float* sbias = reinterpret_cast<float*>(smem + TILES);
     for (int i = threadIdx.x; i < NBIAS; i += 256)
-        sbias[i] = i < P ? p.b2[i] : (i < P + NP ? (NEXT ? p.b1n[i - P] : 0.f) : p.b3[i - P - NP]);
+        sbias[i] = i < P ? p.b2[i] : (i < 2 * P ? (NEXT ? p.b1n[i - P] : 0.f) : p.b3[i - 2 * P]);
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     sp_flags_t ovm = 0;  // lanes that split a finite |x| >= 65520 into an fp16 pair (split_dev.h sp_commit)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -563,12 +556,12 @@ __global__ void __launch_bounds__(256, (P == 64 && NP == P) ? 3 : 2) bneck_kerne
 
     // accumulator multipliers of the three scaled weight splits (trailers behind the matrices: split_dev.h)
     const float s2 = split_wmul(p.W2, P * 9 * P * 4), s3 = split_wmul(p.W3, 4 * P * (P + 32 * NQX) * 4);
-    const float s1n = NEXT ? split_wmul(p.W1N, 4 * P * NP * 4) : 1.f;
+    const float s1n = NEXT ? split_wmul(p.W1N, 4 * P * P * 4) : 1.f;
     (void)s1n;
     const auto t1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.T1), (short)0, (int)p.t1_bytes, 0x00020000);
     const auto w2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W2), (short)0, P * 9 * P * 4, 0x00020000);
     const auto w3rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.W3), (short)0, 4 * P * (P + 32 * NQX) * 4, 0x00020000);
-    const auto w1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(NEXT ? p.W1N : p.W3), (short)0, 4 * P * NP * 4, 0x00020000);
+    const auto w1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(NEXT ? p.W1N : p.W3), (short)0, 4 * P * P * 4, 0x00020000);
 
     // ---------------- phase A: T2 = relu(bn2(conv3x3(T1))), K = 9 taps x P channels, accumulators [P][BM/4] per wave
     constexpr int A_ISS = BM / 32;  // A-tile DMA instructions per wave per K-step (8 rows each)
@@ -842,8 +835,7 @@ __global__ void __launch_bounds__(256, (P == 64 && NP == P) ? 3 : 2) bneck_kerne
     }
 
     // ---------------- weights of output group G -> LDS buffer (G & 1)
-    constexpr int W1_ISS = NP / 32;
-    unsigned g3_off[NQT], g1_off[W1_ISS];  // W3: NQT tiles of 32 rows = NQT*4 instr per block -> NQT per wave; W1N: NP/8 instr -> NP/32 per wave
+    unsigned g3_off[NQT], g1_off[W_ISS];  // W3: NQT tiles of 32 rows = NQT*4 instr per block -> NQT per wave; W1N: P/8 instr -> P/32 per wave
 #pragma unroll
     for (int j = 0; j < NQT; ++j) {
         // instruction j of this wave fills rows [8 wave, 8 wave + 8) of K-step tile j of W3's 32-row group
@@ -851,8 +843,8 @@ __global__ void __launch_bounds__(256, (P == 64 && NP == P) ? 3 : 2) bneck_kerne
         g3_off[j] = (unsigned)((long)row * (NQT * ROWB) + j * ROWB + ((slot ^ swz_key(row)) << 4));
     }
 #pragma unroll
-    for (int j = 0; j < W1_ISS; ++j) {
-        const int row = wave * (W1_ISS * 8) + j * 8 + lrow8;
+    for (int j = 0; j < W_ISS; ++j) {
+        const int row = wave * (W_ISS * 8) + j * 8 + lrow8;
         g1_off[j] = (unsigned)((long)row * (4 * P * 4) + ((slot ^ swz_key(row)) << 4));
     }
     auto issue_group = [&](int G) {
@@ -861,8 +853,8 @@ __global__ void __launch_bounds__(256, (P == 64 && NP == P) ? 3 : 2) bneck_kerne
         for (int j = 0; j < NQT; ++j) dma16(w3rs, base + j * (32 * ROWB) + wave * 1024, g3_off[j], (unsigned)(G * 32 * NQT * ROWB));
         if constexpr (NEXT) {
 #pragma unroll
-            for (int j = 0; j < W1_ISS; ++j)
-                dma16(w1rs, base + NQT * (32 * ROWB) + wave * (W1_ISS * 1024) + j * 1024, g1_off[j], (unsigned)(G * ROWB));
+            for (int j = 0; j < W_ISS; ++j)
+                dma16(w1rs, base + NQT * (32 * ROWB) + wave * (W_ISS * 1024) + j * 1024, g1_off[j], (unsigned)(G * ROWB));
         }
     };
     issue_group(0);  // the tile buffers are free: phase A ended on a barrier
@@ -932,9 +924,9 @@ __global__ void __launch_bounds__(256, (P == 64 && NP == P) ? 3 : 2) bneck_kerne
             split8v(v, t2h[q][t], t2l[q][t], ovm);
         }
     }
-    f32x4_t acc1[NEXT ? NP / 16 : 1][NT];
+    f32x4_t acc1[NEXT ? P / 16 : 1][NT];
 #pragma unroll
-    for (int i = 0; i < (NEXT ? NP / 16 : 1); ++i)
+    for (int i = 0; i < (NEXT ? P / 16 : 1); ++i)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc1[i][t] = f32x4_t{0};
     __syncthreads();  // group 0 has landed
@@ -970,7 +962,7 @@ __global__ void __launch_bounds__(256, (P == 64 && NP == P) ? 3 : 2) bneck_kerne
                     for (int t = 0; t < NT; ++t) mfma3(acc3[tp][t], wh, wl, xh[q][t], xl[q][t]);
                 }
         }
-        const float* bp = sbias + P + NP + 32 * G + 8 * g;
+        const float* bp = sbias + 2 * P + 32 * G + 8 * g;
         const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
         spx8_t oh[NT], ol[NT];
 #pragma unroll
@@ -992,7 +984,7 @@ __global__ void __launch_bounds__(256, (P == 64 && NP == P) ? 3 : 2) bneck_kerne
         if (G + 2 < NG) load_res(G + 2, h, l);  // the slot just consumed
         if constexpr (NEXT) {
 #pragma unroll
-            for (int i = 0; i < NP / 16; ++i) {
+            for (int i = 0; i < P / 16; ++i) {
                 const spx8_t wh = ldfrag(w1t, i * 16 + l15, g), wl = ldfrag(w1t, i * 16 + l15, 4 + g);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) mfma3(acc1[i][t], wh, wl, oh[t], ol[t]);
@@ -1009,7 +1001,7 @@ __global__ void __launch_bounds__(256, (P == 64 && NP == P) ? 3 : 2) bneck_kerne
     // ---------------- T1' = relu(bn1'(conv1'(OUT)))
     if constexpr (NEXT) {
 #pragma unroll
-        for (int q = 0; q < NP / 32; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const float4 b0 = *reinterpret_cast<const float4*>(sbias + P + 32 * q + 8 * g), b1 = *reinterpret_cast<const float4*>(sbias + P + 32 * q + 8 * g + 4);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -1021,7 +1013,7 @@ __global__ void __launch_bounds__(256, (P == 64 && NP == P) ? 3 : 2) bneck_kerne
                 spx8_t hi, lo;
                 split8v(v, hi, lo, ovm);
                 if (m_ok[t]) {
-                    char* yp = p.T1N + (long)m_row[t] * (NP * 4) + q * 128 + 16 * g;  // m_row == the position wherever m_ok
+                    char* yp = p.T1N + (long)m_row[t] * (P * 4) + q * 128 + 16 * g;  // m_row == the position wherever m_ok
                     *reinterpret_cast<spx8_t*>(yp) = hi;
                     *reinterpret_cast<spx8_t*>(yp + 64) = lo;
                 }
@@ -1316,13 +1308,9 @@ int launch_stem_pool_face(avcer_ctx* ctx, const uint8_t* frames, int h, int w, i
 
 int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t1, const void* x, int ds_cin, int out_step,
                  void* out, void* t1n, const void* w2, const float* b2, const void* w3, const float* b3, const void* w1n,
-                 const float* b1n, hipStream_t st, const void* w2_frags, int next_planes) {
+                 const float* b1n, hipStream_t st, const void* w2_frags) {
     if (out_step != 1 && out_step != 2) return set_err(ctx, AVCER_EINVAL, "bneck: out_step %d (1 or 2)", out_step);
-    const int np = next_planes > 0 ? next_planes : planes;  // output channels of the next conv1 (w1n [np][4 planes], t1n [M][np])
-    if (np != planes && !(t1n && planes == 64 && np == 128 && !ds_cin))
-        return set_err(ctx, AVCER_EINVAL, "bneck: a next conv1 of %d channels exists behind a planes-64 block without downsample only (128)", np);
-    if (out_step == 2 && (ds_cin || (t1n && np == planes)))
-        return set_err(ctx, AVCER_EINVAL, "bneck: the strided form is the last block of a stage (no downsample; a next conv1 only as the next stage's: 128 channels)");
+    if (out_step == 2 && (t1n || ds_cin)) return set_err(ctx, AVCER_EINVAL, "bneck: the strided form is the last block of a stage (no next conv1, no downsample)");
     const int oh = (h - 1) / out_step + 1, ow = (w - 1) / out_step + 1;
     const long M = (long)nb * oh * ow, M_in = (long)nb * h * w;
     if (!t1 || !x || !out || !w2 || !w3 || !b2 || !b3 || M <= 0)
@@ -1347,15 +1335,15 @@ int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t
     constexpr int BM = 128;
     // The spatial-tile form (bneck_kernel<..., T11>): planes 64 with a next conv1 on 55 x 55 images (5 x 5 tiles of 11 x 11),
     // when the caller brought the fragment-order copy of the conv2 weights; one block per tile.
-    const bool t11 = planes == 64 && h == 55 && w == 55 && out_step == 1 && t1n && w2_frags && np == planes;
+    const bool t11 = planes == 64 && h == 55 && w == 55 && out_step == 1 && t1n && w2_frags;
     p.nblocks = t11 ? nb * 25 : (int)((M + BM - 1) / BM);
     const int grid = p.nblocks;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     {
         // per position: T1 in (P), residual or downsample operand in (4P | ds_cin), OUT (4P) and T1' (P) out, 4 bytes per element
         const double bytes = 4.0 * ((double)M_in * planes + (double)M * (ds_cin ? ds_cin : 4 * planes) + (double)M * 4 * planes +
-                                    (t1n ? (double)M * np : 0.0));
-        TRY(prof_begin(ctx, st, &ev0, &ev1, FAM_CHAIN, 2.0 * (double)M * planes * (planes * (9.0 + 4.0) + (t1n ? 4.0 * np : 0.0) + 4.0 * ds_cin), bytes, M,
+                                    (t1n ? (double)M * planes : 0.0));
+        TRY(prof_begin(ctx, st, &ev0, &ev1, FAM_CHAIN, 2.0 * (double)M * planes * (planes * (9.0 + 4.0 + (t1n ? 4.0 : 0.0)) + 4.0 * ds_cin), bytes, M,
                        4 * planes, planes));
     }
     // Resident halo patch for the conv2 phase: planes 128 only (28x28: -5..7 % per launch).  At planes 64 (55x55) the patch
@@ -1365,11 +1353,8 @@ int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t
     const int rows_worst = (w - 1 + BM + w - 1) / w + 2 + 2;
     const bool patch = planes == 128 && (long)h * w >= BM && rows_worst * (w + 2) <= 304;
     if (out_step == 2) {
-        if (planes == 64 && t1n) bneck_kernel<64, BM, true, 0, false, 2, false, 128><<<dim3(grid), dim3(256), 0, st>>>(p);
-        else if (planes == 64) bneck_kernel<64, BM, false, 0, false, 2><<<dim3(grid), dim3(256), 0, st>>>(p);
+        if (planes == 64) bneck_kernel<64, BM, false, 0, false, 2><<<dim3(grid), dim3(256), 0, st>>>(p);
         else bneck_kernel<128, BM, false, 0, false, 2><<<dim3(grid), dim3(256), 0, st>>>(p);
-    } else if (np != planes) {
-        bneck_kernel<64, BM, true, 0, false, 1, false, 128><<<dim3(grid), dim3(256), 0, st>>>(p);
     } else if (ds_cin) {
         if (t11) bneck_kernel<64, BM, true, 2, false, 1, true><<<dim3(grid), dim3(256), 0, st>>>(p);
         else bneck_kernel<64, BM, true, 2, false><<<dim3(grid), dim3(256), 0, st>>>(p);
@@ -1390,7 +1375,7 @@ int launch_bneck(avcer_ctx* ctx, int planes, int nb, int h, int w, const void* t
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(ctx, AVCER_EHIP, "bneck launch: %s", hipGetErrorString(e));
     ctx->gemm_launches += 1;
-    ctx->gemm_flops += 2.0 * (double)M * planes * (planes * (9.0 + 4.0) + (t1n ? 4.0 * np : 0.0) + 4.0 * ds_cin);
+    ctx->gemm_flops += 2.0 * (double)M * planes * (planes * (9.0 + 4.0 + (t1n ? 4.0 : 0.0)) + 4.0 * ds_cin);
     return AVCER_OK;
 }
 

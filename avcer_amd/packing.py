@@ -91,8 +91,6 @@ def _fold_fused_weights(out, li: int, blocks: int) -> None:
     """`*.wf` = weight rows times the BN scale, for the layers the x3 mode runs inside fused kernels (csrc/fused.hip), whose
     epilogues only add the BN shift.  Shared by the static CNN and the detector body: a bottleneck WITHOUT spatial stride has the
     same shape in both (video.py:43-60 puts a stage's stride on conv1 of its first block, torchvision on conv2 of the same block)."""
-    if li == 2:  # conv1 of stage 2's first block rides behind stage 1's last chain launch (fused.hip bneck_kernel NP): 256 -> 128
-        out["l2.0.c1.wf"] = np.ascontiguousarray(out["l2.0.c1.w"] * out["l2.0.c1.s"][:, None])
     if li <= 2:  # stages that run as fused chains conv2 -> conv3 (+x) -> next conv1:
         # stage 1 from its first block (stride 1; conv3 + downsample = c3d), stage 2 from its second block.
         for b in range(0 if li == 1 else 1, blocks):
