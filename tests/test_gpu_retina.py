@@ -121,3 +121,37 @@ def test_two_lane_detector_batches_are_bit_identical(engine_face, mode):
 def test_rejects_bad_arguments(engine_face):
     with pytest.raises(Exception):
         engine_face.face_forward(np.zeros((1, 16, 16, 3), np.uint8), MODE_FP32)
+
+
+def test_other_weight_draw_against_the_oracle_in_both_parity_modes(engine):
+    """The golden vectors pin seed 42; a second draw of the detector's synthetic weights against the oracle (96 x 128, two frames):
+    the fused stem / chains / tails of the x3 mode and the exact-f32 mode under the same gates."""
+    sd = synth.to_torch(synth.retina_state_dict(43))
+    engine.load_face(sd)
+    try:
+        frames = synth.video_frames(8, 2, 96, 128)
+        ref = [orf.retina_forward(sd, orf.preprocess(frames[i])) for i in range(2)]
+        for mode in (MODE_FP32, MODE_F16X3):
+            loc, conf, lm = (t.cpu().numpy() for t in engine.face_forward(frames, mode))
+            for i, (rl, rc, rm) in enumerate(ref):
+                assert np.abs(conf[i] - rc[0].numpy()).max() < 1e-4, mode
+                assert np.abs(loc[i] - rl[0].numpy()).max() < 1e-3 and np.abs(lm[i] - rm[0].numpy()).max() < 1e-3, mode
+    finally:
+        engine.load_face(synth.to_torch(synth.retina_state_dict(42)))
+
+
+def test_720p_frames_counting_order_and_other_tile_counts(engine_face, sd_retina):
+    """1280 x 720: 37840 priors per frame -- more than the LDS sort holds, so the candidate order comes from the counting kernel --,
+    stem tiles 23 x 46, layer-1 maps of 180 x 320.  The x3 mode against the exact-f32 mode of the library, and the predictor's batch
+    against frame-by-frame calls (same rows, ties included)."""
+    frames = synth.video_frames(5, 2, 720, 1280)
+    loc, conf, lm = (t.cpu().numpy() for t in engine_face.face_forward(frames, MODE_F16X3))
+    l32, c32, m32 = (t.cpu().numpy() for t in engine_face.face_forward(frames, MODE_FP32))
+    assert conf.shape == (2, 37840, 2) and np.isfinite(conf).all()
+    assert np.abs(conf - c32).max() < 1e-4 and np.abs(loc - l32).max() < 1e-3 and np.abs(lm - m32).max() < 1e-3
+    pred = ft.RetinaFacePredictor(engine_face, sd_retina, threshold=0.3, mode=MODE_F16X3)
+    together = pred.batch(frames, rgb=False)
+    for t in range(2):
+        one = pred(frames[t], rgb=False)
+        np.testing.assert_array_equal(together[t], one)
+    assert sum(len(d) for d in together) > 0

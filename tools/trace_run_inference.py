@@ -3,8 +3,9 @@
 and where it waits for the host -- per HIP queue the span and the summed kernel time of the LAST call, the gaps longer than
 100 us, and the kernels that own the time.
 
-    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ri -o t -- python3 tools/trace_run_inference.py run
+    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ri -o t -- python3 tools/trace_run_inference.py run [det]
     python3 tools/trace_run_inference.py show gpurun_out/ri
+(`det`: with the RetinaFace-R50 detector in front -- `with_detector` of the bench line -- instead of scripted detections)
 """
 import csv
 import glob
@@ -35,13 +36,25 @@ def run():
     frames = torch.from_numpy(synth.video_frames(77, n, h, w)).cuda()
     dets = bench.scripted_detections(n, h, w)
     wav = torch.from_numpy(synth.waveforms(78, 1, seconds * 16000)[0]).cuda()
+    kw = {"detections": dets}
+    if "det" in sys.argv:
+        from avcer_amd.face_tiles import RetinaFacePredictor
+
+        real = RetinaFacePredictor(pipe.engine, synth.to_torch(synth.retina_state_dict(42)), mode=MODE_F16X3)
+
+        class DetectorThenScript:  # the network, decode and NMS run; the scripted track is used behind them (synthetic weights find no faces)
+            def batch(self, fr, rgb=False):
+                real.batch(fr, rgb=rgb)
+                return dets
+
+        kw = {"detector": DetectorThenScript()}
     for i in range(4):
         torch.cuda.synchronize()
         if i == 3:
             torch.zeros(7, device="cuda").cumsum(0)  # marker launch: the last call starts behind it
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        arun.run_inference(pipe.engine, frames, wav, fps, detections=dets, mode=MODE_F16X3)
+        arun.run_inference(pipe.engine, frames, wav, fps, mode=MODE_F16X3, **kw)
         torch.cuda.synchronize()
         print(f"call {i}: {(time.perf_counter() - t0) * 1e3:.1f} ms", flush=True)
 
