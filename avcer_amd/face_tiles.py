@@ -89,17 +89,14 @@ class FaceDetections:
         most = int(cnt.max()) if len(cnt) else 0
         if not most:
             return [np.empty((0, 15), dtype=np.float32) for _ in range(len(cnt))]
-        # only the rows some frame kept cross to the host, through a page-locked buffer kept across calls (a pageable copy of
-        # the worst case -- 750 frames x 750 rows, 34 MB -- is 5 ms with the GPU idle behind it; pinned: ~1.3 ms)
-        shape = (int(rows.shape[0]), most, 15)
-        pin = self.__dict__.get("_pinned_rows")
-        if pin is None or pin.shape[0] < shape[0] or pin.shape[1] < shape[1]:
-            pin = self.__dict__["_pinned_rows"] = torch.empty((shape[0], max(shape[1], 64), 15), dtype=torch.float32, pin_memory=True)
-        host = pin[:shape[0], :most]
+        # only the rows some frame kept cross to the host, through a page-locked buffer (torch's host allocator caches the block from
+        # call to call; a pageable copy of the worst case -- 750 frames x 750 rows, 34 MB -- is 5 ms with the GPU idle behind it,
+        # pinned ~1.4 ms).  The per-frame arrays are VIEWS of that buffer, which they keep alive: no second copy on the host.
+        host = torch.empty((int(rows.shape[0]), most, 15), dtype=torch.float32, pin_memory=True)
         host.copy_(rows[:, :most], non_blocking=True)
         torch.cuda.current_stream(rows.device).synchronize()
         rows = host.numpy()
-        return [rows[t, :int(cnt[t])].copy() if cnt[t] else np.empty((0, 15), dtype=np.float32) for t in range(len(cnt))]
+        return [rows[t, :int(cnt[t])] if cnt[t] else np.empty((0, 15), dtype=np.float32) for t in range(len(cnt))]
 
 
 class RetinaFacePredictor:
