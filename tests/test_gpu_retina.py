@@ -61,7 +61,7 @@ def test_batch_and_rgb_against_oracle(engine_face, sd_retina):
     assert engine_face.lib.avcer_face_num_priors(150, 214) == len(of.prior_boxes((150, 214))) == loc.shape[1]
 
 
-@pytest.mark.parametrize("h,w,n", [(150, 214, 3), (70, 33, 2), (360, 640, 2)])
+@pytest.mark.parametrize("h,w,n", [(150, 214, 3), (70, 33, 2), (75, 101, 2), (360, 640, 2)])
 def test_x3_fused_body_against_oracle_and_fp32_mode(engine_face, sd_retina, h, w, n):
     """The x3 mode runs the body's stride-1 bottlenecks on the fused chain / tail kernels of the recognition CNN (api.hip
     face_forward_impl): odd extents (38 x 54 and 19 x 27 positions per frame in stages 1-2), a frame narrower than one tile row, and
@@ -82,6 +82,10 @@ def test_x3_fused_body_against_oracle_and_fp32_mode(engine_face, sd_retina, h, w
     l1, c1, m1 = (t.cpu().numpy() for t in engine_face.face_forward(frames[1:2], MODE_F16X3))
     np.testing.assert_array_equal(c1[0], conf[1])
     np.testing.assert_array_equal(l1[0], loc[1])
+    # RGB frames (the predictor's rgb=True: flipped first, retina_face_predictor.py:59-61) through the fused stem's own channel swap
+    lr, cr, mr = (t.cpu().numpy() for t in engine_face.face_forward(np.ascontiguousarray(frames[..., ::-1]), MODE_F16X3, rgb=True))
+    np.testing.assert_array_equal(cr, conf)
+    np.testing.assert_array_equal(lr, loc)
 
 
 def test_predictor_chain_matches_oracle_chain(engine_face, sd_retina):
