@@ -273,6 +273,16 @@ def test_native_assignment_equals_scipy_including_ties():
         assert rows[:k].tolist() == r_ref.tolist() and cols[:k].tolist() == c_ref.tolist(), (trial, cost)
         cases += 1
     assert cases == 600
+    # larger problems, both orientations, floats and tie-heavy integers (the augmenting paths get long: duals and tie rule matter)
+    for trial, (nr, nc) in enumerate([(20, 30), (40, 25), (33, 33), (64, 17), (5, 90)] * 4):
+        cost = rng.uniform(0, 1, (nr, nc)) if trial % 2 == 0 else rng.integers(0, 5, (nr, nc)).astype(np.float64)
+        cost = np.ascontiguousarray(cost, dtype=np.float64)
+        k = min(nr, nc)
+        rows, cols = np.full(k, -1, np.int32), np.full(k, -1, np.int32)
+        assert lib.avcer_lsap(nr, nc, cost.ctypes.data_as(ctypes.c_void_p), rows.ctypes.data_as(ctypes.c_void_p),
+                              cols.ctypes.data_as(ctypes.c_void_p)) == 0
+        r_ref, c_ref = linear_sum_assignment(cost)
+        assert rows.tolist() == r_ref.tolist() and cols.tolist() == c_ref.tolist(), (trial, nr, nc)
 
 
 def _track_native(lib, dets, w, h, iou=0.4, min_size=0.0):
