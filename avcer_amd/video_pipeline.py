@@ -7,6 +7,7 @@ per-frame tables are assembled by row gathers.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -125,3 +126,41 @@ def visual_forward(engine: Engine, frames_u8: torch.Tensor, present, fps: float,
         dyn = torch.zeros(n * t, 7, device=dev)
     stat, dyn = stat.view(n, t, 7), dyn.view(n, t, 7)
     return (stat[0], dyn[0]) if single else (stat, dyn)
+
+
+def read_face_dir(path_images: str, total_frames: int, track: str = "00"):
+    """The file side of `preprocess_video_and_predict` (get_prob_video.py:79-100): the face crops stage 0 wrote as
+    `<path_images>/<track>/NNNNNN.jpg`, one per frame in which the track was seen.  Returns (frames u8 [total_frames,224,224,3] RGB,
+    present bool [total_frames]): frame i is the JPEG `%06d.jpg` decoded to RGB and resized to 224 x 224 with PIL's NEAREST filter --
+    the very call `pth_processing` makes (data/utils.py:34) -- or zeros where the file does not exist.  PIL decodes here where the
+    reference decodes with cv2.imread; both sit on libjpeg, a decoder difference of a grey level cannot be excluded.
+    `os.listdir` of a missing track directory raises FileNotFoundError as in the reference."""
+    from PIL import Image
+
+    folder = os.path.join(path_images, track)
+    names = set(os.listdir(folder))
+    frames = np.zeros((total_frames, 224, 224, 3), dtype=np.uint8)
+    present = np.zeros(total_frames, dtype=bool)
+    for i in range(total_frames):
+        name = str(i).zfill(6) + ".jpg"
+        if name in names:
+            with Image.open(os.path.join(folder, name)) as img:
+                frames[i] = np.asarray(img.convert("RGB").resize((224, 224), Image.Resampling.NEAREST))
+            present[i] = True
+    return frames, present
+
+
+def preprocess_video_and_predict(engine: Engine, path_images: str = "", save_path: str = "", fps: float = 30, total_frames: int = 0,
+                                 flag_save_prob: bool = False, mode: int = MODE_DEFAULT):
+    """`get_prob_video.preprocess_video_and_predict` (get_prob_video.py:67-204) with the reference's argument meaning, on the HIP
+    path: the face-crop directory of one video in, the two per-frame tables out -- (dynamic logits, static probabilities), float32
+    [total_frames, 7] in DICT_EMO_VIDEO column order -- and `dynamic__<video>.csv` / `static__<video>.csv` under `save_path` when
+    `flag_save_prob` (the reference's files, io_formats.write_visual_csvs).  Heat maps (`flag_heatmaps`) need a backward pass and
+    are not part of this build."""
+    from . import io_formats
+
+    frames, present = read_face_dir(path_images, total_frames)
+    stat, dyn = visual_forward(engine, torch.from_numpy(frames), present, fps, mode)
+    if flag_save_prob:
+        io_formats.write_visual_csvs(stat, dyn, save_path, os.path.basename(path_images))
+    return dyn.cpu().numpy(), stat.cpu().numpy()

@@ -366,3 +366,31 @@ def test_native_tracker_reproduces_the_reference_generated_records():
     rc, rec = _track_native(lib, script, frames_w, frames_h)
     assert rc == 0
     np.testing.assert_array_equal(rec, G["track_records"])
+
+
+def test_read_face_dir_follows_the_reference_listing(tmp_path):
+    """video_pipeline.read_face_dir = the file side of preprocess_video_and_predict (get_prob_video.py:79-100): frame i comes from
+    `<dir>/00/%06d.jpg` if that file exists, decoded to RGB and resized with PIL NEAREST exactly as pth_processing does
+    (data/utils.py:34); missing frames are absent (zeros, present False); a missing track directory raises like os.listdir."""
+    from PIL import Image
+
+    from avcer_amd.video_pipeline import read_face_dir
+
+    rng = np.random.default_rng(0)
+    d = tmp_path / "vid" / "00"
+    d.mkdir(parents=True)
+    sizes = {0: (97, 80), 1: (224, 224), 3: (301, 190), 6: (50, 61)}
+    for i, (h, w) in sizes.items():
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(d / f"{i:06d}.jpg", quality=95)
+    (d / "notes.txt").write_text("ignored")
+    frames, present = read_face_dir(str(tmp_path / "vid"), 8)
+    assert frames.shape == (8, 224, 224, 3) and frames.dtype == np.uint8
+    assert present.tolist() == [i in sizes for i in range(8)]
+    for i in range(8):
+        if i in sizes:
+            ref = np.asarray(Image.open(d / f"{i:06d}.jpg").convert("RGB").resize((224, 224), Image.Resampling.NEAREST))
+            np.testing.assert_array_equal(frames[i], ref)
+        else:
+            assert not frames[i].any()
+    with pytest.raises(FileNotFoundError):
+        read_face_dir(str(tmp_path / "nothing"), 3)
