@@ -202,9 +202,9 @@ def test_two_granularity_schedule_small_passes(engine, sd_static, mode):
 
 
 def test_preprocess_video_and_predict_from_a_face_directory(engine, sd_static, sd_dynamic, tmp_path):
-    """The file-level mirror of get_prob_video.preprocess_video_and_predict: JPEG face crops of one track on disk (frames 2 and 5
-    missing, a leading miss) -> the two tables and the reference's CSV files; equal to visual_forward on the decoded arrays and,
-    through it, to the oracle's harness."""
+    """The file-level mirror of get_prob_video.preprocess_video_and_predict: JPEG face crops of one track on disk (a leading miss, a
+    miss before the first LSTM evaluation and one after it) -> the two tables and the reference's CSV files; equal to the oracle's
+    harness on the decoded arrays."""
     from PIL import Image
 
     from avcer_amd import io_formats, video_pipeline as vp
@@ -216,17 +216,19 @@ def test_preprocess_video_and_predict_from_a_face_directory(engine, sd_static, s
     d.mkdir(parents=True)
     total = 9
     for i in range(total):
-        if i in (0, 2, 5):
+        if i in (0, 2, 6):
             continue
         Image.fromarray(rng.integers(0, 256, (120 + 7 * i, 100 + 3 * i, 3), dtype=np.uint8)).save(d / f"{i:06d}.jpg", quality=92)
     dyn, stat = vp.preprocess_video_and_predict(engine, str(tmp_path / "clip7"), str(tmp_path / "out"), fps=25, total_frames=total,
                                                 flag_save_prob=True)
     frames, present = vp.read_face_dir(str(tmp_path / "clip7"), total)
-    assert present.tolist() == [i not in (0, 2, 5) for i in range(total)]
+    assert present.tolist() == [i not in (0, 2, 6) for i in range(total)]
     st_o, dy_o = ov.visual_forward(sd_static, sd_dynamic, frames, present, 25, batched=True)
     assert np.abs(stat - st_o).max() < 1e-4 and np.abs(dyn - dy_o).max() < 1e-3
     assert not stat[0].any() and not dyn[0].any()                      # before the first face: zero rows (get_prob_video.py:175-178)
-    np.testing.assert_array_equal(stat[2], stat[1])                    # a gap holds the last rows (:168-172)
+    assert not stat[2].any()                                           # a miss before the first LSTM evaluation (frame 5): zeros too
+    np.testing.assert_array_equal(stat[6], stat[5])                    # a miss after it holds the last rows (:168-172)
+    np.testing.assert_array_equal(dyn[6], dyn[5])
     back_s = io_formats.read_visual_csv(str(tmp_path / "out" / "static__clip7.csv"))
     back_d = io_formats.read_visual_csv(str(tmp_path / "out" / "dynamic__clip7.csv"))
     np.testing.assert_allclose(back_s, stat, rtol=0, atol=1e-7)
